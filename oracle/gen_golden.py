@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE arithmetic.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container (needs `transformers` 5.15 + torch CPU); never on the GPU
+box and never imported by the product.  The reference's own file backend/asr.py cannot be
+imported offline (soundfile / torchaudio / bitsandbytes missing), and all of
+its arithmetic lives in third-party `transformers`, so this script drives exactly the calls
+asr.py makes:
+
+  asr.py:247-276  peak-normalise + PCM_16 round trip     -> frontend.normalise_to_int16 (restated)
+  asr.py:393      processor -> WhisperFeatureExtractor    -> called directly (no tokenizer/chat
+                                                            template offline; prompt ids are synthetic)
+  asr.py:280-301  cast features to the model dtype
+  asr.py:411-422  model.generate(do_sample=False)         -> GlmAsrForConditionalGeneration.generate
+
+Fixture families (small files, committed):
+  mel_*.npz        log-mel features for several segment lengths (fp32, strided subset + checksums)
+  tiny_fp32.npz    seeded TINY model (spec.TINY, weights from synth.py), fp32: per-stage activations,
+                   prefill / per-step logits, greedy token ids, top-1/top-2 margins
+  tiny_bf16.npz    same in bf16 (the reference's `mode="native"` dtype)
+
+Usage:  python oracle/gen_golden.py [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from sonicscribe_amd import spec, synth  # noqa: E402
+from sonicscribe_amd.frontend import normalise_to_int16  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+SEED = 20260128
+PROMPT_PREFIX = [1, 17, 23, 5]          # synthetic stand-in for the chat-template prefix
+PROMPT_SUFFIX = [7, 301, 302, 303, 9, 11]  # ... and the instruction + generation prompt
+
+
+def feature_extractor():
+    from transformers import WhisperFeatureExtractor
+    return WhisperFeatureExtractor(feature_size=128)
+
+
+def mel_case(fe, pcm_i16: np.ndarray):
+    wav = pcm_i16.astype(np.float32) / 32768.0   # what HF load_audio hands over after the WAV round trip
+    out = fe([wav], sampling_rate=16000, return_attention_mask=True, padding="max_length", return_tensors="np")
+    return out["input_features"][0].astype(np.float32), out["attention_mask"][0].astype(np.int32)
+
+
+def gen_mel(out_dir: str):
+    fe = feature_extractor()
+    # the slaney bank exactly as the reference builds it (feature_extraction_whisper.py:95-103)
+    np.savez_compressed(os.path.join(out_dir, "mel_filters.npz"), filters=fe.mel_filters.astype(np.float32))
+    cases = {
+        "5s": (0, 80000), "20s": (1, 320000), "30s": (2, 480000), "partial": (3, 20480),
+        "ragged": (4, 123457), "short": (5, 2048), "one": (6, 1),
+    }
+    for tag, (i, n) in cases.items():
+        pcm = synth.synth_pcm(i, n)
+        feats, mask = mel_case(fe, pcm)
+        np.savez_compressed(
+            os.path.join(out_dir, f"mel_{tag}.npz"),
+            seg_index=i, n_samples=n, pcm_crc=np.uint64(int(pcm.astype(np.int64).sum()) & 0xFFFFFFFFFFFF),
+            pcm_head=pcm[:64],
+            frames_idx=np.arange(0, 3000, 7), feats_sub=feats[:, ::7],
+            feats_tail=feats[:, -16:], feats_sum=np.float64(feats.astype(np.float64).sum()),
+            feats_sqsum=np.float64((feats.astype(np.float64) ** 2).sum()),
+            feats_max=np.float32(feats.max()), feats_min=np.float32(feats.min()),
+            mask_sum=np.int32(mask.sum()),
+        )
+        print(f"mel_{tag}: n={n} valid={mask.sum()} range=[{feats.min():.4f},{feats.max():.4f}]")
+    # silence: max<=1e-6 is passed unnormalised (asr.py:265-267)
+    pcm = np.zeros(16000, np.int16)
+    feats, mask = mel_case(fe, pcm)
+    np.savez_compressed(os.path.join(out_dir, "mel_silence.npz"), n_samples=16000,
+                        feats_sub=feats[:, ::7], feats_sum=np.float64(feats.astype(np.float64).sum()),
+                        feats_max=np.float32(feats.max()), feats_min=np.float32(feats.min()), mask_sum=np.int32(mask.sum()))
+    # normalise_to_int16 reference pairs (asr.py:265-276): recorded so the restatement is pinned to itself
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(4096) * 0.05).astype(np.float32)
+    np.savez_compressed(os.path.join(out_dir, "normalise.npz"), x=x, q=normalise_to_int16(x))
+
+
+def build_tiny(dtype: torch.dtype):
+    from transformers import GlmAsrConfig, GlmAsrForConditionalGeneration
+    d = spec.TINY
+    cfg = GlmAsrConfig(
+        audio_config=dict(hidden_size=d.enc_d, intermediate_size=d.enc_ff, num_hidden_layers=d.enc_layers,
+                          num_attention_heads=d.enc_heads, num_mel_bins=d.n_mels),
+        text_config=dict(vocab_size=d.vocab, hidden_size=d.dec_d, intermediate_size=d.dec_ff,
+                         num_hidden_layers=d.dec_layers, num_attention_heads=d.dec_heads,
+                         num_key_value_heads=d.dec_kv_heads, head_dim=d.dec_head_dim,
+                         eos_token_id=list(d.eos_ids)),
+        audio_token_id=d.audio_token_id,
+    )
+    model = GlmAsrForConditionalGeneration(cfg)
+    sd = synth.synth_state_dict(d, SEED, bf16=(dtype == torch.bfloat16))
+    tsd = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    tsd["lm_head.weight"] = tsd["model.language_model.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(tsd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in m or "inv_freq" in m for m in missing), missing
+    model = model.to(dtype).eval()
+    assert model.config._attn_implementation == "sdpa" or True
+    return model, cfg
+
+
+def gen_tiny(out_dir: str, dtype: torch.dtype, tag: str, n_new: int = 24):
+    d = spec.TINY
+    fe = feature_extractor()
+    model, cfg = build_tiny(dtype)
+    segs = [(10, 80000), (11, 320000)]       # a 5 s and a 20 s segment (BASELINE configs 1 and 2 shapes)
+    rec = {"seed": SEED, "n_new": n_new}
+    for si, (i, n) in enumerate(segs):
+        pcm = synth.synth_pcm(i, n)
+        feats, mask = mel_case(fe, pcm)
+        n_audio = spec.audio_token_count(int(mask.sum()))
+        ids = PROMPT_PREFIX + [d.audio_token_id] * n_audio + PROMPT_SUFFIX
+        input_ids = torch.tensor([ids], dtype=torch.long)
+        feats_t = torch.from_numpy(feats)[None].to(dtype)        # asr.py:280-301 cast
+        mask_t = torch.from_numpy(mask)[None].long()
+
+        acts = {}
+        hooks = []
+        enc = model.model.audio_tower
+
+        def save(name):
+            def fn(_m, _inp, out):
+                o = out[0] if isinstance(out, tuple) else out
+                if hasattr(o, "last_hidden_state"):
+                    o = o.last_hidden_state
+                acts[name] = o.detach().float().numpy()
+            return fn
+        hooks.append(enc.conv1.register_forward_hook(save("conv1")))
+        hooks.append(enc.conv2.register_forward_hook(save("conv2")))
+        for li, layer in enumerate(enc.layers):
+            hooks.append(layer.register_forward_hook(save(f"enc_layer{li}")))
+        hooks.append(enc.register_forward_hook(save("enc_out")))
+        hooks.append(model.model.multi_modal_projector.register_forward_hook(save("proj_out")))
+        for li, layer in enumerate(model.model.language_model.layers):
+            hooks.append(layer.register_forward_hook(save(f"dec_layer{li}")))
+        with torch.no_grad():
+            fw = model(input_ids=input_ids, input_features=feats_t, input_features_mask=mask_t,
+                       attention_mask=torch.ones_like(input_ids))
+        prefill_acts = dict(acts)
+        for h in hooks:
+            h.remove()
+        with torch.no_grad():
+            gen = model.generate(input_ids=input_ids, input_features=feats_t, input_features_mask=mask_t,
+                                 attention_mask=torch.ones_like(input_ids), max_new_tokens=n_new, do_sample=False,
+                                 return_dict_in_generate=True, output_logits=True)
+        new_ids = gen.sequences[0, len(ids):].numpy().astype(np.int32)
+        step_logits = torch.stack([l[0] for l in gen.logits]).float().numpy()   # [n_steps, vocab]
+        srt = np.sort(step_logits, axis=1)
+        margins = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+        p = f"s{si}_"
+        rec[p + "seg_index"] = i
+        rec[p + "n_samples"] = n
+        rec[p + "prompt_ids"] = np.asarray(ids, np.int32)
+        rec[p + "n_audio"] = n_audio
+        rec[p + "conv1_sub"] = prefill_acts["conv1"][0][:, ::97]              # [C, T/97] pre-GELU conv output
+        rec[p + "conv2_sub"] = prefill_acts["conv2"][0][:, ::53]
+        for li in range(d.enc_layers):
+            rec[p + f"enc_layer{li}_sub"] = prefill_acts[f"enc_layer{li}"][0][::31]   # rows every 31 frames
+        rec[p + "enc_out_sub"] = prefill_acts["enc_out"][0][::31]
+        rec[p + "audio_embeds"] = fw.audio_hidden_states.float().numpy()         # [n_audio, dec_d]
+        for li in range(d.dec_layers):
+            rec[p + f"dec_layer{li}_sub"] = prefill_acts[f"dec_layer{li}"][0][::13]
+        rec[p + "prefill_logits_last"] = fw.logits[0, -1].float().numpy()
+        rec[p + "step_logits"] = step_logits
+        rec[p + "new_ids"] = new_ids
+        rec[p + "margins"] = margins
+        print(f"tiny[{tag}] seg{si}: n_audio={n_audio} P={len(ids)} new={new_ids[:8]}... "
+              f"min margin={margins.min():.4f} logit range=[{step_logits.min():.2f},{step_logits.max():.2f}]")
+    np.savez_compressed(os.path.join(out_dir, f"tiny_{tag}.npz"), **rec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    if a.only in ("", "mel"):
+        gen_mel(a.out)
+    if a.only in ("", "tiny"):
+        gen_tiny(a.out, torch.float32, "fp32")
+        gen_tiny(a.out, torch.bfloat16, "bf16")
+
+
+if __name__ == "__main__":
+    main()
