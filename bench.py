@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 20 s-segments/sec (+ RTF) of the SonicScribe hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path (log-mel -> encoder -> projector -> prefill -> 150 greedy tokens) over one batch of 32
+synthetic 20 s segments per GPU (BASELINE.json configs[1]; GLM-ASR-Nano dimensions, bf16, portable-PRNG weights -- no
+checkpoint exists offline).  PCM is HBM-resident before the timed region.  Segments are sharded across ranks (one engine
+replica per GPU, no data-path collective): weak scaling, value = all ranks' segments / max-over-ranks time.
+
+The JSON line also carries
+  roofline      the encoder's dominant GEMM (fc1, [B*1500 x 1280] x [1280 x 5120], bias+GELU epilogue): algorithmic FLOPs per
+                launch / average launch duration measured with HIP events on the engine's stream inside the timed steps
+  cpu_baseline  the reference's DEVICE=cpu arithmetic (transformers GlmAsrForConditionalGeneration.generate, bf16, B=1,
+                asr.py thread rule) on a bounded sample, rank 0 at N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from dataclasses import replace
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEG_SECONDS = 20
+BATCH = 32
+MAX_NEW = 150           # min(50 + 5*20, 200), transcription_manager.py:37
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def cpu_reference_baseline(max_seconds_hint: float = 30.0):
+    """Time the reference's CPU path (third-party torch + transformers, exactly what backend/asr.py drives with DEVICE=cpu)
+    on one synthetic 20 s segment: generate() with 2 and with 10 new tokens, linear extrapolation to 150 tokens."""
+    import multiprocessing
+    import torch
+    from sonicscribe_amd import spec, synth
+    cores = multiprocessing.cpu_count()
+    threads = max(1, cores - 2) if cores > 4 else cores          # asr.py:96-101
+    torch.set_num_threads(threads)
+    try:
+        torch.set_num_interop_threads(1)
+    except RuntimeError:
+        pass
+    from transformers import GlmAsrConfig, GlmAsrForConditionalGeneration, WhisperFeatureExtractor
+    cfg = GlmAsrConfig()
+    with torch.device("meta"):
+        model = GlmAsrForConditionalGeneration(cfg)
+    model = model.to(torch.bfloat16).to_empty(device="cpu")
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).mul_((3.0 / fan_in) ** 0.5))
+            elif "norm" in name and name.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+        for mod in model.modules():      # non-persistent rotary buffers are not covered by to_empty
+            if hasattr(mod, "inv_freq") and hasattr(mod, "compute_default_rope_parameters"):
+                inv, _ = mod.compute_default_rope_parameters(mod.config)
+                mod.inv_freq = inv
+                mod.original_inv_freq = inv.clone()
+    model.eval()
+    fe = WhisperFeatureExtractor(feature_size=128)
+    pcm = synth.synth_pcm(0, SEG_SECONDS * 16000)
+    wav = pcm.astype(np.float32) / 32768.0
+    n_audio = spec.audio_token_count(spec.valid_frames(len(pcm)))
+    ids = torch.tensor([[1, 17, 23, 5] + [cfg.audio_token_id] * n_audio + [7, 301, 302, 303, 9, 11]])
+
+    def run(n_new):
+        t0 = time.perf_counter()
+        f = fe([wav], sampling_rate=16000, return_attention_mask=True, padding="max_length", return_tensors="pt")
+        with torch.no_grad():
+            model.generate(input_ids=ids, input_features=f["input_features"].to(torch.bfloat16), input_features_mask=f["attention_mask"],
+                           attention_mask=torch.ones_like(ids), max_new_tokens=n_new, min_new_tokens=n_new, do_sample=False)
+        return time.perf_counter() - t0
+
+    run(2)                       # warm-up (oneDNN primitive creation)
+    t2 = run(2)
+    t10 = run(10)
+    per_tok = max((t10 - t2) / 8.0, 1e-6)
+    t150 = t2 + per_tok * (MAX_NEW - 2)
+    return {
+        "value": 1.0 / t150, "unit": "20s-segments/sec", "cores": threads, "kind": "reference",
+        "sample": f"1 synthetic 20 s segment, B=1 bf16 torch-CPU + transformers generate(): 2 tokens {t2:.2f}s, 10 tokens {t10:.2f}s, "
+                  f"{per_tok * 1e3:.0f} ms/token, extrapolated to {MAX_NEW} tokens = {t150:.1f}s/segment (RTF {t150 / SEG_SECONDS:.2f}); "
+                  f"{cores} host cores visible, {threads} compute threads (asr.py:96-101), random full-size weights",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--max-new", type=int, default=MAX_NEW)
+    ap.add_argument("--dims", default="full", choices=["full", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    n_gpus = world if world > 1 else 1
+
+    from sonicscribe_amd import spec, synth
+    from sonicscribe_amd.engine import Engine
+    from sonicscribe_amd.sharder import shard_range
+
+    base = spec.FULL if a.dims == "full" else spec.TINY
+    dims = replace(base, eos_ids=())       # random weights: never stop early, every row does the full 150 steps
+    B = a.batch
+    eng = Engine(dims, local_rank, max_batch=B, max_ctx=512)
+    eng.load_synthetic(20260128)
+
+    lo, hi = shard_range(n_gpus * B, rank, n_gpus)           # shard g gets segments g*B .. g*B+B-1
+    n_samples = SEG_SECONDS * 16000
+    segs = [synth.synth_pcm(i, n_samples) for i in range(lo, hi)]
+    n_audio = spec.audio_token_count(spec.valid_frames(n_samples))
+    prompt = [1, 17, 23, 5] + [dims.audio_token_id] * n_audio + [7, 301, 302, 303, 9, 11]
+    eng.stage_pcm(segs)                                        # PCM resident in HBM before any timed region
+    eng.run_staged([prompt] * len(segs), [a.max_new] * len(segs))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.lib.sonic_synchronize(eng.h)
+
+    for _ in range(max(0, a.warmup - 1)):
+        eng.rerun_staged()
+    barrier()
+    stage = {"mel_ms": 0.0, "encoder_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "gemm_ms": 0.0, "gemm_launches": 0, "gemm_flops": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.rerun_staged()                                     # synchronous: returns after the stream drained
+        t = eng.timings()
+        for k in stage:
+            stage[k] += t[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ids = eng.fetch_tokens(len(segs), a.max_new)
+    assert all(len(x) == a.max_new for x in ids)
+
+    if rank == 0:
+        total_segments = n_gpus * B * a.steps
+        value = total_segments / dt
+        gemm_ms = stage["gemm_ms"] / max(1, stage["gemm_launches"])
+        flops_per_launch = stage["gemm_flops"] / max(1, stage["gemm_launches"])
+        achieved = flops_per_launch / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "20s-segments/sec/node + RTF, GLM-ASR-Nano bf16, batch=32, 1/2/4/8 MI355X",
+            "value": value, "unit": "20s-segments/sec", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "rtf": 1.0 / (SEG_SECONDS * value),
+            "config": {"workload": f"batch of {B} synthetic {SEG_SECONDS} s 16 kHz segments per GPU, GLM-ASR-Nano dims ({a.dims}), bf16, "
+                                   f"log-mel + encoder + prefill + {a.max_new} greedy tokens, portable-PRNG weights",
+                       "segments_per_gpu": B, "max_new_tokens": a.max_new, "parallelism": f"replica x{n_gpus} (segments sharded, no collective)"},
+            "stages_ms_per_step": {k: stage[k] / a.steps for k in ("mel_ms", "encoder_ms", "prefill_ms", "decode_ms")},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": None, "kernel": "gemm_kernel<EPI_BIAS_GELU> (encoder fc1)", "avg_launch_ms": gemm_ms,
+                         "flops_per_launch": flops_per_launch, "launches_timed": stage["gemm_launches"]},
+        }
+        if n_gpus == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_reference_baseline()
+            except Exception as ex:   # transformers missing on the box: report that rather than a wrong number
+                out["cpu_baseline"] = {"value": None, "unit": "20s-segments/sec", "cores": 0, "kind": "reference", "sample": f"unavailable: {ex!r}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

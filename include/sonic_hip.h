@@ -1,0 +1,123 @@
+/*
+ * sonic_hip.h -- C ABI of libsonic_hip.so, the MI355X-native engine behind SonicScribe's
+ * ASRModel.transcribe() (reference: backend/asr.py:335-488).
+ *
+ * The reference has no FFI of its own (pure Python); this is the boundary its
+ * `ASRModel` methods bind through ctypes (sonicscribe_amd/engine.py).  Plain
+ * pointers and sizes only; every function returns a sonic_status; outputs are caller-allocated;
+ * no callbacks; no global state besides the handle.  Calls on one engine are serialised
+ * internally (the reference is entered from up to 3 executor threads plus the event-loop
+ * thread, backend/main.py:429-430,616-624, backend/transcription_manager.py:58).
+ *
+ * Which reference interface each entry point replaces:
+ *   sonic_create / sonic_load_* / sonic_finalize_weights
+ *                              ASRModel.__init__ + _load_model_standard   asr.py:25-87,120-146
+ *                              (models_manager.asr_model_init             models_manager.py:16-32)
+ *   sonic_transcribe_batch     the device part of ASRModel.transcribe     asr.py:393-422
+ *                              (processor features + model.generate(do_sample=False))
+ *   sonic_stage_pcm / sonic_run_staged / sonic_fetch_tokens
+ *                              the same, split so PCM can be HBM-resident before a timed region
+ *   sonic_logmel               WhisperFeatureExtractor.__call__ as invoked from asr.py:393
+ *                              (HF:feature_extraction_whisper.py:193-346)
+ *   sonic_encode               GlmAsrModel.get_audio_features             HF:modeling_glmasr.py:380-408
+ *   sonic_destroy              `del asr_model.model`                      backend/main.py:84-86
+ *   sonic_last_error           the exception text re-raised at            asr.py:469-481
+ */
+#ifndef SONIC_HIP_H
+#define SONIC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sonic_engine sonic_engine;
+
+typedef enum {
+    SONIC_OK = 0,
+    SONIC_ERR_INVALID = 1,   /* bad argument / shape / state            -> ValueError / RuntimeError */
+    SONIC_ERR_HIP = 2,       /* HIP runtime failure                     -> RuntimeError */
+    SONIC_ERR_OOM = 3,       /* message contains "out of memory" (asr.py:471 hint branch) */
+    SONIC_ERR_MISMATCH = 4,  /* audio placeholders != audio feature rows (HF:modeling_glmasr.py:426-429) */
+    SONIC_ERR_UNSUPPORTED = 5
+} sonic_status;
+
+enum { SONIC_MODE_NATIVE = 0 /* bf16, asr.py mode="native" */, SONIC_MODE_INT8 = 1 /* asr.py mode="int8" */ };
+enum { SONIC_DTYPE_F32 = 0, SONIC_DTYPE_BF16 = 1 };
+
+/* Model dimensions (defaults: HF:configuration_glmasr.py:44-54,86-103). */
+typedef struct {
+    int32_t n_mels, n_frames, enc_T;
+    int32_t enc_d, enc_ff, enc_layers, enc_heads, enc_rotary_dim;
+    float enc_theta, enc_ln_eps;
+    int32_t merge;
+    int32_t dec_d, dec_ff, dec_layers, dec_heads, dec_kv_heads, dec_head_dim;
+    float dec_theta, dec_rms_eps;
+    int32_t vocab, audio_token_id, n_eos;
+    int32_t eos[8];
+} sonic_dims;
+
+/* Per-stage device time of the last sonic_run_staged / sonic_transcribe_batch (HIP events on the engine stream). */
+typedef struct {
+    float mel_ms, encoder_ms, prefill_ms, decode_ms, total_ms;
+    float gemm_ms;          /* summed duration of the encoder's dominant GEMM kernel launches (fc1, bias+GELU epilogue) */
+    int32_t gemm_launches;  /* ... and how many launches that was */
+    double gemm_flops;      /* algorithmic FLOPs of those launches */
+    int32_t decode_steps;
+} sonic_timings;
+
+/* ---- lifetime ---- */
+int sonic_device_count(void);
+/* max_batch: windows per call (<= 64); max_ctx: decoder context capacity per sequence (multiple of 64). */
+int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out);
+void sonic_destroy(sonic_engine* e);
+const char* sonic_last_error(sonic_engine* e); /* e may be NULL: error of the last failed sonic_create on this thread */
+
+/* ---- weights (names: GlmAsrForConditionalGeneration.state_dict() keys, see sonicscribe_amd/spec.py) ---- */
+int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
+int sonic_load_synthetic(sonic_engine* e, uint64_t seed);          /* portable generator, sonicscribe_amd/synth.py */
+int sonic_finalize_weights(sonic_engine* e);                        /* packs fused QKV / gate-up, conv im2col order */
+int64_t sonic_weight_bytes(sonic_engine* e);
+
+/* ---- stage entry points (parity tests) ---- */
+/* pcm: B segments concatenated; offsets[B+1] in samples (segment i = pcm[offsets[i] .. offsets[i+1])), each <= 30 s.
+ * feats_out: [B][n_mels][n_frames] fp32 (HF layout), mask_out: [B][n_frames] int32; either may be NULL. */
+int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int B, float* feats_out, int32_t* mask_out);
+/* feats: [B][n_mels][n_frames] fp32 (cast to bf16 as asr.py:280-301 does); n_valid_frames[B].
+ * embeds_out: [B][enc_T/merge][dec_d] fp32 (first n_audio_out[b] rows valid).
+ * taps (optional, may be NULL): enc_layers_out [B][enc_layers][enc_T][enc_d], enc_out [B][enc_T][enc_d]. */
+int sonic_encode(sonic_engine* e, const float* feats, const int32_t* n_valid_frames, int B,
+                 float* embeds_out, int32_t* n_audio_out, float* enc_layers_out, float* enc_out);
+
+/* ---- the hot call ---- */
+/* W windows of PCM (as sonic_logmel); R requests, request r owns windows req_win[r] .. req_win[r+1]-1 (R == W and
+ * req_win == NULL for the single-window case).  prompt_ids concatenated, prompt_off[R+1]; max_new[R].
+ * out_ids: [R][out_ld] int32, out_len[R]; step_logits (optional): [max(max_new)][R][vocab] fp32 = the bf16 logits
+ * each step's argmax saw (row r of step s valid while s < out_len[r]). */
+int sonic_transcribe_batch(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W,
+                           const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                           const int32_t* max_new, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+
+/* split form: stage (H2D) -> run (device only, timed) -> fetch (D2H) */
+int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W);
+int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                     const int32_t* max_new, int want_step_logits);
+int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+int sonic_get_timings(sonic_engine* e, sonic_timings* out);
+int sonic_synchronize(sonic_engine* e);
+
+/* ---- single-kernel test hooks (host fp32 in/out, converted to bf16 on device; used by tests/ only) ---- */
+int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float* bias, const float* resid, float* C,
+                    int M, int N, int K, int epi);
+int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K);
+int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
+                         int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal);
+int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
+                                int B, int Tk, int Hq, int Hkv);
+int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, int rms);
+/* times `iters` launches of the encoder's dominant GEMM shape on the engine stream with HIP events */
+int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONIC_HIP_H */

@@ -369,6 +369,7 @@ static void encoder_layer(const oracle_model *m, int l, float *x, int T) {
     free(ln); free(q); free(k); free(v); free(a); free(ff); free(pos);
 }
 
+static int floordiv_i(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 /* a7-a9: feats -> audio embeds [n_keep][dec_d]; returns rows kept */
 int oracle_audio_features(const oracle_model *m, const float *feats, int n_valid_frames, float *embeds, oracle_outputs *o) {
     const oracle_dims *d = &m->d; int T = d->enc_T, D = d->enc_d;
@@ -388,9 +389,9 @@ int oracle_audio_features(const oracle_model *m, const float *feats, int n_valid
     for (long i = 0; i < (long)Tm * PM; ++i) h[i] = RB(m, gelu_erf(h[i]));
     float *e = (float *)malloc(sizeof(float) * (long)Tm * d->dec_d);
     linear(m, h, PM, tw[4], tw[5], e, d->dec_d, Tm, d->dec_d, PM);
-    int L = n_valid_frames; /* modeling_glmasr.py:399-403 */
-    L = (L + 2 - 2 - 1) / 1 + 1; L = (L + 2 - 2 - 1) / 2 + 1;
-    int keep = (L - d->merge) / d->merge + 1; if (keep < 0) keep = 0; if (keep > Tm) keep = Tm;
+    int L = n_valid_frames; /* modeling_glmasr.py:399-403, python floor division */
+    L = floordiv_i(L + 2 - 2 - 1, 1) + 1; L = floordiv_i(L + 2 - 2 - 1, 2) + 1;
+    int keep = floordiv_i(L - d->merge, d->merge) + 1; if (keep < 0) keep = 0; if (keep > Tm) keep = Tm;
     memcpy(embeds, e, sizeof(float) * (long)keep * d->dec_d);
     free(x); free(y); free(h); free(e);
     return keep;

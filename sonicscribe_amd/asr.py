@@ -1,0 +1,284 @@
+"""Drop-in ``ASRModel`` (reference: backend/asr.py) backed by the MI355X HIP engine.
+
+Same constructor, ``transcribe`` signature, return types, error behaviour and auxiliary members
+(``.model``, ``get_model_info``) as the reference class, so ``backend/models_manager.py:32`` only has to
+import this class instead of ``asr.ASRModel``.  What changed underneath:
+
+  * asr.py:230-278  temp-WAV round trip          -> frontend.normalise_to_int16 (no disk)
+  * asr.py:393-399  HF processor feature step    -> log-mel HIP kernel (csrc/logmel.hip)
+  * asr.py:407-422  HF model.generate            -> HIP encoder / prefill / hipGraph greedy loop
+  * asr.py:425-429  batch_decode                 -> unchanged (tokenizer stays in Python)
+
+Concurrent callers (3 executor threads + the event loop, main.py:429-430, transcription_manager.py:58)
+are coalesced into one device batch by ``_Coalescer`` instead of serialising on the model.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import frontend
+from .engine import Engine, MODE_INT8, MODE_NATIVE, SonicError, device_count
+from .spec import FULL, ModelDims
+
+
+# --------------------------------------------------------------------------------------- prompts
+class SyntheticPrompt:
+    """Stand-in for the checkpoint's tokenizer + chat template (absent offline): fixed prefix / suffix ids
+    around the audio placeholders.  Decoding renders ids as text so the call surface stays str-valued."""
+
+    def __init__(self, dims: ModelDims, prefix: Sequence[int] = (1, 17, 23, 5), suffix: Sequence[int] = (7, 301, 302, 303, 9, 11)):
+        self.dims, self.prefix, self.suffix = dims, list(prefix), list(suffix)
+
+    def build(self, instruction: str, n_audio: int) -> List[int]:
+        extra = [] if instruction == frontend.BASE_INSTRUCTION else [2 + (sum(instruction.encode()) % 200)]
+        return self.prefix + [self.dims.audio_token_id] * n_audio + self.suffix + extra
+
+    def decode(self, ids: Sequence[int]) -> str:
+        eos = set(self.dims.eos_ids)
+        return " ".join(str(int(i)) for i in ids if int(i) not in eos)
+
+
+class HFPrompt:
+    """Tokenizer + chat template of a real checkpoint (processing_glmasr.py:178-180: the audio placeholder string is
+    repeated ``num_audio_tokens`` times before tokenisation).  Prompts are cached per (instruction, n_audio) -- SURVEY §8f4."""
+
+    def __init__(self, processor, dims: ModelDims):
+        self.processor, self.dims = processor, dims
+        self.audio_token = getattr(processor, "audio_token", "<|pad|>")
+        self._cache: Dict[Any, List[int]] = {}
+
+    def build(self, instruction: str, n_audio: int) -> List[int]:
+        key = (instruction, n_audio)
+        if key not in self._cache:
+            messages = [{"role": "user", "content": [{"type": "audio", "url": ""}, {"type": "text", "text": instruction}]}]
+            text = self.processor.tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=True,
+                                                                chat_template=self.processor.chat_template)
+            text = text.replace(self.audio_token, self.audio_token * n_audio, 1)
+            self._cache[key] = list(self.processor.tokenizer(text, add_special_tokens=False)["input_ids"])
+        return self._cache[key]
+
+    def decode(self, ids: Sequence[int]) -> str:
+        return self.processor.batch_decode([list(map(int, ids))], skip_special_tokens=True)[0]
+
+
+# --------------------------------------------------------------------------------------- coalescer
+class _Request:
+    __slots__ = ("windows", "prompt", "max_new", "event", "ids", "error")
+
+    def __init__(self, windows, prompt, max_new):
+        self.windows, self.prompt, self.max_new = windows, prompt, max_new
+        self.event = threading.Event()
+        self.ids = None
+        self.error: Optional[BaseException] = None
+
+
+class _Coalescer:
+    """Gathers transcribe() calls from any number of threads into device batches."""
+
+    def __init__(self, engine: Engine, linger_s: float = 0.002):
+        self.engine, self.linger_s = engine, linger_s
+        self.q: List[_Request] = []
+        self.cv = threading.Condition()
+        self.stop = False
+        self.thread = threading.Thread(target=self._loop, name="sonic-coalescer", daemon=True)
+        self.thread.start()
+
+    def submit(self, req: _Request) -> _Request:
+        with self.cv:
+            if self.stop:
+                raise RuntimeError("ASR engine is closed")
+            self.q.append(req)
+            self.cv.notify()
+        req.event.wait()
+        if req.error is not None:
+            raise req.error
+        return req
+
+    def close(self):
+        with self.cv:
+            self.stop = True
+            self.cv.notify_all()
+        self.thread.join(timeout=5)
+
+    def _take(self) -> List[_Request]:
+        with self.cv:
+            while not self.q and not self.stop:
+                self.cv.wait()
+            if self.stop and not self.q:
+                return []
+            if len(self.q) < self.engine.max_batch:
+                self.cv.wait(self.linger_s)  # let concurrent callers join this batch
+            batch, used = [], 0
+            while self.q and used + len(self.q[0].windows) <= self.engine.max_batch:
+                r = self.q.pop(0)
+                batch.append(r)
+                used += len(r.windows)
+            if not batch and self.q:   # a single request larger than a batch
+                r = self.q.pop(0)
+                r.error = ValueError(f"audio spans {len(r.windows)} windows, engine max_batch is {self.engine.max_batch}")
+                r.event.set()
+            return batch
+
+    def _loop(self):
+        while True:
+            batch = self._take()
+            if not batch:
+                if self.stop:
+                    return
+                continue
+            try:
+                segs, req_win = [], [0]
+                for r in batch:
+                    segs.extend(r.windows)
+                    req_win.append(len(segs))
+                ids, _ = self.engine.transcribe_batch(segs, [r.prompt for r in batch], [r.max_new for r in batch], req_win=req_win)
+                for r, i in zip(batch, ids):
+                    r.ids = i
+            except BaseException as ex:  # per-request validation errors must not poison the neighbours
+                if len(batch) == 1:
+                    batch[0].error = ex
+                else:
+                    for r in batch:
+                        try:
+                            ids, _ = self.engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
+                            r.ids = ids[0]
+                        except BaseException as ex2:
+                            r.error = ex2
+            for r in batch:
+                r.event.set()
+
+
+# --------------------------------------------------------------------------------------- façade
+class ASRModel:
+    def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
+                 cpu_threads: Optional[int] = None, cpu_interop_threads: Optional[int] = None,
+                 *, max_batch: int = 32, max_ctx: int = 1024, _dims: Optional[ModelDims] = None, _synthetic_seed: Optional[int] = None):
+        if mode not in ["native", "int8"]:
+            raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
+        if mode == "int8":
+            raise ImportError("INT8 mode is not available in this build of the HIP engine")  # asr.py:49-50 analogue
+        dev = str(device)
+        if dev.startswith("cpu"):
+            raise RuntimeError("sonicscribe_amd runs on MI355X only: DEVICE=cpu has no HIP path (no CPU fallback by design)")
+        self.device_index = int(dev.split(":")[1]) if ":" in dev else 0
+        if device_count() <= self.device_index:
+            raise RuntimeError(f"HIP device {self.device_index} not available")
+        self.device = f"cuda:{self.device_index}"
+        self.mode = mode
+        self.model_dtype = "bfloat16"
+        self.checkpoint_dir = Path(checkpoint_dir)
+        self.target_sr = 16000
+        self.is_glm_asr = True
+        self.processor = None
+        if _synthetic_seed is not None:
+            self.dims = _dims or FULL
+            self.model = Engine(self.dims, self.device_index, MODE_NATIVE, max_batch, max_ctx)
+            self.model.load_synthetic(_synthetic_seed)
+            self.prompt = SyntheticPrompt(self.dims)
+        else:
+            from . import weights
+            self.dims = weights.load_dims(str(self.checkpoint_dir))
+            self.model = Engine(self.dims, self.device_index, MODE_NATIVE, max_batch, max_ctx)
+            weights.load_checkpoint(self.model, str(self.checkpoint_dir))
+            try:
+                from transformers import AutoProcessor
+                self.processor = AutoProcessor.from_pretrained(str(self.checkpoint_dir))
+                self.target_sr = self.processor.feature_extractor.sampling_rate
+                self.prompt = HFPrompt(self.processor, self.dims)
+            except Exception:
+                self.prompt = SyntheticPrompt(self.dims)   # checkpoint without tokenizer files (tests)
+        self._coalescer = _Coalescer(self.model)
+        print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
+              f"{self.model.weight_bytes() / 2**20:.0f} MiB weights)")
+
+    @classmethod
+    def from_synthetic(cls, dims: ModelDims = FULL, seed: int = 20260128, device: str = "cuda", **kw) -> "ASRModel":
+        return cls("<synthetic>", device=device, mode="native", _dims=dims, _synthetic_seed=seed, **kw)
+
+    # -- reference helpers kept under their reference names
+    def _format_hotwords_prompt(self, hotwords: List[str], max_hotwords: int = 10) -> str:
+        return frontend.format_hotwords_prompt(hotwords, max_hotwords)
+
+    def _prepare(self, audio_tensor, sampling_rate: int):
+        wav = audio_tensor
+        if hasattr(wav, "detach"):
+            wav = wav.detach().cpu().numpy()
+        wav = np.asarray(wav, dtype=np.float32)
+        if wav.ndim == 2:
+            wav = wav[0]                                                      # first channel (asr.py:252)
+        if sampling_rate != self.target_sr:
+            wav = frontend.resample_sinc_hann(wav, sampling_rate, self.target_sr)   # asr.py:255-261
+        pcm = frontend.normalise_to_int16(wav)
+        wins = frontend.split_windows(len(pcm), self.dims)
+        n_audio, _ = frontend.request_audio_tokens(len(pcm), self.dims)
+        return pcm, [pcm[s:e] for s, e in wins], n_audio
+
+    def transcribe(self, audio_tensor, sampling_rate: int = 16000, max_new_tokens: int = 128,
+                   hotwords: Optional[List[str]] = None, return_debug_info: bool = False) -> Union[str, Dict[str, Any]]:
+        if not hasattr(self, "model"):
+            raise RuntimeError("ASR model has been released")
+        t0 = time.time()
+        try:
+            pcm, windows, n_audio = self._prepare(audio_tensor, sampling_rate)
+            instruction = frontend.build_instruction(hotwords)
+            prompt = self.prompt.build(instruction, n_audio)
+            req = self._coalescer.submit(_Request(windows, prompt, int(max_new_tokens)))
+            transcript = self.prompt.decode(req.ids).strip()
+            elapsed = time.time() - t0
+            if return_debug_info:
+                n = audio_tensor.shape[-1] if hasattr(audio_tensor, "shape") else len(audio_tensor)
+                return {"transcript": transcript, "processing_time": elapsed, "audio_length_sec": n / sampling_rate,
+                        "mode": self.mode, "device": str(self.device),
+                        "gpu_memory_allocated_mb": self.model.weight_bytes() / 1024 ** 2, "gpu_memory_reserved_mb": self.model.weight_bytes() / 1024 ** 2}
+            return transcript
+        except RuntimeError as e:
+            if "out of memory" in str(e).lower():
+                print("⚠️ 显存不足！建议：使用更短的音频 / 减少 max_new_tokens")
+            raise
+        except Exception as e:
+            print(f"❌ 转录过程中发生错误: {e}")
+            raise
+
+    def transcribe_batch(self, audios: Sequence[Any], sampling_rate: int = 16000, max_new_tokens: Union[int, Sequence[int]] = 128,
+                         hotwords: Optional[List[str]] = None) -> List[str]:
+        """Batched extension (the reference is B=1 per call): one device batch, per-segment results identical to transcribe()."""
+        mn = [int(max_new_tokens)] * len(audios) if isinstance(max_new_tokens, int) else [int(x) for x in max_new_tokens]
+        segs, req_win, prompts = [], [0], []
+        instruction = frontend.build_instruction(hotwords)
+        for a in audios:
+            _, wins, n_audio = self._prepare(a, sampling_rate)
+            segs.extend(wins)
+            req_win.append(len(segs))
+            prompts.append(self.prompt.build(instruction, n_audio))
+        ids, _ = self.model.transcribe_batch(segs, prompts, mn, req_win=req_win)
+        return [self.prompt.decode(i).strip() for i in ids]
+
+    def get_model_info(self) -> Dict[str, Any]:
+        return {"mode": self.mode, "device": str(self.device), "model_dtype": "torch.bfloat16", "target_sampling_rate": self.target_sr,
+                "checkpoint_dir": str(self.checkpoint_dir), "is_glm_asr": self.is_glm_asr, "engine": "sonicscribe_amd/gfx950",
+                "gpu_name": "AMD Instinct MI355X", "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0}
+
+    def close(self):
+        c = self.__dict__.pop("_coalescer", None)
+        if c is not None:
+            c.close()
+        m = self.__dict__.pop("model", None)
+        if m is not None:
+            m.close()
+
+    def __delattr__(self, name):   # main.py:84-86 does `del asr_model.model`
+        if name == "model":
+            self.close()
+        else:
+            super().__delattr__(name)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,63 @@
+// Shared device/host helpers for the sonic_hip engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }          // v_cvt_pk_bf16_f32: RNE, NaN-safe
+__device__ __forceinline__ float rbf(float x) { return (float)((bf16_t)x); }  // round-trip through bf16
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- GEMM launch descriptors (gemm.hip) ----
+enum GemmEpi {
+    EPI_BIAS = 0,       // C = bf16(acc + bias)
+    EPI_BIAS_GELU = 1,  // C = bf16(gelu(bf16(acc + bias)))
+    EPI_BIAS_RESID = 2, // C = bf16(bf16(acc + bias) + R)
+    EPI_SWIGLU = 3,     // rows of W interleaved gate/up in 16-row groups: C[:, n/2] = bf16(bf16(silu(bf16 g)) * bf16 u)
+    EPI_QKV_VT = 4,     // encoder QKV: columns < n_split -> C (row-major, ldc); columns >= n_split -> V^T [seg][col][t]
+};
+
+struct GemmArgs {
+    const bf16_t* A; long lda;       // [M][K] row stride lda (elements); lda < K allowed (overlapping im2col rows)
+    const bf16_t* W;                 // [N][K] contiguous rows (torch Linear layout)
+    bf16_t* C; long ldc;
+    const float* bias;               // [N] or null
+    const bf16_t* R; long ldr;       // residual (EPI_BIAS_RESID)
+    int M, N, K;
+    int batch; long strideA, strideC, strideR;   // blockIdx.z batches (conv stem: one per segment)
+    // EPI_QKV_VT
+    bf16_t* Vt; int n_split; int seg_T; int vt_ld; long vt_seg_stride;  // Vt[seg][n - n_split][t], row stride vt_ld
+};
+
+struct SkinnyArgs {
+    const bf16_t* X; long ldx;       // [M<=64][K]
+    const bf16_t* W;                 // [N][K]
+    float* P;                        // partial slabs [ksplit][Mpad][N] fp32
+    int M, N, K, ksplit;
+};
+
+void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+void launch_skinny(const SkinnyArgs& a, hipStream_t s);
+int skinny_pick_ksplit(int N, int K);

@@ -1,0 +1,339 @@
+// Memory-bound glue kernels: LayerNorm / RMSNorm with wavefront
+// reductions, rotate-half RoPE (partial-32 encoder, full-128 decoder) fused with the KV-cache append,
+// the decode-step consumers of the skinny-GEMM partial slabs, embedding gather, fused argmax + greedy
+// controller, synthetic weight generator.  All bf16 traffic is 16 B per lane (8 elements).
+//
+// Rounding boundaries reproduce torch's bf16 op sequence of the reference path (`mode="native"`):
+// every torch op output is rounded to bf16 once, arithmetic inside an op is fp32.
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------- LayerNorm (modeling_glmasr.py:246-247,305)
+// one wave per row, d % 8 == 0, d <= 2048; two-pass in registers (mean, then centred variance).
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const float* w, const float* b, bf16_t* y,
+                                                        int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * d;
+    const int nv = d >> 3;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const bf16x8 t = *(const bf16x8*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); s += v[i][j]; }
+        }
+    }
+    const float mean = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + i * 64 < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mean; q += c * c; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / d + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(((v[i][j] - mean) * rstd) * w[c * 8 + j] + b[c * 8 + j]);
+            *(bf16x8*)(y + (long)row * d + c * 8) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- RMSNorm (modeling_llama.py:60-65)
+__device__ __forceinline__ void rms_row(const float (&v)[4][8], float ssq, const float* w, bf16_t* yr, int lane, int nv, int d, float eps) {
+    const float r = 1.0f / sqrtf(wave_sum(ssq) / d + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(w[c * 8 + j] * rbf(v[i][j] * r));
+            *(bf16x8*)(yr + c * 8) = o;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps,
+                                                      const int* row_map /* optional gather: y[r] = norm(x[row_map[r]]) */) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)(row_map ? row_map[row] : row) * d;
+    const int nv = d >> 3;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const bf16x8 t = *(const bf16x8*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); s += v[i][j] * v[i][j]; }
+        }
+    }
+    rms_row(v, s, w, y + (long)row * d, lane, nv, d, eps);
+}
+
+// decode: x[r] = bf16(x[r] + bf16(sum_ks P[ks][r][:])); y[r] = rmsnorm(x[r]) (o_proj / down_proj consumer)
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y,
+                                                          int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bf16_t* xr = x + (long)row * d;
+    const int nv = d >> 3;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < ksplit; ++ks) {
+                const float* p = P + ((long)ks * mpad + row) * d + c * 8;
+                const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
+            }
+            const bf16x8 t = *(const bf16x8*)(xr + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o[j] = f2bf(bf2f(t[j]) + rbf(acc[j])); v[i][j] = bf2f(o[j]); s += v[i][j] * v[i][j]; }
+            *(bf16x8*)(xr + c * 8) = o;
+        }
+    }
+    rms_row(v, s, w, y + (long)row * d, lane, nv, d, eps);
+}
+
+// decode: act[r][c] = bf16(bf16(silu(bf16 g)) * bf16 u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)
+__global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 /* 2*ff */, bf16_t* act, int rows) {
+    const int ff = n2 >> 1;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 outputs
+    if (idx >= (long)rows * (ff >> 2)) return;
+    const int row = idx / (ff >> 2), c4 = (idx % (ff >> 2)) * 4;
+    const int grp = c4 >> 4, within = c4 & 15;
+    const int ng = grp * 32 + within, nu = ng + 16;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < ksplit; ++ks) {
+        const float* p = P + ((long)ks * mpad + row) * n2;
+        g += *(const f32x4*)(p + ng);
+        u += *(const f32x4*)(p + nu);
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(rbf(silu_f(rbf(g[j]))) * rbf(u[j]));
+    *(bf16x4*)(act + (long)row * ff + c4) = o;
+}
+
+// ---------------------------------------------------------------- encoder RoPE (modeling_glmasr.py:153-168)
+// in place on the fused q|k buffer [M][ld]; first `rd` dims of each 64-dim head, pairs (i, i + rd/2);
+// cs table [T][rd] = cos[0..rd/2) | sin[0..rd/2) (bf16-rounded fp32).  one thread = 8 pairs.
+__global__ void rope_enc_kernel(bf16_t* qk, long ld, int M, int T, int heads2 /* q heads + k heads */, int hd, int rd, const float* cs) {
+    const int half = rd >> 1, per_head = half >> 3;  // threads per head
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * heads2 * per_head) return;
+    const int u = idx % per_head, hh = (idx / per_head) % heads2;
+    const int m = idx / ((long)per_head * heads2), t = m % T;
+    bf16_t* p = qk + (long)m * ld + hh * hd + u * 8;
+    const bf16x8 a = *(const bf16x8*)p, bb = *(const bf16x8*)(p + half);
+    const float* c = cs + (long)t * rd + u * 8;
+    const float* s = c + half;
+    bf16x8 o1, o2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x1 = bf2f(a[j]), x2 = bf2f(bb[j]);
+        o1[j] = f2bf(rbf(x1 * c[j]) + rbf(-x2 * s[j]));
+        o2[j] = f2bf(rbf(x2 * c[j]) + rbf(x1 * s[j]));
+    }
+    *(bf16x8*)p = o1;
+    *(bf16x8*)(p + half) = o2;
+}
+
+// ---------------------------------------------------------------- decoder RoPE + KV append (modeling_llama.py:121-143,261-262)
+// Source is either the bf16 QKV matrix of the prefill GEMM or the fp32 slabs of the decode skinny GEMM.
+// Writes roped q (bf16 [tok][Hq*128]), roped k -> K cache, v -> V cache, and (prefill) v^T -> Vt scratch.
+template <bool SLAB>
+__global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
+    constexpr int HD = 128, HALF = 64;
+    const int tok = blockIdx.x;
+    const int heads = a.Hq + 2 * a.Hkv;
+    const int N = heads * HD;
+    const int b = a.tok_seq[tok], pos = a.tok_pos[tok];
+    for (int w = threadIdx.x; w < heads * 8; w += blockDim.x) {
+        const int hh = w >> 3, u = w & 7;   // head, 8-wide chunk of the first half
+        float x1[8], x2[8];
+        if (SLAB) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x1[j] = 0.f; x2[j] = 0.f; }
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const float* p = a.P + ((long)ks * a.mpad + tok) * N + hh * HD + u * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { x1[j] += p[j]; x2[j] += p[HALF + j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x1[j] = rbf(x1[j]); x2[j] = rbf(x2[j]); }
+        } else {
+            const bf16_t* p = a.qkv + (long)tok * a.ld + hh * HD + u * 8;
+            const bf16x8 t1 = *(const bf16x8*)p, t2 = *(const bf16x8*)(p + HALF);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x1[j] = bf2f(t1[j]); x2[j] = bf2f(t2[j]); }
+        }
+        bf16x8 o1, o2;
+        if (hh < a.Hq + a.Hkv) {
+            const float* c = a.cs + (long)pos * HD + u * 8;
+            const float* s = c + HALF;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o1[j] = f2bf(rbf(x1[j] * c[j]) + rbf(-x2[j] * s[j]));
+                o2[j] = f2bf(rbf(x2[j] * c[j]) + rbf(x1[j] * s[j]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o1[j] = f2bf(x1[j]); o2[j] = f2bf(x2[j]); }
+        }
+        if (hh < a.Hq) {
+            bf16_t* q = a.q_out + (long)tok * a.Hq * HD + hh * HD + u * 8;
+            *(bf16x8*)q = o1; *(bf16x8*)(q + HALF) = o2;
+        } else if (hh < a.Hq + a.Hkv) {
+            bf16_t* k = a.Kc + (((long)b * a.Hkv + (hh - a.Hq)) * a.ctx_max + pos) * HD + u * 8;
+            *(bf16x8*)k = o1; *(bf16x8*)(k + HALF) = o2;
+        } else {
+            const int kvh = hh - a.Hq - a.Hkv;
+            bf16_t* v = a.Vc + (((long)b * a.Hkv + kvh) * a.ctx_max + pos) * HD + u * 8;
+            *(bf16x8*)v = o1; *(bf16x8*)(v + HALF) = o2;
+            if (a.Vt) {
+                bf16_t* vt = a.Vt + ((long)b * a.Hkv + kvh) * HD * a.vt_ld + pos;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { vt[(long)(u * 8 + j) * a.vt_ld] = o1[j]; vt[(long)(HALF + u * 8 + j) * a.vt_ld] = o2[j]; }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- embedding gather / audio scatter (modeling_glmasr.py:452-465)
+// src[tok] >= 0: row of the embedding table; src[tok] < 0: audio row -(src+1) of `audio`.
+__global__ void assemble_embeds_kernel(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d) {
+    const int tok = blockIdx.x;
+    const int s = src[tok];
+    const bf16_t* from = s >= 0 ? table + (long)s * d : audio + (long)(-(s + 1)) * d;
+    for (int c = threadIdx.x; c < (d >> 3); c += blockDim.x) *(bf16x8*)(x + (long)tok * d + c * 8) = *(const bf16x8*)(from + c * 8);
+}
+
+// ---------------------------------------------------------------- argmax + greedy controller (generation/utils.py:2894-2936)
+__global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* lg = a.logits + (long)b * a.V;
+    float* dump = a.logits_dump ? a.logits_dump + (long)a.step_counter[b] * a.dump_stride_step + (long)b * a.V : nullptr;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid * 4; i < a.V; i += 1024 * 4) {
+        const f32x4 v = *(const f32x4*)(lg + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = rbf(v[j]);          // logits are bf16 in the reference, compared as fp32
+            if (dump) dump[i + j] = r;
+            if (r > best) { best = r; bi = i + j; }   // strict > keeps the first maximum within a thread
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        int tok = bi;
+        const int fin = a.finished[b];
+        if (fin) tok = a.pad_id;                 // finished rows emit the pad token (:2928-2929)
+        else {
+            a.out_ids[(long)b * a.out_ld + a.n_new[b]] = tok;
+            const int nn = a.n_new[b] + 1;
+            a.n_new[b] = nn;
+            bool stop = nn >= a.max_new[b];
+            for (int e = 0; e < a.n_eos; ++e) stop |= (tok == a.eos[e]);
+            if (stop) { a.finished[b] = 1; atomicSub(a.n_active, 1); }
+        }
+        a.tok_pos[b] = a.kv_len[b];              // the new token sits right after the current context
+        a.kv_len[b] += 1;
+        s_tok = tok;
+        if (a.step_counter) a.step_counter[b] += 1;
+    }
+    __syncthreads();
+    const bf16_t* row = a.table + (long)s_tok * a.d;
+    for (int c = tid; c < (a.d >> 3); c += 1024) *(bf16x8*)(a.x + (long)b * a.d + c * 8) = *(const bf16x8*)(row + c * 8);
+}
+
+// ---------------------------------------------------------------- misc
+__global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(in[i]);
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* in, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf2f(in[i]);
+}
+
+// sonicscribe_amd/synth.py restated for the device: writes bf16 and/or fp32
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ void synth_fill_kernel(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long z = mix64(key + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ULL);
+    const int bits = (int)(z >> 40);
+    const float r = __fsub_rn(__fmul_rn((float)bits, 0x1p-23f), 1.0f);
+    const float v = __fadd_rn(offset, __fmul_rn(r, scale));
+    if (out_bf) out_bf[i] = f2bf(v);
+    if (out_f32) out_f32[i] = rbf(v);
+}
+
+// ---------------------------------------------------------------- launchers
+void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, d, eps);
+}
+void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s) {
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, rows, d, eps, row_map);
+}
+void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, P, ksplit, mpad, w, y, rows, d, eps);
+}
+void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s) {
+    const long n = (long)rows * (n2 >> 3);
+    hipLaunchKernelGGL(swiglu_slab_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, ksplit, mpad, n2, act, rows);
+}
+void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s) {
+    const long n = (long)M * heads2 * (rd >> 4);
+    hipLaunchKernelGGL(rope_enc_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qk, ld, M, T, heads2, hd, rd, cs);
+}
+void launch_rope_append(const RopeAppendArgs& a, bool slab, hipStream_t s) {
+    if (a.n_tok <= 0) return;
+    if (slab) hipLaunchKernelGGL(rope_append_kernel<true>, dim3(a.n_tok), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rope_append_kernel<false>, dim3(a.n_tok), dim3(256), 0, s, a);
+}
+void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d, hipStream_t s) {
+    if (n_tok > 0) hipLaunchKernelGGL(assemble_embeds_kernel, dim3(n_tok), dim3(256), 0, s, src, table, audio, x, n_tok, d);
+}
+void launch_greedy(const GreedyArgs& a, hipStream_t s) { hipLaunchKernelGGL(greedy_kernel, dim3(a.B), dim3(1024), 0, s, a); }
+void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+}
+void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+}
+void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(synth_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, key, n, scale, offset, out_bf, out_f32);
+}

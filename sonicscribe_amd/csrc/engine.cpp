@@ -1,0 +1,1103 @@
+// sonic_hip engine: weights, HBM buffers, the mel -> encoder -> projector -> prefill -> greedy-decode
+// pipeline on one HIP stream, hipGraph-captured decode step, and the C ABI of include/sonic_hip.h.
+// One engine = one full model replica on one MI355X (replicas, no collectives).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sonic_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#define T_PAD_ALIGN 64
+
+static thread_local std::string g_create_err;
+
+struct DevTensor {
+    std::vector<int64_t> shape;
+    bf16_t* p = nullptr;
+    size_t n = 0;
+};
+
+struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; };
+struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown; };
+
+struct sonic_engine {
+    sonic_dims d;
+    int device = 0, mode = 0, Bm = 0, max_ctx = 0;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+    std::string err;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0;
+    bool finalized = false;
+
+    std::map<std::string, DevTensor> raw;
+    // packed weights
+    bf16_t *conv1w = nullptr, *conv2w = nullptr; float *conv1b = nullptr, *conv2b = nullptr;
+    std::vector<EncLayerW> enc;
+    float *enc_nw = nullptr, *enc_nb = nullptr;
+    bf16_t *pj1w = nullptr, *pj2w = nullptr; float *pj1b = nullptr, *pj2b = nullptr;
+    bf16_t* embed = nullptr;
+    std::vector<DecLayerW> dec;
+    float* dec_nw = nullptr;
+
+    // derived sizes
+    int T = 0, Tp = 0, Ta = 0, hd_e = 0, qkvN = 0, QD = 0, KD = 0, tok_cap = 0, out_cap = 0;
+    long slabN = 0;
+
+    // front-end
+    int16_t* pcm = nullptr; int* n_samples_d = nullptr; std::vector<int> n_samples_h; int W = 0;
+    float* logspec = nullptr; int* segmax = nullptr; bf16_t* feats_fm = nullptr; float* feats_f32 = nullptr;
+    LogmelConst lc{};
+    // encoder
+    bf16_t *h1 = nullptr, *x = nullptr, *ln = nullptr, *qk = nullptr, *vt = nullptr, *att = nullptr, *ff = nullptr, *ph = nullptr, *pe = nullptr;
+    float* enc_cs = nullptr;
+    // decoder
+    bf16_t *dx = nullptr, *dhn = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dact = nullptr;
+    bf16_t *Kc = nullptr, *Vc = nullptr, *Vts = nullptr;
+    float* dec_cs = nullptr;
+    float *slab = nullptr, *lslab = nullptr;
+    bf16_t *sx = nullptr, *shn = nullptr, *sq = nullptr, *satt = nullptr, *sact = nullptr;
+    int *kv_len = nullptr, *tok_pos = nullptr, *n_new = nullptr, *finished = nullptr, *max_new_d = nullptr, *n_active = nullptr;
+    int *out_ids = nullptr, *step_ctr = nullptr, *seq_iota = nullptr;
+    int *src = nullptr, *tok_seq = nullptr, *tok_pos_pf = nullptr, *q_off = nullptr, *q_len = nullptr, *last_row = nullptr;
+    float* dump = nullptr; size_t dump_cap = 0; int dump_steps = 0;
+    int* n_active_h = nullptr;  // pinned
+    int R = 0, max_steps = 0;
+    std::map<int, hipGraphExec_t> graphs;
+
+    // timing
+    hipEvent_t ev[5]{};
+    std::vector<hipEvent_t> gemm_ev;
+    int gemm_ev_used = 0;
+    sonic_timings tim{};
+};
+
+// ------------------------------------------------------------------------------------------ helpers
+static int fail(sonic_engine* e, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (e) e->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIPC(e, call)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _r = (call);                                                                            \
+        if (_r != hipSuccess) {                                                                            \
+            const bool oom = (_r == hipErrorOutOfMemory);                                                  \
+            return fail(e, oom ? SONIC_ERR_OOM : SONIC_ERR_HIP, "%s%s failed: %s (%s:%d)",                 \
+                        oom ? "HIP out of memory: " : "", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+        }                                                                                                  \
+    } while (0)
+
+template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
+    void* q = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(Tt);
+    HIPC(e, hipMalloc(&q, bytes));
+    e->allocs.push_back(q);
+    if (zero) HIPC(e, hipMemsetAsync(q, 0, bytes, e->st));
+    *p = (Tt*)q;
+    return SONIC_OK;
+}
+#define TRY(x) do { int _s = (x); if (_s != SONIC_OK) return _s; } while (0)
+
+static inline float bf16_round_host(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    memcpy(&x, &u, 4); return x;
+}
+static uint64_t mix64h(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31);
+}
+static uint64_t fnv1a64h(const char* s) { uint64_t h = 0xCBF29CE484222325ULL; for (; *s; ++s) { h ^= (uint8_t)*s; h *= 0x100000001B3ULL; } return h; }
+
+// small in-file kernels ---------------------------------------------------------------------------
+// [B][n_mels][n_frames] fp32 (HF layout) -> frame-major bf16 with one zero row each side
+__global__ void feats_to_fm_kernel(const float* in, bf16_t* out, int n_mels, int n_frames) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)n_mels * n_frames) return;
+    const int t = e / n_mels, m = e % n_mels;
+    out[((long)b * (n_frames + 2) + 1 + t) * n_mels + m] = f2bf(in[((long)b * n_mels + m) * n_frames + t]);
+}
+// conv weight [C][Ci][3] -> [C][3][Ci]
+__global__ void conv_permute_kernel(const bf16_t* in, bf16_t* out, int C, int Ci) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * Ci * 3) return;
+    const int k = e % 3, ci = (e / 3) % Ci, c = e / (3L * Ci);
+    out[((long)c * 3 + k) * Ci + ci] = in[e];
+}
+
+// ------------------------------------------------------------------------------------------ tensor inventory (spec.py order)
+struct InvEntry { std::string name; std::vector<int64_t> shape; int kind; };  // kind 0 mat, 1 embed, 2 bias, 3 norm
+static std::vector<InvEntry> inventory(const sonic_dims& d) {
+    std::vector<InvEntry> v;
+    const int64_t C = d.enc_d, F = d.enc_ff, M = d.n_mels;
+    auto add = [&](const std::string& n, std::vector<int64_t> s, int k) { v.push_back({n, s, k}); };
+    const std::string at = "model.audio_tower.";
+    add(at + "conv1.weight", {C, M, 3}, 0); add(at + "conv1.bias", {C}, 2);
+    add(at + "conv2.weight", {C, C, 3}, 0); add(at + "conv2.bias", {C}, 2);
+    for (int i = 0; i < d.enc_layers; ++i) {
+        const std::string p = at + "layers." + std::to_string(i) + ".";
+        add(p + "input_layernorm.weight", {C}, 3); add(p + "input_layernorm.bias", {C}, 2);
+        add(p + "self_attn.q_proj.weight", {C, C}, 0); add(p + "self_attn.q_proj.bias", {C}, 2);
+        add(p + "self_attn.k_proj.weight", {C, C}, 0);
+        add(p + "self_attn.v_proj.weight", {C, C}, 0); add(p + "self_attn.v_proj.bias", {C}, 2);
+        add(p + "self_attn.o_proj.weight", {C, C}, 0); add(p + "self_attn.o_proj.bias", {C}, 2);
+        add(p + "post_attention_layernorm.weight", {C}, 3); add(p + "post_attention_layernorm.bias", {C}, 2);
+        add(p + "mlp.fc1.weight", {F, C}, 0); add(p + "mlp.fc1.bias", {F}, 2);
+        add(p + "mlp.fc2.weight", {C, F}, 0); add(p + "mlp.fc2.bias", {C}, 2);
+    }
+    add(at + "norm.weight", {C}, 3); add(at + "norm.bias", {C}, 2);
+    const int64_t PI = C * d.merge, PM = 2L * d.dec_d, D = d.dec_d;
+    const std::string pj = "model.multi_modal_projector.";
+    add(pj + "linear_1.weight", {PM, PI}, 0); add(pj + "linear_1.bias", {PM}, 2);
+    add(pj + "linear_2.weight", {D, PM}, 0); add(pj + "linear_2.bias", {D}, 2);
+    const std::string lm = "model.language_model.";
+    add(lm + "embed_tokens.weight", {d.vocab, D}, 1);
+    const int64_t QD = (int64_t)d.dec_heads * d.dec_head_dim, KD = (int64_t)d.dec_kv_heads * d.dec_head_dim, FF = d.dec_ff;
+    for (int i = 0; i < d.dec_layers; ++i) {
+        const std::string p = lm + "layers." + std::to_string(i) + ".";
+        add(p + "input_layernorm.weight", {D}, 3);
+        add(p + "self_attn.q_proj.weight", {QD, D}, 0); add(p + "self_attn.k_proj.weight", {KD, D}, 0);
+        add(p + "self_attn.v_proj.weight", {KD, D}, 0); add(p + "self_attn.o_proj.weight", {D, QD}, 0);
+        add(p + "post_attention_layernorm.weight", {D}, 3);
+        add(p + "mlp.gate_proj.weight", {FF, D}, 0); add(p + "mlp.up_proj.weight", {FF, D}, 0); add(p + "mlp.down_proj.weight", {D, FF}, 0);
+    }
+    add(lm + "norm.weight", {D}, 3);
+    return v;
+}
+static size_t numel(const std::vector<int64_t>& s) { size_t n = 1; for (auto x : s) n *= (size_t)x; return n; }
+
+// ------------------------------------------------------------------------------------------ constants
+static int build_constants(sonic_engine* e) {
+    const sonic_dims& d = e->d;
+    std::vector<float> win(400), ct(400), stb(400);
+    for (int i = 0; i < 400; ++i) {
+        win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / 400.0));   // torch.hann_window(400), periodic
+        ct[i] = (float)cos(2.0 * M_PI * i / 400.0);
+        stb[i] = (float)sin(2.0 * M_PI * i / 400.0);
+    }
+    // slaney mel bank, HF:audio_utils.py:448-518,541-560,690-722 -> CSR per filter
+    const int nm = d.n_mels, nf = nm + 2;
+    auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + log(f / 1000.0) * (27.0 / log(6.4)) : 3.0 * f / 200.0; };
+    auto mel2hz = [](double m) { return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0; };
+    std::vector<double> ffq(nf);
+    const double mmin = hz2mel(0.0), mmax = hz2mel(8000.0);
+    for (int i = 0; i < nf; ++i) ffq[i] = mel2hz(i == nf - 1 ? mmax : mmin + (mmax - mmin) / (nf - 1) * i);
+    std::vector<int> lo(nm), cnt(nm), off(nm);
+    std::vector<float> w;
+    for (int m = 0; m < nm; ++m) {
+        int first = -1, last = -2;
+        std::vector<float> taps(201);
+        for (int b = 0; b < 201; ++b) {
+            const double fb = (b == 200) ? 8000.0 : 8000.0 / 200.0 * b;
+            const double down = -(ffq[m] - fb) / (ffq[m + 1] - ffq[m]), up = (ffq[m + 2] - fb) / (ffq[m + 2] - ffq[m + 1]);
+            double v = down < up ? down : up; if (v < 0) v = 0;
+            v *= 2.0 / (ffq[m + 2] - ffq[m]);
+            taps[b] = (float)v;
+            if (taps[b] != 0.f) { if (first < 0) first = b; last = b; }
+        }
+        if (first < 0) { first = 0; last = -1; }
+        lo[m] = first; cnt[m] = last - first + 1; off[m] = (int)w.size();
+        for (int b = first; b <= last; ++b) w.push_back(taps[b]);
+    }
+    float *dwin, *dct, *dst, *dw; int *dlo, *dcnt, *doff;
+    TRY(dalloc(e, &dwin, 400)); TRY(dalloc(e, &dct, 400)); TRY(dalloc(e, &dst, 400)); TRY(dalloc(e, &dw, w.size()));
+    TRY(dalloc(e, &dlo, nm)); TRY(dalloc(e, &dcnt, nm)); TRY(dalloc(e, &doff, nm));
+    HIPC(e, hipMemcpyAsync(dwin, win.data(), 1600, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(dct, ct.data(), 1600, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(dst, stb.data(), 1600, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(dlo, lo.data(), nm * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(dcnt, cnt.data(), nm * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(doff, off.data(), nm * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipStreamSynchronize(e->st));
+    e->lc = LogmelConst{dwin, dct, dst, dlo, dcnt, doff, dw};
+
+    // RoPE tables: cos/sin computed in fp32 and cast to the activation dtype (modeling_glmasr.py:95-106)
+    auto rope_table = [&](int n_pos, int rd, float theta, float** out) -> int {
+        const int half = rd / 2;
+        std::vector<float> t((size_t)n_pos * rd);
+        for (int p = 0; p < n_pos; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)rd);
+                const float ang = inv * (float)p;
+                t[(size_t)p * rd + i] = bf16_round_host(cosf(ang));
+                t[(size_t)p * rd + half + i] = bf16_round_host(sinf(ang));
+            }
+        TRY(dalloc(e, out, t.size()));
+        HIPC(e, hipMemcpy(*out, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        return SONIC_OK;
+    };
+    TRY(rope_table(e->T, d.enc_rotary_dim, d.enc_theta, &e->enc_cs));
+    TRY(rope_table(e->max_ctx, d.dec_head_dim, d.dec_theta, &e->dec_cs));
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ create / destroy
+extern "C" int sonic_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+static int check_dims(const sonic_dims& d, int max_batch, int max_ctx) {
+    if (d.n_mels <= 0 || d.n_mels % 64 != 0) return fail(nullptr, SONIC_ERR_INVALID, "n_mels must be a positive multiple of 64");
+    if (d.enc_d % 64 || d.enc_ff % 64 || d.dec_d % 128 || d.dec_ff % 128) return fail(nullptr, SONIC_ERR_INVALID, "hidden sizes must be multiples of 64 (encoder) / 128 (decoder)");
+    if (d.enc_d / d.enc_heads != 64 || d.enc_d % d.enc_heads) return fail(nullptr, SONIC_ERR_INVALID, "encoder head_dim must be 64");
+    if (d.dec_head_dim != 128) return fail(nullptr, SONIC_ERR_INVALID, "decoder head_dim must be 128");
+    if (d.enc_rotary_dim % 16 || d.enc_rotary_dim > 64) return fail(nullptr, SONIC_ERR_INVALID, "encoder rotary dim must be a multiple of 16");
+    if (d.dec_heads % d.dec_kv_heads || d.dec_heads / d.dec_kv_heads > 4) return fail(nullptr, SONIC_ERR_INVALID, "GQA group must divide and be <= 4");
+    if (d.vocab % 64) return fail(nullptr, SONIC_ERR_INVALID, "vocab must be a multiple of 64");
+    if (d.enc_T * 2 != d.n_frames || d.enc_T % d.merge || d.enc_T % 4) return fail(nullptr, SONIC_ERR_INVALID, "enc_T must be n_frames/2 and divisible by merge and 4");
+    if ((2 * d.enc_d) % 128) return fail(nullptr, SONIC_ERR_INVALID, "2*enc_d must be a multiple of 128");
+    if (max_batch < 1 || max_batch > 64) return fail(nullptr, SONIC_ERR_INVALID, "max_batch must be in 1..64");
+    if (max_ctx < 64 || max_ctx % 64 || max_ctx > 8192) return fail(nullptr, SONIC_ERR_INVALID, "max_ctx must be a multiple of 64 in 64..8192");
+    if (d.n_eos < 0 || d.n_eos > 8) return fail(nullptr, SONIC_ERR_INVALID, "n_eos must be 0..8");
+    return SONIC_OK;
+}
+
+extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out) {
+    if (!dims || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (mode == SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_UNSUPPORTED, "INT8 mode is not built yet (SURVEY.md §8a row a14, parity unpinned)");
+    if (mode != SONIC_MODE_NATIVE) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
+    TRY(check_dims(*dims, max_batch, max_ctx));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SONIC_ERR_HIP, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    sonic_engine* e = new sonic_engine();
+    e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
+    auto bail = [&](int code) { g_create_err = e->err; sonic_destroy(e); return code; };
+    if (hipSetDevice(device_id) != hipSuccess) { e->err = "hipSetDevice failed"; return bail(SONIC_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(SONIC_ERR_HIP); }
+    const sonic_dims& d = e->d;
+    e->T = d.enc_T; e->Tp = (d.enc_T + T_PAD_ALIGN - 1) / T_PAD_ALIGN * T_PAD_ALIGN; e->Ta = d.enc_T / d.merge; e->hd_e = d.enc_d / d.enc_heads;
+    e->QD = d.dec_heads * d.dec_head_dim; e->KD = d.dec_kv_heads * d.dec_head_dim; e->qkvN = e->QD + 2 * e->KD;
+    e->tok_cap = max_batch * max_ctx; e->out_cap = max_ctx;
+    const int Bm = max_batch, T = e->T, C = d.enc_d;
+    const size_t Mp = (size_t)Bm * T + 128;
+    int s;
+#define A(x) do { s = (x); if (s != SONIC_OK) return bail(s); } while (0)
+    A(dalloc(e, &e->pcm, (size_t)Bm * d.n_frames * 160)); A(dalloc(e, &e->n_samples_d, Bm));
+    A(dalloc(e, &e->logspec, (size_t)Bm * d.n_frames * d.n_mels)); A(dalloc(e, &e->segmax, Bm));
+    A(dalloc(e, &e->feats_fm, (size_t)Bm * (d.n_frames + 2) * d.n_mels + 4096));
+    A(dalloc(e, &e->h1, (size_t)Bm * (d.n_frames + 2) * C + 4096));
+    A(dalloc(e, &e->x, Mp * C)); A(dalloc(e, &e->ln, Mp * C)); A(dalloc(e, &e->att, Mp * C));
+    A(dalloc(e, &e->qk, Mp * 2 * C)); A(dalloc(e, &e->vt, (size_t)Bm * C * e->Tp)); A(dalloc(e, &e->ff, Mp * d.enc_ff));
+    A(dalloc(e, &e->ph, ((size_t)Bm * e->Ta + 128) * 2 * d.dec_d)); A(dalloc(e, &e->pe, ((size_t)Bm * e->Ta + 128) * d.dec_d));
+    const size_t tc = (size_t)e->tok_cap + 128;
+    A(dalloc(e, &e->dx, tc * d.dec_d)); A(dalloc(e, &e->dhn, tc * d.dec_d)); A(dalloc(e, &e->dqkv, tc * e->qkvN));
+    A(dalloc(e, &e->dq, tc * e->QD)); A(dalloc(e, &e->datt, tc * e->QD)); A(dalloc(e, &e->dact, tc * d.dec_ff));
+    const size_t kvn = (size_t)d.dec_layers * Bm * d.dec_kv_heads * max_ctx * d.dec_head_dim;
+    A(dalloc(e, &e->Kc, kvn)); A(dalloc(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
+    long mx = 2L * d.dec_ff; if (e->qkvN > mx) mx = e->qkvN; if (d.dec_d > mx) mx = d.dec_d;
+    e->slabN = mx;
+    A(dalloc(e, &e->slab, (size_t)8 * 64 * mx)); A(dalloc(e, &e->lslab, (size_t)64 * d.vocab));
+    A(dalloc(e, &e->sx, (size_t)64 * d.dec_d)); A(dalloc(e, &e->shn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->sq, (size_t)64 * e->QD));
+    A(dalloc(e, &e->satt, (size_t)64 * e->QD)); A(dalloc(e, &e->sact, (size_t)64 * d.dec_ff));
+    A(dalloc(e, &e->kv_len, 64)); A(dalloc(e, &e->tok_pos, 64)); A(dalloc(e, &e->n_new, 64)); A(dalloc(e, &e->finished, 64));
+    A(dalloc(e, &e->max_new_d, 64)); A(dalloc(e, &e->n_active, 4)); A(dalloc(e, &e->out_ids, (size_t)64 * e->out_cap));
+    A(dalloc(e, &e->step_ctr, 64)); A(dalloc(e, &e->seq_iota, 64));
+    A(dalloc(e, &e->src, tc)); A(dalloc(e, &e->tok_seq, tc)); A(dalloc(e, &e->tok_pos_pf, tc));
+    A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
+    {
+        int iota[64]; for (int i = 0; i < 64; ++i) iota[i] = i;
+        if (hipMemcpy(e->seq_iota, iota, sizeof iota, hipMemcpyHostToDevice) != hipSuccess) { e->err = "memcpy failed"; return bail(SONIC_ERR_HIP); }
+    }
+    if (hipHostMalloc((void**)&e->n_active_h, 64, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return bail(SONIC_ERR_HIP); }
+    for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
+    e->gemm_ev.resize(2 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));
+    for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
+    A(build_constants(e));
+#undef A
+    e->n_samples_h.assign(Bm, 0);
+    if (hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; return bail(SONIC_ERR_HIP); }
+    *out = e;
+    return SONIC_OK;
+}
+
+extern "C" void sonic_destroy(sonic_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->st) (void)hipStreamSynchronize(e->st);
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->dump) (void)hipFree(e->dump);
+    if (e->feats_f32) (void)hipFree(e->feats_f32);
+    if (e->n_active_h) (void)hipHostFree(e->n_active_h);
+    for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
+    for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
+    if (e->st) (void)hipStreamDestroy(e->st);
+    delete e;
+}
+
+extern "C" const char* sonic_last_error(sonic_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+extern "C" int64_t sonic_weight_bytes(sonic_engine* e) { return e ? e->weight_bytes : 0; }
+extern "C" int sonic_synchronize(sonic_engine* e) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    HIPC(e, hipStreamSynchronize(e->st));
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+static int raw_alloc(sonic_engine* e, const std::string& name, const std::vector<int64_t>& shape, DevTensor** out) {
+    DevTensor& t = e->raw[name];
+    if (!t.p) {
+        t.shape = shape; t.n = numel(shape);
+        void* q = nullptr;
+        HIPC(e, hipMalloc(&q, t.n * sizeof(bf16_t)));
+        t.p = (bf16_t*)q;
+    } else if (t.shape != shape) return fail(e, SONIC_ERR_INVALID, "tensor %s loaded twice with different shapes", name.c_str());
+    *out = &t;
+    return SONIC_OK;
+}
+
+extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !data || !shape) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (e->finalized) return fail(e, SONIC_ERR_INVALID, "weights already finalized");
+    std::vector<int64_t> shp(shape, shape + ndim);
+    bool known = false;
+    for (auto& it : inventory(e->d)) if (it.name == name) { known = true; if (it.shape != shp) return fail(e, SONIC_ERR_INVALID, "tensor %s: unexpected shape", name); }
+    if (!known) return fail(e, SONIC_ERR_INVALID, "unknown tensor name %s", name);
+    DevTensor* t;
+    TRY(raw_alloc(e, name, shp, &t));
+    if (dtype == SONIC_DTYPE_BF16) {
+        HIPC(e, hipMemcpy(t->p, data, t->n * 2, hipMemcpyHostToDevice));
+    } else if (dtype == SONIC_DTYPE_F32) {
+        float* tmp = nullptr;
+        HIPC(e, hipMalloc((void**)&tmp, t->n * 4));
+        hipError_t r = hipMemcpy(tmp, data, t->n * 4, hipMemcpyHostToDevice);
+        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st); r = hipStreamSynchronize(e->st); }
+        (void)hipFree(tmp);
+        HIPC(e, r);
+    } else return fail(e, SONIC_ERR_INVALID, "dtype must be f32 or bf16");
+    return SONIC_OK;
+}
+
+extern "C" int sonic_load_synthetic(sonic_engine* e, uint64_t seed) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (e->finalized) return fail(e, SONIC_ERR_INVALID, "weights already finalized");
+    for (auto& it : inventory(e->d)) {
+        DevTensor* t;
+        TRY(raw_alloc(e, it.name, it.shape, &t));
+        float scale = 0.1f, offset = 0.f;
+        if (it.kind == 0) { double fi = 1; for (size_t i = 1; i < it.shape.size(); ++i) fi *= (double)it.shape[i]; scale = (float)sqrt(3.0 / fi); }
+        else if (it.kind == 1) scale = (float)sqrt(3.0 / (double)it.shape[1]);
+        else if (it.kind == 3) offset = 1.0f;
+        const uint64_t key = mix64h(seed * 0x9E3779B97F4A7C15ULL + fnv1a64h(it.name.c_str()));
+        launch_synth_fill(key, (long)t->n, scale, offset, t->p, nullptr, e->st);
+    }
+    HIPC(e, hipStreamSynchronize(e->st));
+    return SONIC_OK;
+}
+
+static int need(sonic_engine* e, const std::string& name, DevTensor** t) {
+    auto it = e->raw.find(name);
+    if (it == e->raw.end() || !it->second.p) return fail(e, SONIC_ERR_INVALID, "missing weight tensor %s", name.c_str());
+    *t = &it->second;
+    return SONIC_OK;
+}
+static int to_f32(sonic_engine* e, const std::string& name, float** out) {
+    DevTensor* t; TRY(need(e, name, &t));
+    TRY(dalloc(e, out, t->n, false));
+    launch_bf16_to_f32(t->p, *out, (long)t->n, e->st);
+    e->weight_bytes += (int64_t)t->n * 4;
+    return SONIC_OK;
+}
+// concatenate row blocks of [rows_i][K] tensors
+static int concat_rows(sonic_engine* e, const std::vector<std::string>& names, bf16_t** out) {
+    size_t tot = 0; std::vector<DevTensor*> ts;
+    for (auto& n : names) { DevTensor* t; TRY(need(e, n, &t)); ts.push_back(t); tot += t->n; }
+    TRY(dalloc(e, out, tot, false));
+    size_t o = 0;
+    for (auto* t : ts) { HIPC(e, hipMemcpyAsync(*out + o, t->p, t->n * 2, hipMemcpyDeviceToDevice, e->st)); o += t->n; }
+    e->weight_bytes += (int64_t)tot * 2;
+    return SONIC_OK;
+}
+static int keep_raw(sonic_engine* e, const std::string& name, bf16_t** out) {
+    DevTensor* t; TRY(need(e, name, &t));
+    *out = t->p; e->allocs.push_back(t->p); t->p = nullptr;   // ownership moves to the engine's alloc list
+    e->weight_bytes += (int64_t)t->n * 2;
+    return SONIC_OK;
+}
+
+extern "C" int sonic_finalize_weights(sonic_engine* e) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (e->finalized) return SONIC_OK;
+    const sonic_dims& d = e->d;
+    const std::string at = "model.audio_tower.", pj = "model.multi_modal_projector.", lm = "model.language_model.";
+    e->weight_bytes = 0;
+    {   // conv stem in im2col order [C][3][Ci]
+        DevTensor *w1, *w2; TRY(need(e, at + "conv1.weight", &w1)); TRY(need(e, at + "conv2.weight", &w2));
+        TRY(dalloc(e, &e->conv1w, w1->n, false)); TRY(dalloc(e, &e->conv2w, w2->n, false));
+        hipLaunchKernelGGL(conv_permute_kernel, dim3((w1->n + 255) / 256), dim3(256), 0, e->st, w1->p, e->conv1w, d.enc_d, d.n_mels);
+        hipLaunchKernelGGL(conv_permute_kernel, dim3((w2->n + 255) / 256), dim3(256), 0, e->st, w2->p, e->conv2w, d.enc_d, d.enc_d);
+        e->weight_bytes += (int64_t)(w1->n + w2->n) * 2;
+        TRY(to_f32(e, at + "conv1.bias", &e->conv1b)); TRY(to_f32(e, at + "conv2.bias", &e->conv2b));
+    }
+    e->enc.resize(d.enc_layers);
+    for (int i = 0; i < d.enc_layers; ++i) {
+        const std::string p = at + "layers." + std::to_string(i) + ".";
+        EncLayerW& L = e->enc[i];
+        TRY(to_f32(e, p + "input_layernorm.weight", &L.ln1w)); TRY(to_f32(e, p + "input_layernorm.bias", &L.ln1b));
+        TRY(concat_rows(e, {p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, &L.wqkv));
+        TRY(dalloc(e, &L.bqkv, (size_t)3 * d.enc_d, true));   // k_proj has no bias (modeling_glmasr.py:184)
+        DevTensor *bq, *bv; TRY(need(e, p + "self_attn.q_proj.bias", &bq)); TRY(need(e, p + "self_attn.v_proj.bias", &bv));
+        launch_bf16_to_f32(bq->p, L.bqkv, d.enc_d, e->st);
+        launch_bf16_to_f32(bv->p, L.bqkv + 2 * d.enc_d, d.enc_d, e->st);
+        TRY(keep_raw(e, p + "self_attn.o_proj.weight", &L.wo)); TRY(to_f32(e, p + "self_attn.o_proj.bias", &L.bo));
+        TRY(to_f32(e, p + "post_attention_layernorm.weight", &L.ln2w)); TRY(to_f32(e, p + "post_attention_layernorm.bias", &L.ln2b));
+        TRY(keep_raw(e, p + "mlp.fc1.weight", &L.w1)); TRY(to_f32(e, p + "mlp.fc1.bias", &L.b1));
+        TRY(keep_raw(e, p + "mlp.fc2.weight", &L.w2)); TRY(to_f32(e, p + "mlp.fc2.bias", &L.b2));
+    }
+    TRY(to_f32(e, at + "norm.weight", &e->enc_nw)); TRY(to_f32(e, at + "norm.bias", &e->enc_nb));
+    TRY(keep_raw(e, pj + "linear_1.weight", &e->pj1w)); TRY(to_f32(e, pj + "linear_1.bias", &e->pj1b));
+    TRY(keep_raw(e, pj + "linear_2.weight", &e->pj2w)); TRY(to_f32(e, pj + "linear_2.bias", &e->pj2b));
+    TRY(keep_raw(e, lm + "embed_tokens.weight", &e->embed));
+    e->dec.resize(d.dec_layers);
+    for (int i = 0; i < d.dec_layers; ++i) {
+        const std::string p = lm + "layers." + std::to_string(i) + ".";
+        DecLayerW& L = e->dec[i];
+        TRY(to_f32(e, p + "input_layernorm.weight", &L.ln1)); TRY(to_f32(e, p + "post_attention_layernorm.weight", &L.ln2));
+        TRY(concat_rows(e, {p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, &L.wqkv));
+        TRY(keep_raw(e, p + "self_attn.o_proj.weight", &L.wo));
+        // gate / up interleaved in 16-row groups (EPI_SWIGLU, swiglu_slab_kernel)
+        DevTensor *g, *u; TRY(need(e, p + "mlp.gate_proj.weight", &g)); TRY(need(e, p + "mlp.up_proj.weight", &u));
+        TRY(dalloc(e, &L.wgu, g->n * 2, false));
+        const size_t blk = (size_t)16 * d.dec_d * 2;
+        HIPC(e, hipMemcpy2DAsync(L.wgu, 2 * blk, g->p, blk, blk, d.dec_ff / 16, hipMemcpyDeviceToDevice, e->st));
+        HIPC(e, hipMemcpy2DAsync((char*)L.wgu + blk, 2 * blk, u->p, blk, blk, d.dec_ff / 16, hipMemcpyDeviceToDevice, e->st));
+        e->weight_bytes += (int64_t)g->n * 4;
+        TRY(keep_raw(e, p + "mlp.down_proj.weight", &L.wdown));
+    }
+    TRY(to_f32(e, lm + "norm.weight", &e->dec_nw));
+    HIPC(e, hipStreamSynchronize(e->st));
+    for (auto& kv : e->raw) if (kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; }
+    e->raw.clear();
+    e->finalized = true;
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ pipeline stages
+static void gemm(sonic_engine* e, int epi, const bf16_t* A, long lda, const bf16_t* W, const float* bias, bf16_t* C, long ldc,
+                 int M, int N, int K, const bf16_t* R = nullptr, long ldr = 0) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1;
+    launch_gemm(a, epi, e->st);
+}
+
+static int run_mel(sonic_engine* e, int W, bool want_f32) {
+    const sonic_dims& d = e->d;
+    if (want_f32 && !e->feats_f32) {
+        HIPC(e, hipMalloc((void**)&e->feats_f32, (size_t)e->Bm * d.n_mels * d.n_frames * 4));
+    }
+    int mx = 0; for (int i = 0; i < W; ++i) mx = e->n_samples_h[i] > mx ? e->n_samples_h[i] : mx;
+    launch_logmel(e->pcm, (long)d.n_frames * 160, e->n_samples_d, mx, e->lc, e->logspec, e->segmax, W, d.n_frames, d.n_mels,
+                  e->feats_fm, want_f32 ? e->feats_f32 : nullptr, e->st);
+    return SONIC_OK;
+}
+
+// feats_fm (bf16, frame-major, padded) -> pe [W*Ta][dec_d]
+static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc_out_host) {
+    const sonic_dims& d = e->d;
+    const int C = d.enc_d, T = e->T, M = W * T, H = d.enc_heads;
+    {   // conv stem as two batched im2col-free GEMMs (modeling_glmasr.py:313-316)
+        GemmArgs a{};
+        a.A = e->feats_fm; a.lda = d.n_mels; a.W = e->conv1w; a.bias = e->conv1b; a.C = e->h1 + C; a.ldc = C;
+        a.M = d.n_frames; a.N = C; a.K = 3 * d.n_mels; a.batch = W;
+        a.strideA = (long)(d.n_frames + 2) * d.n_mels; a.strideC = (long)(d.n_frames + 2) * C;
+        launch_gemm(a, EPI_BIAS_GELU, e->st);
+        GemmArgs b{};
+        b.A = e->h1; b.lda = 2L * C; b.W = e->conv2w; b.bias = e->conv2b; b.C = e->x; b.ldc = C;
+        b.M = T; b.N = C; b.K = 3 * C; b.batch = W; b.strideA = (long)(d.n_frames + 2) * C; b.strideC = (long)T * C;
+        launch_gemm(b, EPI_BIAS_GELU, e->st);
+    }
+    float* tap = nullptr;
+    if (enc_layers_out || enc_out_host) HIPC(e, hipMalloc((void**)&tap, (size_t)M * C * 4));
+    e->gemm_ev_used = 0;
+    for (int l = 0; l < d.enc_layers; ++l) {
+        const EncLayerW& L = e->enc[l];
+        launch_layernorm(e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, e->st);
+        {
+            GemmArgs a{};
+            a.A = e->ln; a.lda = C; a.W = L.wqkv; a.bias = L.bqkv; a.C = e->qk; a.ldc = 2L * C; a.M = M; a.N = 3 * C; a.K = C; a.batch = 1;
+            a.Vt = e->vt; a.n_split = 2 * C; a.seg_T = T; a.vt_ld = e->Tp; a.vt_seg_stride = (long)C * e->Tp;
+            launch_gemm(a, EPI_QKV_VT, e->st);
+        }
+        launch_rope_enc(e->qk, 2L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st);
+        {
+            FlashArgs f{};
+            f.Q = e->qk; f.q_ld = 2L * C; f.K = e->qk + C; f.k_ld = 2L * C; f.Vt = e->vt; f.vt_ld = e->Tp; f.O = e->att; f.o_ld = C;
+            f.q_seq_stride = (long)T * 2 * C; f.k_seq_stride = (long)T * 2 * C; f.k_head_stride = e->hd_e;
+            f.vt_seq_stride = (long)C * e->Tp; f.vt_head_stride = (long)e->hd_e * e->Tp;
+            f.T = T; f.Hq = H; f.Hkv = H; f.scale = 1.0f / sqrtf((float)e->hd_e);
+            launch_flash(f, 64, false, W, T, e->st);
+        }
+        gemm(e, EPI_BIAS_RESID, e->att, C, L.wo, L.bo, e->x, C, M, C, C, e->x, C);
+        launch_layernorm(e->x, L.ln2w, L.ln2b, e->ln, M, C, d.enc_ln_eps, e->st);
+        const bool tev = (size_t)(2 * l + 1) < e->gemm_ev.size();
+        if (tev) (void)hipEventRecord(e->gemm_ev[2 * l], e->st);
+        gemm(e, EPI_BIAS_GELU, e->ln, C, L.w1, L.b1, e->ff, d.enc_ff, M, d.enc_ff, C);
+        if (tev) { (void)hipEventRecord(e->gemm_ev[2 * l + 1], e->st); e->gemm_ev_used = l + 1; }
+        gemm(e, EPI_BIAS_RESID, e->ff, d.enc_ff, L.w2, L.b2, e->x, C, M, C, d.enc_ff, e->x, C);
+        if (enc_layers_out) {
+            launch_bf16_to_f32(e->x, tap, (long)M * C, e->st);
+            HIPC(e, hipStreamSynchronize(e->st));
+            for (int b = 0; b < W; ++b)
+                HIPC(e, hipMemcpy(enc_layers_out + ((size_t)b * d.enc_layers + l) * T * C, tap + (size_t)b * T * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    launch_layernorm(e->x, e->enc_nw, e->enc_nb, e->ln, M, C, d.enc_ln_eps, e->st);
+    if (enc_out_host) {
+        launch_bf16_to_f32(e->ln, tap, (long)M * C, e->st);
+        HIPC(e, hipStreamSynchronize(e->st));
+        HIPC(e, hipMemcpy(enc_out_host, tap, (size_t)M * C * 4, hipMemcpyDeviceToHost));
+    }
+    if (tap) (void)hipFree(tap);
+    // 4-frame merge is a view: [M][C] == [W*Ta][4C] (modeling_glmasr.py:392-397)
+    const int Mp = W * e->Ta, PI = C * d.merge, PM = 2 * d.dec_d;
+    gemm(e, EPI_BIAS_GELU, e->ln, PI, e->pj1w, e->pj1b, e->ph, PM, Mp, PM, PI);
+    gemm(e, EPI_BIAS, e->ph, PM, e->pj2w, e->pj2b, e->pe, d.dec_d, Mp, d.dec_d, PM);
+    return SONIC_OK;
+}
+
+static int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+static int keep_rows(const sonic_dims& d, int n_valid_frames) {  // modeling_glmasr.py:399-403 (python floor division)
+    int L = n_valid_frames;
+    L = floordiv(L + 2 - 2 - 1, 1) + 1;
+    L = floordiv(L + 2 - 2 - 1, 2) + 1;
+    const int k = floordiv(L - d.merge, d.merge) + 1;
+    const int Ta = d.enc_T / d.merge;
+    return k < 0 ? 0 : (k > Ta ? Ta : k);
+}
+static int frames_of(int n_samples) { return n_samples > 0 ? (n_samples + 159) / 160 : 0; }
+
+static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, float* P, int M, int N, int K, int* ks_out) {
+    SkinnyArgs a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = (P == e->lslab) ? 1 : skinny_pick_ksplit(N, K);
+    if (ks_out) *ks_out = a.ksplit;
+    launch_skinny(a, e->st);
+}
+
+static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
+    const sonic_dims& d = e->d;
+    GreedyArgs g{};
+    g.logits = e->lslab; g.V = d.vocab; g.B = R; g.table = e->embed; g.x = e->sx; g.d = d.dec_d;
+    g.out_ids = e->out_ids; g.out_ld = e->out_cap; g.n_new = e->n_new; g.finished = e->finished; g.kv_len = e->kv_len; g.tok_pos = e->tok_pos;
+    g.max_new = e->max_new_d; g.n_active = e->n_active; g.n_eos = d.n_eos; g.pad_id = d.n_eos > 0 ? d.eos[0] : 0;
+    for (int i = 0; i < d.n_eos; ++i) g.eos[i] = d.eos[i];
+    g.logits_dump = dump ? e->dump : nullptr; g.dump_stride_step = (long)R * d.vocab; g.step_counter = dump ? e->step_ctr : nullptr;
+    return g;
+}
+
+// one decode step for R rows: sx (bf16 [R][d]) -> next token (generation/utils.py:2876-2943)
+static void decode_step(sonic_engine* e, int R, bool dump) {
+    const sonic_dims& d = e->d;
+    const int D = d.dec_d, mpad = ((R + 15) / 16) * 16;
+    int ks;
+    launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st);
+    for (int l = 0; l < d.dec_layers; ++l) {
+        const DecLayerW& L = e->dec[l];
+        const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
+        skinny(e, e->shn, D, L.wqkv, e->slab, R, e->qkvN, D, &ks);
+        RopeAppendArgs ra{};
+        ra.P = e->slab; ra.ksplit = ks; ra.mpad = mpad; ra.q_out = e->sq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = nullptr;
+        ra.tok_seq = e->seq_iota; ra.tok_pos = e->tok_pos; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = R;
+        launch_rope_append(ra, true, e->st);
+        DecodeAttnArgs da{};
+        da.Q = e->sq; da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
+        da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
+        launch_decode_attn(da, R, e->st);
+        skinny(e, e->satt, e->QD, L.wo, e->slab, R, D, e->QD, &ks);
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st);
+        skinny(e, e->shn, D, L.wgu, e->slab, R, 2 * d.dec_ff, D, &ks);
+        launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st);
+        skinny(e, e->sact, d.dec_ff, L.wdown, e->slab, R, D, d.dec_ff, &ks);
+        const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st);
+    }
+    skinny(e, e->shn, D, e->embed, e->lslab, R, d.vocab, D, nullptr);   // tied lm_head (modeling_glmasr.py:517)
+    launch_greedy(greedy_args(e, R, dump), e->st);
+}
+
+struct HostPlan {
+    std::vector<int> src, tok_seq, tok_pos, q_off, q_len, last_row, max_new;
+    int n_tok = 0, max_p = 0, max_steps = 0;
+};
+
+static int plan_requests(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                         const int32_t* max_new, HostPlan& hp) {
+    const sonic_dims& d = e->d;
+    const int W = e->W;
+    if (R < 1 || R > e->Bm) return fail(e, SONIC_ERR_INVALID, "request count %d out of range 1..%d", R, e->Bm);
+    if (!req_win && R != W) return fail(e, SONIC_ERR_INVALID, "R (%d) must equal staged windows (%d) when req_win is NULL", R, W);
+    if (req_win && (req_win[0] != 0 || req_win[R] != W)) return fail(e, SONIC_ERR_INVALID, "req_win must cover exactly the staged windows");
+    hp.q_off.resize(R); hp.q_len.resize(R); hp.last_row.resize(R); hp.max_new.resize(R);
+    for (int r = 0; r < R; ++r) {
+        const int w0 = req_win ? req_win[r] : r, w1 = req_win ? req_win[r + 1] : r + 1;
+        if (w1 <= w0) return fail(e, SONIC_ERR_INVALID, "request %d has no audio window", r);
+        std::vector<int> rows;  // audio rows of this request in order
+        for (int w = w0; w < w1; ++w) {
+            const int k = keep_rows(d, frames_of(e->n_samples_h[w]));
+            for (int j = 0; j < k; ++j) rows.push_back(w * e->Ta + j);
+        }
+        const int64_t p0 = prompt_off[r], p1 = prompt_off[r + 1];
+        const int P = (int)(p1 - p0);
+        if (P < 1) return fail(e, SONIC_ERR_INVALID, "request %d has an empty prompt", r);
+        if (max_new[r] < 1) return fail(e, SONIC_ERR_INVALID, "max_new_tokens must be >= 1");
+        if (P + max_new[r] > e->max_ctx) return fail(e, SONIC_ERR_INVALID, "prompt (%d) + max_new_tokens (%d) exceeds max_ctx (%d)", P, max_new[r], e->max_ctx);
+        if (max_new[r] > e->out_cap) return fail(e, SONIC_ERR_INVALID, "max_new_tokens too large");
+        size_t used = 0; int n_ph = 0;
+        for (int i = 0; i < P; ++i) n_ph += (prompt_ids[p0 + i] == d.audio_token_id);
+        if ((size_t)n_ph != rows.size())
+            return fail(e, SONIC_ERR_MISMATCH, "Audio features and audio tokens do not match, tokens: %d, features: %zu", n_ph, rows.size());
+        hp.q_off[r] = hp.n_tok; hp.q_len[r] = P;
+        for (int i = 0; i < P; ++i) {
+            const int id = prompt_ids[p0 + i];
+            if (id == d.audio_token_id) hp.src.push_back(-(1 + rows[used++]));
+            else {
+                if (id < 0 || id >= d.vocab) return fail(e, SONIC_ERR_INVALID, "token id %d out of vocabulary", id);
+                hp.src.push_back(id);
+            }
+            hp.tok_seq.push_back(r); hp.tok_pos.push_back(i);
+        }
+        hp.n_tok += P;
+        hp.last_row[r] = hp.n_tok - 1;
+        hp.max_new[r] = max_new[r];
+        if (P > hp.max_p) hp.max_p = P;
+        if (max_new[r] > hp.max_steps) hp.max_steps = max_new[r];
+    }
+    if (hp.n_tok > e->tok_cap) return fail(e, SONIC_ERR_INVALID, "too many prompt tokens");
+    return SONIC_OK;
+}
+
+static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
+    const sonic_dims& d = e->d;
+    const int D = d.dec_d, M = hp.n_tok;
+    HIPC(e, hipMemcpyAsync(e->src, hp.src.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->tok_seq, hp.tok_seq.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->tok_pos_pf, hp.tok_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->q_off, hp.q_off.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->q_len, hp.q_len.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->kv_len, hp.q_len.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->last_row, hp.last_row.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemcpyAsync(e->max_new_d, hp.max_new.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipMemsetAsync(e->n_new, 0, 64 * 4, e->st));
+    HIPC(e, hipMemsetAsync(e->finished, 0, 64 * 4, e->st));
+    HIPC(e, hipMemsetAsync(e->step_ctr, 0, 64 * 4, e->st));
+    HIPC(e, hipMemcpyAsync(e->n_active, &R, 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipStreamSynchronize(e->st));   // host vectors go out of scope with the caller; tiny copies
+    launch_assemble_embeds(e->src, e->embed, e->pe, e->dx, M, D, e->st);
+    for (int l = 0; l < d.dec_layers; ++l) {
+        const DecLayerW& L = e->dec[l];
+        const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
+        launch_rmsnorm(e->dx, L.ln1, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st);
+        gemm(e, EPI_BIAS, e->dhn, D, L.wqkv, nullptr, e->dqkv, e->qkvN, M, e->qkvN, D);
+        RopeAppendArgs ra{};
+        ra.qkv = e->dqkv; ra.ld = e->qkvN; ra.q_out = e->dq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = e->Vts; ra.vt_ld = e->max_ctx;
+        ra.tok_seq = e->tok_seq; ra.tok_pos = e->tok_pos_pf; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = M;
+        launch_rope_append(ra, false, e->st);
+        FlashArgs f{};
+        f.Q = e->dq; f.q_ld = e->QD; f.K = e->Kc + kvoff; f.k_ld = d.dec_head_dim; f.Vt = e->Vts; f.vt_ld = e->max_ctx; f.O = e->datt; f.o_ld = e->QD;
+        f.k_seq_stride = (long)d.dec_kv_heads * e->max_ctx * d.dec_head_dim; f.k_head_stride = (long)e->max_ctx * d.dec_head_dim;
+        f.vt_seq_stride = (long)d.dec_kv_heads * d.dec_head_dim * e->max_ctx; f.vt_head_stride = (long)d.dec_head_dim * e->max_ctx;
+        f.q_off = e->q_off; f.q_len = e->q_len; f.kv_len = e->q_len; f.Hq = d.dec_heads; f.Hkv = d.dec_kv_heads;
+        f.scale = 1.0f / sqrtf((float)d.dec_head_dim);
+        launch_flash(f, 128, true, R, hp.max_p, e->st);
+        gemm(e, EPI_BIAS_RESID, e->datt, e->QD, L.wo, nullptr, e->dx, D, M, D, e->QD, e->dx, D);
+        launch_rmsnorm(e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st);
+        gemm(e, EPI_SWIGLU, e->dhn, D, L.wgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D);
+        gemm(e, EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, nullptr, e->dx, D, M, D, d.dec_ff, e->dx, D);
+    }
+    // logits only for the last prompt position of each request (logits_to_keep=1, generation/utils.py:2612-2616)
+    launch_rmsnorm(e->dx, e->dec_nw, e->shn, R, D, d.dec_rms_eps, e->last_row, e->st);
+    skinny(e, e->shn, D, e->embed, e->lslab, R, d.vocab, D, nullptr);
+    return SONIC_OK;
+}
+
+static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                   const int32_t* max_new, bool want_logits) {
+    const sonic_dims& d = e->d;
+    if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
+    if (e->W < 1) return fail(e, SONIC_ERR_INVALID, "no PCM staged");
+    HostPlan hp;
+    TRY(plan_requests(e, req_win, R, prompt_ids, prompt_off, max_new, hp));
+    e->R = R; e->max_steps = hp.max_steps;
+    if (want_logits) {
+        const size_t need_n = (size_t)hp.max_steps * R * d.vocab;
+        if (need_n > e->dump_cap) {
+            if (e->dump) (void)hipFree(e->dump);
+            e->dump = nullptr; e->dump_cap = 0;
+            HIPC(e, hipMalloc((void**)&e->dump, need_n * 4));
+            e->dump_cap = need_n;
+        }
+        e->dump_steps = hp.max_steps;
+    } else e->dump_steps = 0;
+
+    (void)hipEventRecord(e->ev[0], e->st);
+    TRY(run_mel(e, e->W, false));
+    (void)hipEventRecord(e->ev[1], e->st);
+    TRY(run_encoder(e, e->W, nullptr, nullptr));
+    (void)hipEventRecord(e->ev[2], e->st);
+    TRY(run_prefill(e, R, hp));
+    launch_greedy(greedy_args(e, R, want_logits), e->st);
+    (void)hipEventRecord(e->ev[3], e->st);
+
+    // ---- decode loop: hipGraph replay of one captured step
+    const bool use_graph = !want_logits && getenv("SONIC_NO_GRAPH") == nullptr;
+    hipGraphExec_t gx = nullptr;
+    if (use_graph && hp.max_steps > 1) {
+        auto it = e->graphs.find(R);
+        if (it == e->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPC(e, hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
+            decode_step(e, R, false);
+            HIPC(e, hipStreamEndCapture(e->st, &g));
+            HIPC(e, hipGraphInstantiate(&gx, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            e->graphs[R] = gx;
+        } else gx = it->second;
+    }
+    int steps_done = 0;
+    for (int s = 1; s < hp.max_steps; ++s) {
+        if (gx) HIPC(e, hipGraphLaunch(gx, e->st)); else decode_step(e, R, want_logits);
+        ++steps_done;
+        if ((s & 15) == 0 && s + 1 < hp.max_steps) {   // ragged termination: stop once every row hit EOS / its budget
+            HIPC(e, hipMemcpyAsync(e->n_active_h, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+            HIPC(e, hipStreamSynchronize(e->st));
+            if (*e->n_active_h <= 0) break;
+        }
+    }
+    (void)hipEventRecord(e->ev[4], e->st);
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    sonic_timings& t = e->tim;
+    memset(&t, 0, sizeof t);
+    (void)hipEventElapsedTime(&t.mel_ms, e->ev[0], e->ev[1]);
+    (void)hipEventElapsedTime(&t.encoder_ms, e->ev[1], e->ev[2]);
+    (void)hipEventElapsedTime(&t.prefill_ms, e->ev[2], e->ev[3]);
+    (void)hipEventElapsedTime(&t.decode_ms, e->ev[3], e->ev[4]);
+    (void)hipEventElapsedTime(&t.total_ms, e->ev[0], e->ev[4]);
+    for (int l = 0; l < e->gemm_ev_used; ++l) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, e->gemm_ev[2 * l], e->gemm_ev[2 * l + 1]);
+        t.gemm_ms += ms; t.gemm_launches += 1;
+        t.gemm_flops += 2.0 * (double)e->W * e->T * d.enc_ff * d.enc_d;
+    }
+    t.decode_steps = steps_done;
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: hot path
+static int stage_pcm_locked(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W) {
+    const sonic_dims& d = e->d;
+    if (!pcm || !offsets) return fail(e, SONIC_ERR_INVALID, "null argument");
+    if (W < 1 || W > e->Bm) return fail(e, SONIC_ERR_INVALID, "window count %d out of range 1..%d", W, e->Bm);
+    const long cap = (long)d.n_frames * 160;
+    for (int i = 0; i < W; ++i) {
+        const int64_t n = offsets[i + 1] - offsets[i];
+        if (n < 0 || n > cap) return fail(e, SONIC_ERR_INVALID, "window %d has %lld samples (max %ld)", i, (long long)n, cap);
+        e->n_samples_h[i] = (int)n;
+        if (n > 0) HIPC(e, hipMemcpyAsync(e->pcm + (size_t)i * cap, pcm + offsets[i], (size_t)n * 2, hipMemcpyHostToDevice, e->st));
+    }
+    HIPC(e, hipMemcpyAsync(e->n_samples_d, e->n_samples_h.data(), (size_t)W * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipStreamSynchronize(e->st));
+    e->W = W;
+    return SONIC_OK;
+}
+
+extern "C" int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    return stage_pcm_locked(e, pcm, offsets, W);
+}
+
+extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                                const int32_t* max_new, int want_step_logits) {
+    if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    return run_all(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0);
+}
+
+static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
+    const int R = e->R;
+    if (R < 1) return fail(e, SONIC_ERR_INVALID, "nothing to fetch");
+    std::vector<int> nn(64);
+    HIPC(e, hipMemcpy(nn.data(), e->n_new, 64 * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < R; ++r) {
+        if (out_len) out_len[r] = nn[r];
+        if (out_ids) {
+            if (nn[r] > out_ld) return fail(e, SONIC_ERR_INVALID, "out_ld too small");
+            HIPC(e, hipMemcpy(out_ids + (size_t)r * out_ld, e->out_ids + (size_t)r * e->out_cap, (size_t)nn[r] * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    if (step_logits) {
+        if (!e->dump_steps) return fail(e, SONIC_ERR_INVALID, "step logits were not requested for the last run");
+        HIPC(e, hipMemcpy(step_logits, e->dump, (size_t)e->dump_steps * R * e->d.vocab * 4, hipMemcpyDeviceToHost));
+    }
+    return SONIC_OK;
+}
+
+extern "C" int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    return fetch_locked(e, out_ids, out_ld, out_len, step_logits);
+}
+
+extern "C" int sonic_transcribe_batch(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W, const int32_t* req_win, int R,
+                                      const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new,
+                                      int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
+    if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    TRY(stage_pcm_locked(e, pcm, offsets, W));
+    TRY(run_all(e, req_win, R, prompt_ids, prompt_off, max_new, step_logits != nullptr));
+    return fetch_locked(e, out_ids, out_ld, out_len, step_logits);
+}
+
+extern "C" int sonic_get_timings(sonic_engine* e, sonic_timings* out) {
+    if (!e || !out) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    *out = e->tim;
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: stage entry points
+extern "C" int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int B, float* feats_out, int32_t* mask_out) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    TRY(stage_pcm_locked(e, pcm, offsets, B));
+    TRY(run_mel(e, B, feats_out != nullptr));
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    const sonic_dims& d = e->d;
+    if (feats_out) HIPC(e, hipMemcpy(feats_out, e->feats_f32, (size_t)B * d.n_mels * d.n_frames * 4, hipMemcpyDeviceToHost));
+    if (mask_out)
+        for (int b = 0; b < B; ++b) {
+            const int v = frames_of(e->n_samples_h[b]);
+            for (int t = 0; t < d.n_frames; ++t) mask_out[(size_t)b * d.n_frames + t] = t < v ? 1 : 0;   // attention_mask[:, ::160]
+        }
+    return SONIC_OK;
+}
+
+extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* n_valid_frames, int B,
+                            float* embeds_out, int32_t* n_audio_out, float* enc_layers_out, float* enc_out) {
+    if (!e || !feats || !n_valid_frames) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
+    if (B < 1 || B > e->Bm) return fail(e, SONIC_ERR_INVALID, "batch out of range");
+    const sonic_dims& d = e->d;
+    const size_t n = (size_t)B * d.n_mels * d.n_frames;
+    float* tmp = nullptr;
+    HIPC(e, hipMalloc((void**)&tmp, n * 4));
+    hipError_t r = hipMemcpy(tmp, feats, n * 4, hipMemcpyHostToDevice);
+    if (r != hipSuccess) { (void)hipFree(tmp); HIPC(e, r); }
+    const long per = (long)d.n_mels * d.n_frames;
+    hipLaunchKernelGGL(feats_to_fm_kernel, dim3((per + 255) / 256, B), dim3(256), 0, e->st, tmp, e->feats_fm, d.n_mels, d.n_frames);
+    int s = run_encoder(e, B, enc_layers_out, enc_out);
+    hipError_t r2 = hipStreamSynchronize(e->st);
+    (void)hipFree(tmp);
+    TRY(s); HIPC(e, r2); HIPC(e, hipGetLastError());
+    if (embeds_out) {
+        float* t2 = nullptr;
+        const size_t m = (size_t)B * e->Ta * d.dec_d;
+        HIPC(e, hipMalloc((void**)&t2, m * 4));
+        launch_bf16_to_f32(e->pe, t2, (long)m, e->st);
+        hipError_t r3 = hipStreamSynchronize(e->st);
+        if (r3 == hipSuccess) r3 = hipMemcpy(embeds_out, t2, m * 4, hipMemcpyDeviceToHost);
+        (void)hipFree(t2);
+        HIPC(e, r3);
+    }
+    if (n_audio_out) for (int b = 0; b < B; ++b) n_audio_out[b] = keep_rows(d, n_valid_frames[b]);
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: kernel test hooks
+struct TmpBuf {
+    std::vector<void*> v;
+    ~TmpBuf() { for (void* p : v) (void)hipFree(p); }
+    template <typename Tt> Tt* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n ? n : 1) * sizeof(Tt)) != hipSuccess) return nullptr; (void)hipMemset(p, 0, (n ? n : 1) * sizeof(Tt)); v.push_back(p); return (Tt*)p; }
+};
+static bf16_t* up_bf16(sonic_engine* e, TmpBuf& tb, const float* h, size_t n, size_t pad = 0) {
+    float* f = tb.get<float>(n); bf16_t* b = tb.get<bf16_t>(n + pad);
+    if (!f || !b) return nullptr;
+    if (hipMemcpy(f, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    launch_f32_to_bf16(f, b, (long)n, e->st);
+    return b;
+}
+static float* up_f32(TmpBuf& tb, const float* h, size_t n) {
+    float* f = tb.get<float>(n);
+    if (f && hipMemcpy(f, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return f;
+}
+static int down_bf16(sonic_engine* e, TmpBuf& tb, const bf16_t* d, float* h, size_t n) {
+    float* f = tb.get<float>(n);
+    if (!f) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    launch_bf16_to_f32(d, f, (long)n, e->st);
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    HIPC(e, hipMemcpy(h, f, n * 4, hipMemcpyDeviceToHost));
+    return SONIC_OK;
+}
+
+extern "C" int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float* bias, const float* resid, float* C,
+                               int M, int N, int K, int epi) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (K % 64 || N % 4) return fail(e, SONIC_ERR_INVALID, "K must be a multiple of 64 and N of 4");
+    TmpBuf tb;
+    const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
+    bf16_t* dA = up_bf16(e, tb, A, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
+    float* db = bias ? up_f32(tb, bias, N) : nullptr;
+    bf16_t* dR = resid ? up_bf16(e, tb, resid, (size_t)M * Nout) : nullptr;
+    bf16_t* dC = tb.get<bf16_t>((size_t)M * Nout);
+    if (!dA || !dW || !dC) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    gemm(e, epi, dA, K, dW, db, dC, Nout, M, N, K, dR, Nout);
+    return down_bf16(e, tb, dC, C, (size_t)M * Nout);
+}
+
+extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (M < 1 || M > 64 || N % 64 || K % 128) return fail(e, SONIC_ERR_INVALID, "skinny: M<=64, N%%64==0, K%%128==0");
+    TmpBuf tb;
+    bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
+    const int ks = skinny_pick_ksplit(N, K), mpad = ((M + 15) / 16) * 16;
+    float* P = tb.get<float>((size_t)ks * mpad * N);
+    if (!dX || !dW || !P) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dW; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks;
+    launch_skinny(a, e->st);
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    std::vector<float> h((size_t)ks * mpad * N);
+    HIPC(e, hipMemcpy(h.data(), P, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float s = 0;
+            for (int k = 0; k < ks; ++k) s += h[((size_t)k * mpad + m) * N + n];
+            C[(size_t)m * N + n] = s;
+        }
+    return SONIC_OK;
+}
+
+__global__ void transpose_v_kernel(const bf16_t* v, bf16_t* vt, int B, int Tk, int Hkv, int hd, int ld_t) {
+    // v [B][Tk][Hkv*hd] -> vt [B][Hkv][hd][ld_t]
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)B * Tk * Hkv * hd) return;
+    const int c = e % (Hkv * hd), t = (e / (Hkv * hd)) % Tk, b = e / ((long)Hkv * hd * Tk);
+    vt[(((long)b * Hkv + c / hd) * hd + c % hd) * ld_t + t] = v[e];
+}
+
+extern "C" int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
+                                    int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (hd != 64 && hd != 128) return fail(e, SONIC_ERR_INVALID, "hd must be 64 or 128");
+    TmpBuf tb;
+    const int Tkp = (Tk + 63) / 64 * 64;
+    bf16_t* dq = up_bf16(e, tb, q, (size_t)B * Tq * Hq * hd);
+    bf16_t* dk = up_bf16(e, tb, k, (size_t)B * Tk * Hkv * hd, (size_t)64 * Hkv * hd);
+    bf16_t* dv = up_bf16(e, tb, v, (size_t)B * Tk * Hkv * hd);
+    bf16_t* dvt = tb.get<bf16_t>((size_t)B * Hkv * hd * Tkp);
+    bf16_t* dO = tb.get<bf16_t>((size_t)B * Tq * Hq * hd);
+    if (!dq || !dk || !dv || !dvt || !dO) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    const long nv = (long)B * Tk * Hkv * hd;
+    hipLaunchKernelGGL(transpose_v_kernel, dim3((nv + 255) / 256), dim3(256), 0, e->st, dv, dvt, B, Tk, Hkv, hd, Tkp);
+    FlashArgs f{};
+    f.Q = dq; f.q_ld = (long)Hq * hd; f.K = dk; f.k_ld = (long)Hkv * hd; f.Vt = dvt; f.vt_ld = Tkp; f.O = dO; f.o_ld = (long)Hq * hd;
+    f.q_seq_stride = (long)Tq * Hq * hd; f.k_seq_stride = (long)Tk * Hkv * hd; f.k_head_stride = hd;
+    f.vt_seq_stride = (long)Hkv * hd * Tkp; f.vt_head_stride = (long)hd * Tkp; f.T = Tq; f.Hq = Hq; f.Hkv = Hkv; f.scale = 1.0f / sqrtf((float)hd);
+    int *ql = nullptr, *kl = nullptr;
+    if (Tq != Tk) {   // per-sequence lengths (decode-style offset: query t sits at position Tk - Tq + t)
+        ql = tb.get<int>(B); kl = tb.get<int>(B);
+        std::vector<int> a(B, Tq), b2(B, Tk);
+        HIPC(e, hipMemcpy(ql, a.data(), B * 4, hipMemcpyHostToDevice)); HIPC(e, hipMemcpy(kl, b2.data(), B * 4, hipMemcpyHostToDevice));
+        f.q_len = ql; f.kv_len = kl;
+    }
+    launch_flash(f, hd, causal != 0, B, Tq, e->st);
+    return down_bf16(e, tb, dO, out, (size_t)B * Tq * Hq * hd);
+}
+
+extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out, int B, int Tk, int Hq, int Hkv) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    const int hd = 128, ctx = (Tk + 63) / 64 * 64;
+    if (Hq % Hkv || Hq / Hkv > 4) return fail(e, SONIC_ERR_INVALID, "bad GQA group");
+    TmpBuf tb;
+    // k, v given as [B][Tk][Hkv*hd]; cache layout is [B][Hkv][ctx][hd]
+    std::vector<float> kc((size_t)B * Hkv * ctx * hd, 0.f), vc(kc.size(), 0.f);
+    for (int b = 0; b < B; ++b) for (int t = 0; t < Tk; ++t) for (int h = 0; h < Hkv; ++h) for (int i = 0; i < hd; ++i) {
+        const size_t s = (((size_t)b * Tk + t) * Hkv + h) * hd + i, dd = (((size_t)b * Hkv + h) * ctx + t) * hd + i;
+        kc[dd] = k[s]; vc[dd] = v[s];
+    }
+    bf16_t* dq = up_bf16(e, tb, q, (size_t)B * Hq * hd); bf16_t* dk = up_bf16(e, tb, kc.data(), kc.size()); bf16_t* dv = up_bf16(e, tb, vc.data(), vc.size());
+    bf16_t* dO = tb.get<bf16_t>((size_t)B * Hq * hd); int* kl = tb.get<int>(B);
+    if (!dq || !dk || !dv || !dO || !kl) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    std::vector<int> l(B, Tk); HIPC(e, hipMemcpy(kl, l.data(), B * 4, hipMemcpyHostToDevice));
+    DecodeAttnArgs a{}; a.Q = dq; a.Kc = dk; a.Vc = dv; a.O = dO; a.kv_len = kl; a.Hq = Hq; a.Hkv = Hkv; a.ctx_max = ctx; a.scale = 1.0f / sqrtf(128.f);
+    launch_decode_attn(a, B, e->st);
+    return down_bf16(e, tb, dO, out, (size_t)B * Hq * hd);
+}
+
+extern "C" int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, int rms) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (d % 8 || d > 2048) return fail(e, SONIC_ERR_INVALID, "d must be a multiple of 8 and <= 2048");
+    TmpBuf tb;
+    bf16_t* dx = up_bf16(e, tb, x, (size_t)rows * d); float* dw = up_f32(tb, w, d); float* db = b ? up_f32(tb, b, d) : nullptr;
+    bf16_t* dy = tb.get<bf16_t>((size_t)rows * d);
+    if (!dx || !dw || !dy) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    if (rms) launch_rmsnorm(dx, dw, dy, rows, d, eps, nullptr, e->st);
+    else launch_layernorm(dx, dw, db, dy, rows, d, eps, e->st);
+    return down_bf16(e, tb, dy, y, (size_t)rows * d);
+}
+
+extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch) {
+    if (!e || !ms_per_launch) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (K % 64 || N % 4 || iters < 1) return fail(e, SONIC_ERR_INVALID, "bad gemm bench shape");
+    TmpBuf tb;
+    const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
+    bf16_t* dA = tb.get<bf16_t>((size_t)M * K + 1024); bf16_t* dW = tb.get<bf16_t>((size_t)N * K); bf16_t* dC = tb.get<bf16_t>((size_t)M * Nout);
+    float* db = tb.get<float>(N);
+    if (!dA || !dW || !dC || !db) return fail(e, SONIC_ERR_OOM, "HIP out of memory in gemm bench");
+    // random (not zero) operands: zero data reads high on this chip (cdna_hip_programming.md rule 25)
+    launch_synth_fill(0x1234, (long)M * K, 1.0f, 0.f, dA, nullptr, e->st);
+    launch_synth_fill(0x5678, (long)N * K, 0.05f, 0.f, dW, nullptr, e->st);
+    for (int i = 0; i < 2; ++i) gemm(e, epi, dA, K, dW, db, dC, Nout, M, N, K, dC, Nout);
+    hipEvent_t a, b; HIPC(e, hipEventCreate(&a)); HIPC(e, hipEventCreate(&b));
+    (void)hipEventRecord(a, e->st);
+    for (int i = 0; i < iters; ++i) gemm(e, epi, dA, K, dW, db, dC, Nout, M, N, K, dC, Nout);
+    (void)hipEventRecord(b, e->st);
+    hipError_t r = hipStreamSynchronize(e->st);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    HIPC(e, r); HIPC(e, hipGetLastError());
+    *ms_per_launch = ms / iters;
+    return SONIC_OK;
+}

@@ -1,0 +1,79 @@
+// Launch descriptors and host-callable launchers of the HIP kernels (attn.hip, elementwise.hip, logmel.hip).
+#pragma once
+#include "common.h"
+
+struct FlashArgs {
+    const bf16_t* Q; long q_ld;            // token-major, head h at column h*HD
+    const bf16_t* K; long k_ld;            // key-major rows
+    const bf16_t* Vt; long vt_ld;          // V^T rows: [hd][key]
+    bf16_t* O; long o_ld;
+    long q_seq_stride, k_seq_stride, k_head_stride, vt_seq_stride, vt_head_stride;
+    const int* q_off;                      // optional [B]: first packed token of each sequence (ragged); else b * q_seq_stride
+    const int* q_len;                      // optional [B]; else T
+    const int* kv_len;                     // optional [B]; else T
+    int T, Hq, Hkv;
+    float scale;
+};
+void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s);
+
+struct DecodeAttnArgs {
+    const bf16_t* Q;      // [B][Hq*128] (roped)
+    const bf16_t* Kc;     // [B][Hkv][ctx_max][128]
+    const bf16_t* Vc;     // [B][Hkv][ctx_max][128]
+    bf16_t* O;            // [B][Hq*128]
+    const int* kv_len;    // [B] keys visible (new token included)
+    int Hq, Hkv, ctx_max;
+    float scale;
+};
+void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s);
+
+struct RopeAppendArgs {
+    const bf16_t* qkv; long ld;          // prefill source [tok][Hq*hd + 2*Hkv*hd]
+    const float* P; int ksplit, mpad;    // decode source slabs [ks][mpad][N]
+    bf16_t* q_out;                       // [tok][Hq*hd]
+    bf16_t* Kc; bf16_t* Vc;              // [B][Hkv][ctx_max][hd]
+    bf16_t* Vt; long vt_ld;              // optional [B][Hkv][hd][vt_ld]
+    const int* tok_seq; const int* tok_pos;  // per token: sequence index, absolute position
+    const float* cs;                     // [ctx_max][hd]: cos[0..hd/2) | sin[0..hd/2)
+    int Hq, Hkv, ctx_max, n_tok;
+};
+void launch_rope_append(const RopeAppendArgs& a, bool slab, hipStream_t s);
+
+struct GreedyArgs {
+    const float* logits;   // slab [mpad][V] fp32 accumulators of the lm_head (ksplit == 1)
+    int V, B;
+    const bf16_t* table;   // embedding table (tied lm_head), for the next step's input row
+    bf16_t* x; int d;      // [B][d] next-step hidden input
+    int* out_ids; int out_ld;   // [B][out_ld] generated ids
+    int* n_new;            // [B]
+    int* finished;         // [B]
+    int* kv_len;           // [B] keys visible to the *next* step (incremented here)
+    int* tok_pos;          // [B] position of the next token
+    const int* max_new;    // [B]
+    int* n_active;         // [1] rows still running (host polls)
+    int eos[8]; int n_eos; int pad_id;
+    float* logits_dump; long dump_stride_step; int* step_counter;  // optional: bf16-rounded logits per step [step][B][V]; counter per row [B]
+};
+void launch_greedy(const GreedyArgs& a, hipStream_t s);
+
+struct LogmelConst {
+    const float* win;      // [400]
+    const float* cos_t;    // [400]
+    const float* sin_t;    // [400]
+    const int* mel_lo;     // [n_mels] first bin of each filter
+    const int* mel_cnt;    // [n_mels] taps
+    const int* mel_off;    // [n_mels] offset into mel_w
+    const float* mel_w;    // packed taps
+};
+void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev, int max_samples, const LogmelConst& lc,
+                   float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s);
+
+void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s);
+void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s);
+void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s);
+void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s);
+void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s);
+void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d, hipStream_t s);
+void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
+void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s);
+void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s);

@@ -1,0 +1,315 @@
+"""ctypes binding of libsonic_hip.so (include/sonic_hip.h).
+
+The product path fails loudly when the HIP library is missing or no GPU is visible; there is no
+CPU fallback (the CPU oracle lives under oracle/ and is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .spec import ModelDims
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libsonic_hip.so")
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU = 0, 1, 2, 3
+MODE_NATIVE, MODE_INT8 = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
+SONIC_ERR_MISMATCH, SONIC_ERR_UNSUPPORTED = 4, 5
+
+EXPORTS = [
+    "sonic_device_count", "sonic_create", "sonic_destroy", "sonic_last_error", "sonic_load_tensor", "sonic_load_synthetic",
+    "sonic_finalize_weights", "sonic_weight_bytes", "sonic_logmel", "sonic_encode", "sonic_transcribe_batch", "sonic_stage_pcm",
+    "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
+    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm",
+]
+
+
+class SonicDims(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int32), ("n_frames", C.c_int32), ("enc_T", C.c_int32),
+        ("enc_d", C.c_int32), ("enc_ff", C.c_int32), ("enc_layers", C.c_int32), ("enc_heads", C.c_int32), ("enc_rotary_dim", C.c_int32),
+        ("enc_theta", C.c_float), ("enc_ln_eps", C.c_float),
+        ("merge", C.c_int32),
+        ("dec_d", C.c_int32), ("dec_ff", C.c_int32), ("dec_layers", C.c_int32), ("dec_heads", C.c_int32), ("dec_kv_heads", C.c_int32), ("dec_head_dim", C.c_int32),
+        ("dec_theta", C.c_float), ("dec_rms_eps", C.c_float),
+        ("vocab", C.c_int32), ("audio_token_id", C.c_int32), ("n_eos", C.c_int32),
+        ("eos", C.c_int32 * 8),
+    ]
+
+
+class SonicTimings(C.Structure):
+    _fields_ = [
+        ("mel_ms", C.c_float), ("encoder_ms", C.c_float), ("prefill_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
+        ("gemm_ms", C.c_float), ("gemm_launches", C.c_int32), ("gemm_flops", C.c_double), ("decode_steps", C.c_int32),
+    ]
+
+
+def make_dims(d: ModelDims) -> SonicDims:
+    x = SonicDims()
+    x.n_mels, x.n_frames, x.enc_T = d.n_mels, d.n_frames, d.enc_T
+    x.enc_d, x.enc_ff, x.enc_layers, x.enc_heads, x.enc_rotary_dim = d.enc_d, d.enc_ff, d.enc_layers, d.enc_heads, d.enc_rotary_dim
+    x.enc_theta, x.enc_ln_eps, x.merge = d.enc_rope_theta, d.enc_ln_eps, d.merge
+    x.dec_d, x.dec_ff, x.dec_layers, x.dec_heads, x.dec_kv_heads, x.dec_head_dim = d.dec_d, d.dec_ff, d.dec_layers, d.dec_heads, d.dec_kv_heads, d.dec_head_dim
+    x.dec_theta, x.dec_rms_eps = d.dec_rope_theta, d.dec_rms_eps
+    x.vocab, x.audio_token_id, x.n_eos = d.vocab, d.audio_token_id, len(d.eos_ids)
+    for i, e in enumerate(d.eos_ids):
+        x.eos[i] = e
+    return x
+
+
+_lib = None
+
+
+def load_library():
+    """Load libsonic_hip.so; raise RuntimeError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"sonicscribe_amd: HIP extension not built ({LIB_PATH} missing). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sonicscribe_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, i64p, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_void_p
+    lib.sonic_device_count.restype = C.c_int
+    lib.sonic_create.restype = C.c_int
+    lib.sonic_create.argtypes = [C.POINTER(SonicDims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.sonic_destroy.argtypes = [vp]
+    lib.sonic_destroy.restype = None
+    lib.sonic_last_error.restype = C.c_char_p
+    lib.sonic_last_error.argtypes = [vp]
+    lib.sonic_load_tensor.argtypes = [vp, C.c_char_p, vp, C.c_int, i64p, C.c_int]
+    lib.sonic_load_synthetic.argtypes = [vp, C.c_uint64]
+    lib.sonic_finalize_weights.argtypes = [vp]
+    lib.sonic_weight_bytes.restype = C.c_int64
+    lib.sonic_weight_bytes.argtypes = [vp]
+    lib.sonic_logmel.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    lib.sonic_encode.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.sonic_transcribe_batch.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
+    lib.sonic_stage_pcm.argtypes = [vp, vp, vp, C.c_int]
+    lib.sonic_run_staged.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
+    lib.sonic_fetch_tokens.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.sonic_get_timings.argtypes = [vp, C.POINTER(SonicTimings)]
+    lib.sonic_synchronize.argtypes = [vp]
+    lib.sonic_test_gemm.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.sonic_test_skinny.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.sonic_test_attention.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 7
+    lib.sonic_test_decode_attention.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 4
+    lib.sonic_test_layernorm.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int]
+    lib.sonic_bench_gemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    for name in EXPORTS:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+class SonicError(RuntimeError):
+    pass
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One model replica on one MI355X."""
+
+    def __init__(self, dims: ModelDims, device_id: int = 0, mode: int = MODE_NATIVE, max_batch: int = 32, max_ctx: int = 1024):
+        self.lib = load_library()
+        self.dims = dims
+        self.max_batch, self.max_ctx = max_batch, max_ctx
+        self._cd = make_dims(dims)
+        h = C.c_void_p()
+        rc = self.lib.sonic_create(C.byref(self._cd), device_id, mode, max_batch, max_ctx, C.byref(h))
+        if rc != 0:
+            msg = (self.lib.sonic_last_error(None) or b"").decode()
+            if rc == SONIC_ERR_UNSUPPORTED:
+                raise ImportError(msg)
+            raise (ValueError if "mode must be" in msg else SonicError)(msg)
+        self.h = h
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = (self.lib.sonic_last_error(self.h) or b"").decode()
+            if rc == SONIC_ERR_MISMATCH:
+                raise ValueError(msg)
+            raise SonicError(msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sonic_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights
+    def load_tensor(self, name: str, arr: np.ndarray, bf16_bits: bool = False):
+        arr = np.ascontiguousarray(arr)
+        shape = (C.c_int64 * arr.ndim)(*arr.shape)
+        if bf16_bits:
+            assert arr.dtype == np.uint16
+            dt = DTYPE_BF16
+        else:
+            arr = arr.astype(np.float32, copy=False)
+            dt = DTYPE_F32
+        self._check(self.lib.sonic_load_tensor(self.h, name.encode(), _p(arr), dt, shape, arr.ndim))
+
+    def load_state_dict(self, state: Dict[str, np.ndarray]):
+        for k, v in state.items():
+            self.load_tensor(k, v)
+        self.finalize()
+
+    def load_synthetic(self, seed: int):
+        self._check(self.lib.sonic_load_synthetic(self.h, seed))
+        self.finalize()
+
+    def finalize(self):
+        self._check(self.lib.sonic_finalize_weights(self.h))
+
+    def weight_bytes(self) -> int:
+        return int(self.lib.sonic_weight_bytes(self.h))
+
+    # -- stages
+    @staticmethod
+    def _pack_pcm(segments: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+        offs = np.zeros(len(segments) + 1, np.int64)
+        for i, s in enumerate(segments):
+            offs[i + 1] = offs[i] + len(s)
+        pcm = np.concatenate([np.ascontiguousarray(s, dtype=np.int16) for s in segments]) if segments else np.zeros(0, np.int16)
+        if pcm.size == 0:
+            pcm = np.zeros(1, np.int16)
+        return np.ascontiguousarray(pcm), offs
+
+    def logmel(self, segments: Sequence[np.ndarray]):
+        d = self.dims
+        pcm, offs = self._pack_pcm(segments)
+        B = len(segments)
+        feats = np.empty((B, d.n_mels, d.n_frames), np.float32)
+        mask = np.empty((B, d.n_frames), np.int32)
+        self._check(self.lib.sonic_logmel(self.h, _p(pcm), _p(offs), B, _p(feats), _p(mask)))
+        return feats, mask
+
+    def encode(self, feats: np.ndarray, n_valid_frames: Sequence[int], want_layers: bool = False, want_enc_out: bool = False):
+        d = self.dims
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        B = feats.shape[0]
+        nv = np.ascontiguousarray(n_valid_frames, dtype=np.int32)
+        emb = np.empty((B, d.max_audio_tokens, d.dec_d), np.float32)
+        n_audio = np.empty(B, np.int32)
+        layers = np.empty((B, d.enc_layers, d.enc_T, d.enc_d), np.float32) if want_layers else None
+        enc_out = np.empty((B, d.enc_T, d.enc_d), np.float32) if want_enc_out else None
+        self._check(self.lib.sonic_encode(self.h, _p(feats), _p(nv), B, _p(emb), _p(n_audio), _p(layers), _p(enc_out)))
+        return emb, n_audio, layers, enc_out
+
+    # -- the hot call
+    @staticmethod
+    def _pack_prompts(prompts: Sequence[Sequence[int]]):
+        offs = np.zeros(len(prompts) + 1, np.int64)
+        for i, p in enumerate(prompts):
+            offs[i + 1] = offs[i] + len(p)
+        ids = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)
+        return np.ascontiguousarray(ids), offs
+
+    def transcribe_batch(self, segments: Sequence[np.ndarray], prompts: Sequence[Sequence[int]], max_new: Sequence[int],
+                         req_win: Optional[Sequence[int]] = None, want_logits: bool = False):
+        """segments: int16 PCM windows (<= 30 s each); one prompt per request. Returns (ids list, logits or None)."""
+        pcm, offs = self._pack_pcm(segments)
+        ids, poffs = self._pack_prompts(prompts)
+        R = len(prompts)
+        mn = np.ascontiguousarray(max_new, dtype=np.int32)
+        out_ld = int(mn.max())
+        out = np.zeros((R, out_ld), np.int32)
+        out_len = np.zeros(R, np.int32)
+        rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+        logits = np.zeros((out_ld, R, self.dims.vocab), np.float32) if want_logits else None
+        self._check(self.lib.sonic_transcribe_batch(self.h, _p(pcm), _p(offs), len(segments), _p(rw), R, _p(ids), _p(poffs), _p(mn),
+                                                    _p(out), out_ld, _p(out_len), _p(logits)))
+        return [out[r, : out_len[r]].copy() for r in range(R)], logits
+
+    def stage_pcm(self, segments: Sequence[np.ndarray]):
+        pcm, offs = self._pack_pcm(segments)
+        self._check(self.lib.sonic_stage_pcm(self.h, _p(pcm), _p(offs), len(segments)))
+
+    def run_staged(self, prompts: Sequence[Sequence[int]], max_new: Sequence[int], req_win: Optional[Sequence[int]] = None,
+                   want_logits: bool = False):
+        ids, poffs = self._pack_prompts(prompts)
+        mn = np.ascontiguousarray(max_new, dtype=np.int32)
+        rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+        self._run_cache = (ids, poffs, mn, rw)
+        self._check(self.lib.sonic_run_staged(self.h, _p(rw), len(prompts), _p(ids), _p(poffs), _p(mn), int(want_logits)))
+
+    def rerun_staged(self):
+        """Repeat the last run_staged call without re-packing (benchmark inner loop)."""
+        ids, poffs, mn, rw = self._run_cache
+        self._check(self.lib.sonic_run_staged(self.h, _p(rw), len(mn), _p(ids), _p(poffs), _p(mn), 0))
+
+    def fetch_tokens(self, R: int, out_ld: int):
+        out = np.zeros((R, out_ld), np.int32)
+        out_len = np.zeros(R, np.int32)
+        self._check(self.lib.sonic_fetch_tokens(self.h, _p(out), out_ld, _p(out_len), None))
+        return [out[r, : out_len[r]].copy() for r in range(R)]
+
+    def timings(self) -> Dict[str, float]:
+        t = SonicTimings()
+        self._check(self.lib.sonic_get_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in SonicTimings._fields_}
+
+    # -- kernel test hooks
+    def test_gemm(self, A, W, bias=None, resid=None, epi=EPI_BIAS):
+        A = np.ascontiguousarray(A, np.float32); W = np.ascontiguousarray(W, np.float32)
+        M, K = A.shape; N = W.shape[0]
+        n_out = N // 2 if epi == EPI_SWIGLU else N
+        out = np.empty((M, n_out), np.float32)
+        b = np.ascontiguousarray(bias, np.float32) if bias is not None else None
+        r = np.ascontiguousarray(resid, np.float32) if resid is not None else None
+        self._check(self.lib.sonic_test_gemm(self.h, _p(A), _p(W), _p(b), _p(r), _p(out), M, N, K, epi))
+        return out
+
+    def test_skinny(self, X, W):
+        X = np.ascontiguousarray(X, np.float32); W = np.ascontiguousarray(W, np.float32)
+        M, K = X.shape; N = W.shape[0]
+        out = np.empty((M, N), np.float32)
+        self._check(self.lib.sonic_test_skinny(self.h, _p(X), _p(W), _p(out), M, N, K))
+        return out
+
+    def test_attention(self, q, k, v, causal: bool):
+        """q [B][Tq][Hq][hd], k/v [B][Tk][Hkv][hd] -> [B][Tq][Hq][hd]"""
+        q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+        B, Tq, Hq, hd = q.shape; Tk, Hkv = k.shape[1], k.shape[2]
+        out = np.empty_like(q)
+        self._check(self.lib.sonic_test_attention(self.h, _p(q), _p(k), _p(v), _p(out), B, Tq, Tk, Hq, Hkv, hd, int(causal)))
+        return out
+
+    def test_decode_attention(self, q, k, v):
+        """q [B][Hq][128], k/v [B][Tk][Hkv][128] -> [B][Hq][128]"""
+        q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+        B, Hq, _ = q.shape; Tk, Hkv = k.shape[1], k.shape[2]
+        out = np.empty_like(q)
+        self._check(self.lib.sonic_test_decode_attention(self.h, _p(q), _p(k), _p(v), _p(out), B, Tk, Hq, Hkv))
+        return out
+
+    def test_layernorm(self, x, w, b=None, eps=1e-5, rms=False):
+        x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+        bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+        out = np.empty_like(x)
+        self._check(self.lib.sonic_test_layernorm(self.h, _p(x), _p(w), _p(bb), _p(out), x.shape[0], x.shape[1], eps, int(rms)))
+        return out
+
+    def bench_gemm(self, M: int, N: int, K: int, epi: int = EPI_BIAS_GELU, iters: int = 20) -> float:
+        ms = C.c_float(0)
+        self._check(self.lib.sonic_bench_gemm(self.h, M, N, K, epi, iters, C.byref(ms)))
+        return float(ms.value)
+
+
+def device_count() -> int:
+    return int(load_library().sonic_device_count())

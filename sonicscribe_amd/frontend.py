@@ -94,3 +94,32 @@ def request_audio_tokens(n_samples: int, dims: ModelDims = FULL) -> Tuple[int, L
 def max_new_tokens_committed(segment_duration: float) -> int:
     """transcription_manager.py:37."""
     return min(50 + int(segment_duration * 5), 200)
+
+
+def resample_sinc_hann(wav: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """asr.py:255-261: ``torchaudio.transforms.Resample(orig, new)`` with its defaults (sinc_interp_hann, width 6,
+    rolloff 0.99), restated in numpy.  Never taken on the reference's own call sites (both pass 16 kHz); torchaudio is
+    absent offline, so this branch is unpinned."""
+    import math
+    wav = np.asarray(wav, dtype=np.float32)
+    if orig_freq == new_freq or wav.size == 0:
+        return wav
+    g = math.gcd(int(orig_freq), int(new_freq))
+    of, nf = int(orig_freq) // g, int(new_freq) // g
+    base = min(of, nf) * rolloff
+    width = math.ceil(lowpass_filter_width * of / base)
+    idx = np.arange(-width, width + of, dtype=np.float64)[None, :] / of
+    t = (np.arange(0, -nf, -1, dtype=np.float64)[:, None] / nf + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    with np.errstate(divide="ignore", invalid="ignore"):
+        kern = np.where(t == 0, 1.0, np.sin(t) / t)
+    kern = (kern * window * (base / of)).astype(np.float32)          # [nf][2*width + of]
+    length = wav.shape[-1]
+    x = np.pad(wav, (width, width + of))
+    n_out = (x.size - kern.shape[1]) // of + 1
+    frames = np.lib.stride_tricks.as_strided(x, shape=(n_out, kern.shape[1]), strides=(x.strides[0] * of, x.strides[0]))
+    out = (frames @ kern.T).reshape(-1)
+    target = int(math.ceil(nf * length / of))
+    return out[:target].astype(np.float32)
