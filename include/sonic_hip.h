@@ -116,6 +116,10 @@ int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k,
 int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, int rms);
 /* times `iters` launches of the encoder's dominant GEMM shape on the engine stream with HIP events */
 int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch);
+/* times the decode-step skinny GEMM (variant: 0 LDS-DMA nt, 1 LDS-DMA default policy, 2 registers nt, 3 registers plain, 9 pure-read floor) */
+int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int iters, float* us_per_launch);
+/* tuning knobs for experiments ("skinny_variant") */
+int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus
 }

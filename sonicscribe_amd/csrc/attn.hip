@@ -211,100 +211,166 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 
 // ------------------------------------------------------------------------------------------------
 
-// HD = 128, group size G = Hq/Hkv <= 4.
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a) {
-    constexpr int HD = 128, GMAX = 4;
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
+// HD = 128, group size G = Hq/Hkv <= 4.  One block (8 waves) per (sequence, kv head).
+//  1. prologue (fused RoPE + KV append, modeling_llama.py:121-143,261-262): sums the QKV skinny-GEMM slabs of this
+//     (sequence, kv head), rounds to bf16, applies rotate-half RoPE at the token's position, writes the new K / V rows
+//     into the cache and keeps q (4 heads), k, v in LDS;
+//  2. single pass over the cached keys with a per-wave online softmax: a wave-iteration covers 4 x 4 keys of K and V
+//     (8 KiB per wave, next iteration's rows prefetched into registers before the current one is consumed), lane
+//     (sub = lane>>4, ch = lane&15) owns key `sub` of each 4-key group and head-dim chunk `ch`;
+//  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
+// Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
+__global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
+    constexpr int HD = 128, HALF = 64, GMAX = 4, U = 4, NW = 8;
+    __shared__ float s_acc[NW][GMAX][HD];
+    __shared__ float s_m[NW][GMAX], s_l[NW][GMAX];
+    __shared__ float s_q[GMAX + 2][HD];     // q heads (scaled), then k, v of the new token
     const int G = a.Hq / a.Hkv;
-    float* sc = (float*)dsm;                       // [G][ctx_max] scores -> probabilities
-    float* red = sc + GMAX * a.ctx_max;            // [4 waves][G][HD] partial outputs
-    float* stat = red + 4 * GMAX * HD;             // [G] 1/l
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x, kvh = blockIdx.y;
-    const int n = a.kv_len[b];
-    const int sub = lane >> 4, ch = lane & 15;     // key sub-index within a 4-key wave load, 8-wide hd chunk
-    const bf16_t* Kc = a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
-    const bf16_t* Vc = a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    const int n = a.kv_len[b];              // keys visible, the new token included at position n-1
+    const int sub = lane >> 4, ch = lane & 15;
+    bf16_t* Kc = a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    bf16_t* Vc = a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
 
+    if (a.P) {
+        const int N = (a.Hq + 2 * a.Hkv) * HD, pos = n - 1;
+        for (int w = tid; w < (G + 2) * HALF; w += 512) {
+            const int vi = w / HALF, i = w % HALF;          // vector (q heads.., k, v), index in the first half
+            const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
+            float x1 = 0.f, x2 = 0.f;
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const float* p = a.P + ((long)ks * a.mpad + b) * N + col;
+                x1 += p[0]; x2 += p[HALF];
+            }
+            x1 = rbf(x1); x2 = rbf(x2);
+            float o1 = x1, o2 = x2;
+            if (vi <= G) {
+                const float c = a.cs[(long)pos * HD + i], sn = a.cs[(long)pos * HD + HALF + i];
+                o1 = rbf(rbf(x1 * c) + rbf(-x2 * sn));
+                o2 = rbf(rbf(x2 * c) + rbf(x1 * sn));
+            }
+            const float sc = vi < G ? a.scale : 1.0f;
+            s_q[vi < G ? vi : (vi == G ? GMAX : GMAX + 1)][i] = o1 * sc;
+            s_q[vi < G ? vi : (vi == G ? GMAX : GMAX + 1)][HALF + i] = o2 * sc;
+            if (vi == G) { Kc[(long)pos * HD + i] = f2bf(o1); Kc[(long)pos * HD + HALF + i] = f2bf(o2); }
+            if (vi == G + 1) { Vc[(long)pos * HD + i] = f2bf(o1); Vc[(long)pos * HD + HALF + i] = f2bf(o2); }
+        }
+        __syncthreads();
+    }
     float q[GMAX][8];
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
-        const int hq = kvh * G + (g < G ? g : 0);
-        const bf16x8 v = *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + hq * HD + ch * 8);
+        if (a.P) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) q[g][i] = bf2f(v[i]);
+            for (int i = 0; i < 8; ++i) q[g][i] = s_q[g < G ? g : 0][ch * 8 + i];
+        } else {
+            const int hq = kvh * G + (g < G ? g : 0);
+            const bf16x8 v = *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + hq * HD + ch * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[g][i] = bf2f(v[i]) * a.scale;
+        }
     }
-    // phase 1: scores
-    for (int k0 = wid * 4; k0 < n; k0 += 16) {
-        const int key = k0 + sub;
-        float d[GMAX] = {0.f, 0.f, 0.f, 0.f};
-        if (key < n) {
-            const bf16x8 kv = *(const bf16x8*)(Kc + (long)key * HD + ch * 8);
+    float m[GMAX], l[GMAX], acc[GMAX][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float kf = bf2f(kv[i]);
+    for (int g = 0; g < GMAX; ++g) {
+        m[g] = -1e30f; l[g] = 0.f;
 #pragma unroll
-                for (int g = 0; g < GMAX; ++g) d[g] += q[g][i] * kf;
+        for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
+    }
+    const int nc = a.P ? n - 1 : n;          // keys read from the cache
+    const bf16_t* Kr = Kc + ch * 8;
+    const bf16_t* Vr = Vc + ch * 8;
+    bf16x8 kv[U], vv[U], kn[U], vn[U];
+    auto load = [&](int k0, bf16x8 (&kd)[U], bf16x8 (&vd)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int key = k0 + u * 4 + sub; key = key < nc ? key : (nc > 0 ? nc - 1 : 0);
+            kd[u] = *(const bf16x8*)(Kr + (long)key * HD);
+            vd[u] = *(const bf16x8*)(Vr + (long)key * HD);
+        }
+    };
+    auto consume = [&](int k0, const bf16x8 (&kd)[U], const bf16x8 (&vd)[U], int limit) {
+        float sc[U][GMAX];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = (k0 + u * 4 + sub) < limit;
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d += q[g][i] * bf2f(kd[u][i]);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                sc[u][g] = ok[u] ? d : -1e30f;
             }
         }
 #pragma unroll
         for (int g = 0; g < GMAX; ++g) {
-            float v = d[g];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (ch == 0 && key < n && g < G) sc[g * a.ctx_max + key] = v * a.scale;
-        }
-    }
-    __syncthreads();
-    // phase 2: wave g normalises head g
-    if (wid < G) {
-        float* s = sc + wid * a.ctx_max;
-        float mx = -1e30f;
-        for (int k = lane; k < n; k += 64) mx = fmaxf(mx, s[k]);
-        mx = wave_max(mx);
-        float l = 0.f;
-        for (int k = lane; k < n; k += 64) { const float p = __expf(s[k] - mx); l += p; s[k] = rbf(p); }
-        l = wave_sum(l);
-        if (lane == 0) stat[wid] = 1.0f / l;
-    }
-    __syncthreads();
-    // phase 3: O = P . V
-    float acc[GMAX][8];
+            float mx = fmaxf(fmaxf(sc[0][g], sc[1][g]), fmaxf(sc[2][g], sc[3][g]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[g], mx);
+            const float alpha = __expf(m[g] - mn);
+            m[g] = mn;
+            float ps = 0.f, pr[U];
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
-    for (int k0 = wid * 4; k0 < n; k0 += 16) {
-        const int key = k0 + sub;
-        if (key < n) {
-            const bf16x8 vv = *(const bf16x8*)(Vc + (long)key * HD + ch * 8);
-            float p[GMAX];
-#pragma unroll
-            for (int g = 0; g < GMAX; ++g) p[g] = g < G ? sc[g * a.ctx_max + key] : 0.f;
+            for (int u = 0; u < U; ++u) { const float p = ok[u] ? __expf(sc[u][g] - mn) : 0.f; ps += p; pr[u] = rbf(p); }
+            l[g] = l[g] * alpha + ps;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float vf = bf2f(vv[i]);
+                float t = acc[g][i] * alpha;
 #pragma unroll
-                for (int g = 0; g < GMAX; ++g) acc[g][i] += p[g] * vf;
+                for (int u = 0; u < U; ++u) t += pr[u] * bf2f(vd[u][i]);
+                acc[g][i] = t;
             }
         }
-    }
+    };
+    const int stride = NW * 4 * U;
+    int k0 = wid * (4 * U);
+    if (k0 < nc) load(k0, kv, vv);
+    for (; k0 < nc; k0 += stride) {
+        const bool more = k0 + stride < nc;
+        if (more) load(k0 + stride, kn, vn);
+        consume(k0, kv, vv, nc);
+        if (more) {
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g)
+            for (int u = 0; u < U; ++u) { kv[u] = kn[u]; vv[u] = vn[u]; }
+        }
+    }
+    if (a.P && wid == 0) {                   // the token being decoded: its k / v are still in LDS
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { kv[u][i] = f2bf(s_q[GMAX][ch * 8 + i]); vv[u][i] = f2bf(s_q[GMAX + 1][ch * 8 + i]); }
+        consume(0, kv, vv, 1);                // only (u = 0, sub = 0) is in range
+    }
+    // merge the 4 key sub-groups of the wave, then the 8 waves
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        float lv = l[g];
+        lv += __shfl_xor(lv, 16, 64); lv += __shfl_xor(lv, 32, 64);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v = acc[g][i];
             v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (sub == 0) red[(wid * GMAX + g) * HD + ch * 8 + i] = v;
+            if (sub == 0) s_acc[wid][g][ch * 8 + i] = v;
         }
+        if (lane == 0) { s_m[wid][g] = m[g]; s_l[wid][g] = lv; }
+    }
     __syncthreads();
-    for (int idx = tid; idx < G * HD; idx += 256) {
+    for (int idx = tid; idx < G * HD; idx += 512) {
         const int g = idx / HD, e = idx % HD;
-        const float v = red[(0 * GMAX + g) * HD + e] + red[(1 * GMAX + g) * HD + e] + red[(2 * GMAX + g) * HD + e] + red[(3 * GMAX + g) * HD + e];
-        a.O[(long)b * a.Hq * HD + (kvh * G + g) * HD + e] = f2bf(v * stat[g]);
+        float M = -1e30f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][g]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][g] - M); num += f * s_acc[w][g][e]; den += f * s_l[w][g]; }
+        a.O[(long)b * a.Hq * HD + (kvh * G + g) * HD + e] = f2bf(num / den);
     }
 }
 
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {
-    const size_t lds = (size_t)(4 * a.ctx_max + 4 * 4 * 128 + 4) * sizeof(float);
-    hipLaunchKernelGGL(decode_attn_kernel, dim3(B, a.Hkv), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(B, a.Hkv), dim3(512), 0, s, a);
 }

@@ -53,7 +53,7 @@ struct GemmArgs {
 
 struct SkinnyArgs {
     const bf16_t* X; long ldx;       // [M<=64][K]
-    const bf16_t* W;                 // [N][K]
+    const bf16_t* W;                 // [N][K] in fragment-tiled order (launch_tile_weights)
     float* P;                        // partial slabs [ksplit][Mpad][N] fp32
     int M, N, K, ksplit;
 };
@@ -61,3 +61,5 @@ struct SkinnyArgs {
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
+void set_skinny_variant(int v);
+void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);

@@ -82,34 +82,43 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* x, const flo
     rms_row(v, s, w, y + (long)row * d, lane, nv, d, eps);
 }
 
-// decode: x[r] = bf16(x[r] + bf16(sum_ks P[ks][r][:])); y[r] = rmsnorm(x[r]) (o_proj / down_proj consumer)
+// decode: x[r] = bf16(x[r] + bf16(sum_ks P[ks][r][:])); y[r] = rmsnorm(x[r]) (o_proj / down_proj consumer).
+// one block of d/8 threads per row (the step has only <= 64 rows: parallelism comes from the row width).
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y,
                                                           int rows, int d, float eps) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    bf16_t* xr = x + (long)row * d;
+    __shared__ float part[4];
+    const int row = blockIdx.x, c = threadIdx.x, lane = c & 63, wid = c >> 6;
     const int nv = d >> 3;
-    float v[4][8];
+    float v[8];
     float s = 0.f;
+    if (c < nv) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ksplit; ++ks) {
+            const float* p = P + ((long)ks * mpad + row) * d + c * 8;
+            const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < ksplit; ++ks) {
-                const float* p = P + ((long)ks * mpad + row) * d + c * 8;
-                const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
-            }
-            const bf16x8 t = *(const bf16x8*)(xr + c * 8);
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { o[j] = f2bf(bf2f(t[j]) + rbf(acc[j])); v[i][j] = bf2f(o[j]); s += v[i][j] * v[i][j]; }
-            *(bf16x8*)(xr + c * 8) = o;
+            for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
         }
+        bf16_t* xr = x + (long)row * d + c * 8;
+        const bf16x8 t = *(const bf16x8*)xr;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = f2bf(bf2f(t[j]) + rbf(acc[j])); v[j] = bf2f(o[j]); s += v[j] * v[j]; }
+        *(bf16x8*)xr = o;
     }
-    rms_row(v, s, w, y + (long)row * d, lane, nv, d, eps);
+    s = wave_sum(s);
+    if (lane == 0) part[wid] = s;
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += part[i];
+    const float r = 1.0f / sqrtf(tot / d + eps);
+    if (c < nv) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(w[c * 8 + j] * rbf(v[j] * r));
+        *(bf16x8*)(y + (long)row * d + c * 8) = o;
+    }
 }
 
 // decode: act[r][c] = bf16(bf16(silu(bf16 g)) * bf16 u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)
@@ -233,10 +242,12 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
     __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (long)b * a.V;
+    const long ks_stride = (long)a.mpad * a.V;
     float* dump = a.logits_dump ? a.logits_dump + (long)a.step_counter[b] * a.dump_stride_step + (long)b * a.V : nullptr;
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int i = tid * 4; i < a.V; i += 1024 * 4) {
-        const f32x4 v = *(const f32x4*)(lg + i);
+        f32x4 v = *(const f32x4*)(lg + i);
+        for (int ks = 1; ks < a.ksplit; ++ks) v += *(const f32x4*)(lg + ks * ks_stride + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float r = rbf(v[j]);          // logits are bf16 in the reference, compared as fp32
@@ -309,7 +320,8 @@ void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d,
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, rows, d, eps, row_map);
 }
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, P, ksplit, mpad, w, y, rows, d, eps);
+    const int threads = ((d >> 3) + 63) / 64 * 64;   // d <= 2048 -> <= 256 threads
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(rows), dim3(threads), 0, s, x, P, ksplit, mpad, w, y, rows, d, eps);
 }
 void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s) {
     const long n = (long)rows * (n2 >> 3);

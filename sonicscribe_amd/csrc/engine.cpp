@@ -28,7 +28,8 @@ struct DevTensor {
 };
 
 struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; };
-struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown; };
+struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          // row-major (prefill GEMM)
+                   bf16_t *wqkv_t, *wo_t, *wgu_t, *wdown_t; };                 // fragment-tiled copies (decode skinny GEMM)
 
 struct sonic_engine {
     sonic_dims d;
@@ -46,7 +47,7 @@ struct sonic_engine {
     std::vector<EncLayerW> enc;
     float *enc_nw = nullptr, *enc_nb = nullptr;
     bf16_t *pj1w = nullptr, *pj2w = nullptr; float *pj1b = nullptr, *pj2b = nullptr;
-    bf16_t* embed = nullptr;
+    bf16_t* embed = nullptr; bf16_t* embed_t = nullptr;
     std::vector<DecLayerW> dec;
     float* dec_nw = nullptr;
 
@@ -249,7 +250,7 @@ extern "C" int sonic_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) !
 
 static int check_dims(const sonic_dims& d, int max_batch, int max_ctx) {
     if (d.n_mels <= 0 || d.n_mels % 64 != 0) return fail(nullptr, SONIC_ERR_INVALID, "n_mels must be a positive multiple of 64");
-    if (d.enc_d % 64 || d.enc_ff % 64 || d.dec_d % 128 || d.dec_ff % 128) return fail(nullptr, SONIC_ERR_INVALID, "hidden sizes must be multiples of 64 (encoder) / 128 (decoder)");
+    if (d.enc_d % 64 || d.enc_ff % 64 || d.dec_d % 256 || d.dec_ff % 256) return fail(nullptr, SONIC_ERR_INVALID, "hidden sizes must be multiples of 64 (encoder) / 256 (decoder)");
     if (d.enc_d / d.enc_heads != 64 || d.enc_d % d.enc_heads) return fail(nullptr, SONIC_ERR_INVALID, "encoder head_dim must be 64");
     if (d.dec_head_dim != 128) return fail(nullptr, SONIC_ERR_INVALID, "decoder head_dim must be 128");
     if (d.enc_rotary_dim % 16 || d.enc_rotary_dim > 64) return fail(nullptr, SONIC_ERR_INVALID, "encoder rotary dim must be a multiple of 16");
@@ -299,7 +300,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->Kc, kvn)); A(dalloc(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
     long mx = 2L * d.dec_ff; if (e->qkvN > mx) mx = e->qkvN; if (d.dec_d > mx) mx = d.dec_d;
     e->slabN = mx;
-    A(dalloc(e, &e->slab, (size_t)8 * 64 * mx)); A(dalloc(e, &e->lslab, (size_t)64 * d.vocab));
+    A(dalloc(e, &e->slab, (size_t)8 * 64 * mx)); A(dalloc(e, &e->lslab, (size_t)8 * 64 * d.vocab));
     A(dalloc(e, &e->sx, (size_t)64 * d.dec_d)); A(dalloc(e, &e->shn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->sq, (size_t)64 * e->QD));
     A(dalloc(e, &e->satt, (size_t)64 * e->QD)); A(dalloc(e, &e->sact, (size_t)64 * d.dec_ff));
     A(dalloc(e, &e->kv_len, 64)); A(dalloc(e, &e->tok_pos, 64)); A(dalloc(e, &e->n_new, 64)); A(dalloc(e, &e->finished, 64));
@@ -484,7 +485,18 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         HIPC(e, hipMemcpy2DAsync((char*)L.wgu + blk, 2 * blk, u->p, blk, blk, d.dec_ff / 16, hipMemcpyDeviceToDevice, e->st));
         e->weight_bytes += (int64_t)g->n * 4;
         TRY(keep_raw(e, p + "mlp.down_proj.weight", &L.wdown));
+        auto tiled = [&](const bf16_t* w, bf16_t** out, int N, int K) -> int {
+            TRY(dalloc(e, out, (size_t)N * K, false));
+            launch_tile_weights(w, *out, N, K, e->st);
+            e->weight_bytes += (int64_t)N * K * 2;
+            return SONIC_OK;
+        };
+        TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
+        TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
     }
+    TRY(dalloc(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
+    launch_tile_weights(e->embed, e->embed_t, d.vocab, d.dec_d, e->st);
+    e->weight_bytes += (int64_t)d.vocab * d.dec_d * 2;
     TRY(to_f32(e, lm + "norm.weight", &e->dec_nw));
     HIPC(e, hipStreamSynchronize(e->st));
     for (auto& kv : e->raw) if (kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; }
@@ -589,7 +601,7 @@ static int frames_of(int n_samples) { return n_samples > 0 ? (n_samples + 159) /
 
 static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, float* P, int M, int N, int K, int* ks_out) {
     SkinnyArgs a{};
-    a.X = X; a.ldx = ldx; a.W = W; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = (P == e->lslab) ? 1 : skinny_pick_ksplit(N, K);
+    a.X = X; a.ldx = ldx; a.W = W; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit(N, K);
     if (ks_out) *ks_out = a.ksplit;
     launch_skinny(a, e->st);
 }
@@ -597,7 +609,7 @@ static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, 
 static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     const sonic_dims& d = e->d;
     GreedyArgs g{};
-    g.logits = e->lslab; g.V = d.vocab; g.B = R; g.table = e->embed; g.x = e->sx; g.d = d.dec_d;
+    g.logits = e->lslab; g.ksplit = skinny_pick_ksplit(d.vocab, d.dec_d); g.mpad = ((R + 15) / 16) * 16; g.V = d.vocab; g.B = R; g.table = e->embed; g.x = e->sx; g.d = d.dec_d;
     g.out_ids = e->out_ids; g.out_ld = e->out_cap; g.n_new = e->n_new; g.finished = e->finished; g.kv_len = e->kv_len; g.tok_pos = e->tok_pos;
     g.max_new = e->max_new_d; g.n_active = e->n_active; g.n_eos = d.n_eos; g.pad_id = d.n_eos > 0 ? d.eos[0] : 0;
     for (int i = 0; i < d.n_eos; ++i) g.eos[i] = d.eos[i];
@@ -614,24 +626,21 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
-        skinny(e, e->shn, D, L.wqkv, e->slab, R, e->qkvN, D, &ks);
-        RopeAppendArgs ra{};
-        ra.P = e->slab; ra.ksplit = ks; ra.mpad = mpad; ra.q_out = e->sq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = nullptr;
-        ra.tok_seq = e->seq_iota; ra.tok_pos = e->tok_pos; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = R;
-        launch_rope_append(ra, true, e->st);
+        skinny(e, e->shn, D, L.wqkv_t, e->slab, R, e->qkvN, D, &ks);
         DecodeAttnArgs da{};
-        da.Q = e->sq; da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
+        da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs;     // RoPE + KV append fused into the attention kernel
+        da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_decode_attn(da, R, e->st);
-        skinny(e, e->satt, e->QD, L.wo, e->slab, R, D, e->QD, &ks);
+        skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st);
-        skinny(e, e->shn, D, L.wgu, e->slab, R, 2 * d.dec_ff, D, &ks);
+        skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
         launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st);
-        skinny(e, e->sact, d.dec_ff, L.wdown, e->slab, R, D, d.dec_ff, &ks);
+        skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks);
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st);
     }
-    skinny(e, e->shn, D, e->embed, e->lslab, R, d.vocab, D, nullptr);   // tied lm_head (modeling_glmasr.py:517)
+    skinny(e, e->shn, D, e->embed_t, e->lslab, R, d.vocab, D, nullptr);   // tied lm_head (modeling_glmasr.py:517)
     launch_greedy(greedy_args(e, R, dump), e->st);
 }
 
@@ -726,7 +735,7 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     }
     // logits only for the last prompt position of each request (logits_to_keep=1, generation/utils.py:2612-2616)
     launch_rmsnorm(e->dx, e->dec_nw, e->shn, R, D, d.dec_rms_eps, e->last_row, e->st);
-    skinny(e, e->shn, D, e->embed, e->lslab, R, d.vocab, D, nullptr);
+    skinny(e, e->shn, D, e->embed_t, e->lslab, R, d.vocab, D, nullptr);
     return SONIC_OK;
 }
 
@@ -934,8 +943,18 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
 // ------------------------------------------------------------------------------------------ C ABI: kernel test hooks
 struct TmpBuf {
     std::vector<void*> v;
+    hipStream_t st;
+    explicit TmpBuf(hipStream_t s) : st(s) {}
     ~TmpBuf() { for (void* p : v) (void)hipFree(p); }
-    template <typename Tt> Tt* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n ? n : 1) * sizeof(Tt)) != hipSuccess) return nullptr; (void)hipMemset(p, 0, (n ? n : 1) * sizeof(Tt)); v.push_back(p); return (Tt*)p; }
+    // zero-fill on the ENGINE stream: a null-stream hipMemset is not ordered against a non-blocking stream's kernels
+    template <typename Tt> Tt* get(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (n ? n : 1) * sizeof(Tt)) != hipSuccess) return nullptr;
+        (void)hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(Tt), st);
+        (void)hipStreamSynchronize(st);
+        v.push_back(p);
+        return (Tt*)p;
+    }
 };
 static bf16_t* up_bf16(sonic_engine* e, TmpBuf& tb, const float* h, size_t n, size_t pad = 0) {
     float* f = tb.get<float>(n); bf16_t* b = tb.get<bf16_t>(n + pad);
@@ -965,7 +984,7 @@ extern "C" int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, 
     std::lock_guard<std::mutex> lk(e->mu);
     HIPC(e, hipSetDevice(e->device));
     if (K % 64 || N % 4) return fail(e, SONIC_ERR_INVALID, "K must be a multiple of 64 and N of 4");
-    TmpBuf tb;
+    TmpBuf tb(e->st);
     const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
     bf16_t* dA = up_bf16(e, tb, A, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
     float* db = bias ? up_f32(tb, bias, N) : nullptr;
@@ -980,13 +999,15 @@ extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W
     if (!e) return SONIC_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     HIPC(e, hipSetDevice(e->device));
-    if (M < 1 || M > 64 || N % 64 || K % 128) return fail(e, SONIC_ERR_INVALID, "skinny: M<=64, N%%64==0, K%%128==0");
-    TmpBuf tb;
+    if (M < 1 || M > 64 || N % 16 || K % 256 || skinny_pick_ksplit(N, K) < 1) return fail(e, SONIC_ERR_INVALID, "skinny: M<=64, N%%16==0, K%%256==0");
+    TmpBuf tb(e->st);
     bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
+    bf16_t* dWt = tb.get<bf16_t>((size_t)N * K);
     const int ks = skinny_pick_ksplit(N, K), mpad = ((M + 15) / 16) * 16;
     float* P = tb.get<float>((size_t)ks * mpad * N);
-    if (!dX || !dW || !P) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
-    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dW; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks;
+    if (!dX || !dW || !dWt || !P) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    launch_tile_weights(dW, dWt, N, K, e->st);
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks;
     launch_skinny(a, e->st);
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
@@ -1015,7 +1036,7 @@ extern "C" int sonic_test_attention(sonic_engine* e, const float* q, const float
     std::lock_guard<std::mutex> lk(e->mu);
     HIPC(e, hipSetDevice(e->device));
     if (hd != 64 && hd != 128) return fail(e, SONIC_ERR_INVALID, "hd must be 64 or 128");
-    TmpBuf tb;
+    TmpBuf tb(e->st);
     const int Tkp = (Tk + 63) / 64 * 64;
     bf16_t* dq = up_bf16(e, tb, q, (size_t)B * Tq * Hq * hd);
     bf16_t* dk = up_bf16(e, tb, k, (size_t)B * Tk * Hkv * hd, (size_t)64 * Hkv * hd);
@@ -1046,7 +1067,7 @@ extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, cons
     HIPC(e, hipSetDevice(e->device));
     const int hd = 128, ctx = (Tk + 63) / 64 * 64;
     if (Hq % Hkv || Hq / Hkv > 4) return fail(e, SONIC_ERR_INVALID, "bad GQA group");
-    TmpBuf tb;
+    TmpBuf tb(e->st);
     // k, v given as [B][Tk][Hkv*hd]; cache layout is [B][Hkv][ctx][hd]
     std::vector<float> kc((size_t)B * Hkv * ctx * hd, 0.f), vc(kc.size(), 0.f);
     for (int b = 0; b < B; ++b) for (int t = 0; t < Tk; ++t) for (int h = 0; h < Hkv; ++h) for (int i = 0; i < hd; ++i) {
@@ -1057,7 +1078,7 @@ extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, cons
     bf16_t* dO = tb.get<bf16_t>((size_t)B * Hq * hd); int* kl = tb.get<int>(B);
     if (!dq || !dk || !dv || !dO || !kl) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     std::vector<int> l(B, Tk); HIPC(e, hipMemcpy(kl, l.data(), B * 4, hipMemcpyHostToDevice));
-    DecodeAttnArgs a{}; a.Q = dq; a.Kc = dk; a.Vc = dv; a.O = dO; a.kv_len = kl; a.Hq = Hq; a.Hkv = Hkv; a.ctx_max = ctx; a.scale = 1.0f / sqrtf(128.f);
+    DecodeAttnArgs a{}; a.Q = dq; a.P = nullptr; a.Kc = dk; a.Vc = dv; a.O = dO; a.kv_len = kl; a.Hq = Hq; a.Hkv = Hkv; a.ctx_max = ctx; a.scale = 1.0f / sqrtf(128.f);
     launch_decode_attn(a, B, e->st);
     return down_bf16(e, tb, dO, out, (size_t)B * Hq * hd);
 }
@@ -1067,7 +1088,7 @@ extern "C" int sonic_test_layernorm(sonic_engine* e, const float* x, const float
     std::lock_guard<std::mutex> lk(e->mu);
     HIPC(e, hipSetDevice(e->device));
     if (d % 8 || d > 2048) return fail(e, SONIC_ERR_INVALID, "d must be a multiple of 8 and <= 2048");
-    TmpBuf tb;
+    TmpBuf tb(e->st);
     bf16_t* dx = up_bf16(e, tb, x, (size_t)rows * d); float* dw = up_f32(tb, w, d); float* db = b ? up_f32(tb, b, d) : nullptr;
     bf16_t* dy = tb.get<bf16_t>((size_t)rows * d);
     if (!dx || !dw || !dy) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
@@ -1081,7 +1102,7 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     std::lock_guard<std::mutex> lk(e->mu);
     HIPC(e, hipSetDevice(e->device));
     if (K % 64 || N % 4 || iters < 1) return fail(e, SONIC_ERR_INVALID, "bad gemm bench shape");
-    TmpBuf tb;
+    TmpBuf tb(e->st);
     const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
     bf16_t* dA = tb.get<bf16_t>((size_t)M * K + 1024); bf16_t* dW = tb.get<bf16_t>((size_t)N * K); bf16_t* dC = tb.get<bf16_t>((size_t)M * Nout);
     float* db = tb.get<float>(N);
@@ -1100,4 +1121,41 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     HIPC(e, r); HIPC(e, hipGetLastError());
     *ms_per_launch = ms / iters;
     return SONIC_OK;
+}
+
+extern "C" int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int iters, float* us_per_launch) {
+    if (!e || !us_per_launch) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (M < 1 || M > 64 || N % 16 || K % 256 || skinny_pick_ksplit(N, K) < 1 || iters < 1) return fail(e, SONIC_ERR_INVALID, "bad skinny bench shape");
+    struct Restore { ~Restore() { set_skinny_variant(0); } } restore_variant;
+    TmpBuf tb(e->st);
+    set_skinny_variant(variant);   // before the ksplit pick: the slab count depends on the kernel family
+    // 8 distinct weight copies so consecutive launches do not re-read an Infinity-Cache-resident matrix
+    const int copies = 8;
+    bf16_t* dW = tb.get<bf16_t>((size_t)copies * N * K); bf16_t* dX = tb.get<bf16_t>((size_t)64 * K);
+    const int ks = skinny_pick_ksplit(N, K), mpad = ((M + 15) / 16) * 16;
+    float* P = tb.get<float>((size_t)ks * mpad * N);
+    if (!dW || !dX || !P) return fail(e, SONIC_ERR_OOM, "HIP out of memory in skinny bench");
+    launch_synth_fill(0x77, (long)copies * N * K, 0.05f, 0.f, dW, nullptr, e->st);
+    launch_synth_fill(0x78, (long)64 * K, 1.0f, 0.f, dX, nullptr, e->st);
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks;
+    for (int i = 0; i < copies; ++i) { a.W = dW + (size_t)(i % copies) * N * K; launch_skinny(a, e->st); }
+    hipEvent_t ea, eb; HIPC(e, hipEventCreate(&ea)); HIPC(e, hipEventCreate(&eb));
+    (void)hipEventRecord(ea, e->st);
+    for (int i = 0; i < iters; ++i) { a.W = dW + (size_t)(i % copies) * N * K; launch_skinny(a, e->st); }
+    (void)hipEventRecord(eb, e->st);
+    hipError_t r = hipStreamSynchronize(e->st);
+    float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    set_skinny_variant(0);
+    HIPC(e, r); HIPC(e, hipGetLastError());
+    *us_per_launch = ms * 1e3f / iters;
+    return SONIC_OK;
+}
+extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
+    if (!e || !key) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
+    return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
 }

@@ -201,72 +201,208 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny_kernel: decode-step GEMM, M <= 64 rows.  HBM-bound weight streaming: every weight byte is
-// read once, straight to VGPRs (no LDS round trip for an operand no other wave shares).  grid =
-// (N/64, ksplit); wave w of a block owns weight rows n0 + 16w .. +15 over the block's K slice and
-// emits D[n][m] (A-operand = W rows, B-operand = X rows) so its fp32 partials store as 16-byte
-// quads.  Partials land in per-slice slabs summed in fixed order by the consumer kernel
-// (deterministic; no float atomics).
-template <int MB>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// skinny_kernel: decode-step GEMM, M <= 64 rows.  HBM-bound weight streaming: every weight byte is read once, straight
+// to VGPRs (no LDS round trip for an operand no other wave shares).  The step is latency-bound, not bandwidth-bound, so
+// the kernel is "one-shot": a block owns 16 weight rows x (8 waves * KW * 32) of K; every wave issues ALL of its weight
+// loads (nontemporal, 1 KiB each) and activation loads before its first MFMA, so the whole matrix is in flight at once.
+// D[n][m] (A-operand = W rows, B-operand = X rows); the 8 K-slices of a block are summed through LDS in fixed order
+// (deterministic, no float atomics) and stored as fp32.  K = 2048 needs no split at all (one slab); down_proj
+// (K = 6144) leaves 3 slabs for its consumer.
+template <int MB, int KW, bool NT>
+__global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs a) {
+    __shared__ f32x4 red[8][MB][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 64 + wid * 16;
-    const int kslice = a.K / a.ksplit, kb = blockIdx.y * kslice;
-    const bf16_t* wp = a.W + (long)(n0 + r) * a.K + kb + g * 8;
-    const bf16_t* xp[MB];
+    const int n0 = blockIdx.x * 16;
+    const int kb = (blockIdx.y * 8 + wid) * (KW * 32);
+    // fragment-tiled weights (tile_weights_kernel): k-step s of row tile t is the contiguous 1 KiB block (t*K/32 + s)
+    const bf16_t* wp = a.W + ((long)blockIdx.x * (a.K >> 5) + (kb >> 5)) * 512 + lane * 8;
+    bf16x8 wf[KW];
+#pragma unroll
+    for (int u = 0; u < KW; ++u) wf[u] = NT ? __builtin_nontemporal_load((const bf16x8*)(wp + u * 512)) : *(const bf16x8*)(wp + u * 512);
+    bf16x8 xf[MB][KW];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         int row = mb * 16 + r; row = row < a.M ? row : a.M - 1;
-        xp[mb] = a.X + (long)row * a.ldx + kb + g * 8;
+        const bf16_t* xp = a.X + (long)row * a.ldx + kb + g * 8;
+#pragma unroll
+        for (int u = 0; u < KW; ++u) xf[mb][u] = *(const bf16x8*)(xp + u * 32);
     }
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // K slice is a multiple of 128: chunks of 4 k-steps, next chunk's weight loads issued before
-    // the current chunk's MFMAs (register double buffer) so >= 4 KiB per wave stays in flight.
-    bf16x8 wf[4], wn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 32));
-    for (int k = 0; k < kslice; k += 128) {
-        const bool more = (k + 128) < kslice;
-        if (more) {
+    for (int u = 0; u < KW; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wn[u] = __builtin_nontemporal_load((const bf16x8*)(wp + k + 128 + u * 32));
-        }
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[mb][u], acc[mb], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const bf16x8 xf = *(const bf16x8*)(xp[mb] + k + u * 32);
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[mb], 0, 0, 0);
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) wf[u] = wn[u];
-        }
-    }
+    for (int mb = 0; mb < MB; ++mb) red[wid][mb][lane] = acc[mb];
+    __syncthreads();
     const int mpad = MB * 16;
+    for (int o = tid; o < 16 * mpad; o += 512) {
+        const int m = o >> 4, nl = o & 15, mb = m >> 4, ln = (nl >> 2) * 16 + (m & 15), j = nl & 3;
+        float s = 0.f;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        float* p = a.P + ((long)blockIdx.y * mpad + mb * 16 + r) * a.N + n0 + g * 4;
-        *(f32x4*)p = acc[mb];
+        for (int w = 0; w < 8; ++w) s += red[w][mb][ln][j];
+        a.P[((long)blockIdx.y * mpad + m) * a.N + n0 + nl] = s;
     }
 }
 
-int skinny_pick_ksplit(int N, int K) {
-    const int tiles = N / 64;
-    int ks = 1;
-    while (ks < 8 && tiles * ks < 256 && (K / (ks * 2)) % 32 == 0 && K / (ks * 2) >= 128) ks *= 2;
-    return ks;
+// floor: read the same weight bytes, fully coalesced 16 B/lane, one-shot, trivially reduced (bench only)
+template <int KW>
+__global__ __launch_bounds__(512) void skinny_readfloor_kernel(SkinnyArgs a) {
+    const int tid = threadIdx.x;
+    const bf16_t* base = a.W + ((long)blockIdx.x * gridDim.y + blockIdx.y) * (8L * KW * 512) ;
+    bf16x8 v[KW];
+#pragma unroll
+    for (int u = 0; u < KW; ++u) v[u] = __builtin_nontemporal_load((const bf16x8*)(base + ((long)u * 512 + tid) * 8));
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < KW; ++u) s += bf2f(v[u][0]) + bf2f(v[u][7]);
+    if (s == 123.456f) a.P[0] = s;
 }
 
+// skinny_xs_kernel: the decode-step GEMM with the activation slice SHARED through LDS.  Measured on MI355X (tools/
+// bench_skinny.py): the weight stream is not the limiter of the one-shot kernels above -- their time scales with M,
+// i.e. with the per-wave 64-byte-per-row gathers of X out of L2.  Here a block owns BN = 16*WN weight rows and a K slice
+// of BKk = WK*KSW*32; the X slice [M][BKk] is DMA'd ONCE per block into LDS in full 128-byte lines (swizzled on the
+// source address, conflict-free ds_read_b128 fragments) and read by all 8 waves; weights go straight to VGPRs from the
+// fragment-tiled copy (every wave load is one contiguous 1 KiB, each weight byte read once, nontemporal).  The WK
+// K-slices of a block are summed through LDS; K/BKk slabs are left for the consumer (2 for K = 2048 with BKk = 1024).
+template <int MB, int WN, int WK, int KSW>
+__global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
+    constexpr int BKk = WK * KSW * 32, NKB = BKk / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048;
+    static_assert(WN * WK == 8 && NI % 8 == 0, "8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wn = wid % WN, wk = wid / WN;
+    const int n0 = blockIdx.x * (WN * 16) + wn * 16;
+    const int kb = blockIdx.y * BKk;
+    // weights first: they come from HBM
+    const bf16_t* wp = a.W + ((long)(n0 >> 4) * (a.K >> 5) + ((kb + wk * (KSW * 32)) >> 5)) * 512 + lane * 8;
+    bf16x8 wf[KSW];
+#pragma unroll
+    for (int u = 0; u < KSW; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
+    {
+        const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+#pragma unroll
+        for (int t = 0; t < NI / 8; ++t) {
+            const int ii = wid * (NI / 8) + t, kblock = ii / RG, rg = ii % RG;
+            int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
+            const bf16_t* src = a.X + (long)row * a.ldx + kb + kblock * 64 + lc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
+        }
+    }
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KSW; ++u) {
+        const int kg = wk * KSW + u, kblock = kg >> 1, half = kg & 1;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = mb * 16 + r;
+            const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[mb], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    f32x4* red = (f32x4*)smem;   // [WK][WN][MB][64]
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) red[((wk * WN + wn) * MB + mb) * 64 + lane] = acc[mb];
+    __syncthreads();
+    constexpr int BNR = WN * 16, mpad = MB * 16;
+    const int nb0 = blockIdx.x * BNR;
+    for (int o = tid; o < BNR * mpad; o += 512) {
+        const int m = o / BNR, nl = o % BNR, wn2 = nl >> 4, nloc = nl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < WK; ++k) s += red[((k * WN + wn2) * MB + (m >> 4)) * 64 + ln][j];
+        a.P[((long)blockIdx.y * mpad + m) * a.N + nb0 + nl] = s;
+    }
+}
+
+int g_skinny_variant = 0;   // 0: shared-X kernel where the shape allows, else one-shot; 2: one-shot nt; 3: one-shot plain loads; 9: read floor (bench only)
+void set_skinny_variant(int v) { g_skinny_variant = v; }
+
+static int skinny_pick_kw(int K) {
+    for (int kw = 8; kw >= 1; kw >>= 1)
+        if (K % (256 * kw) == 0 && K / (256 * kw) <= 8) return kw;
+    return 0;
+}
+// config: 1 = BIG (64 rows x 1024 k per block), 2 = SMALL (32 rows x 512 k), 0 = one-shot register kernel (small K)
+static int skinny_pick_cfg(int N, int K) {
+    if (g_skinny_variant >= 2) return 0;
+    if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8 && (long)(N / 64) * (K / 1024) >= 192) return 1;
+    if (K % 512 == 0 && N % 32 == 0 && K / 512 <= 8) return 2;
+    if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8) return 1;
+    return 0;
+}
+int skinny_pick_ksplit(int N, int K) {
+    const int cfg = skinny_pick_cfg(N, K);
+    if (cfg == 1) return K / 1024;
+    if (cfg == 2) return K / 512;
+    const int kw = skinny_pick_kw(K);
+    return kw ? K / (256 * kw) : 0;
+}
+
+template <int MB, int KW> static void launch_skinny_v(const SkinnyArgs& a, hipStream_t s) {
+    dim3 grid(a.N / 16, a.ksplit), block(512);
+    const int v = g_skinny_variant;
+    if (v == 9) hipLaunchKernelGGL((skinny_readfloor_kernel<KW>), grid, block, 0, s, a);
+    else if (v == 3) hipLaunchKernelGGL((skinny_kernel<MB, KW, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<MB, KW, true>), grid, block, 0, s, a);
+}
+template <int MB> static void launch_skinny_mb(const SkinnyArgs& a, int kw, hipStream_t s) {
+    switch (kw) {
+        case 8: launch_skinny_v<MB, 8>(a, s); break;
+        case 4: launch_skinny_v<MB, 4>(a, s); break;
+        case 2: launch_skinny_v<MB, 2>(a, s); break;
+        default: launch_skinny_v<MB, 1>(a, s); break;
+    }
+}
+template <int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
+    if (cfg == 1) {
+        const size_t lds = (size_t)16 * MB * 2048;
+        static bool attr_done = false;
+        if (!attr_done && lds > 65536) { (void)hipFuncSetAttribute((const void*)skinny_xs_kernel<MB, 4, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        hipLaunchKernelGGL((skinny_xs_kernel<MB, 4, 2, 16>), dim3(a.N / 64, a.K / 1024), dim3(512), lds, s, a);
+    } else {
+        const size_t lds = (size_t)8 * MB * 2048;
+        hipLaunchKernelGGL((skinny_xs_kernel<MB, 2, 4, 4>), dim3(a.N / 32, a.K / 512), dim3(512), lds, s, a);
+    }
+}
 void launch_skinny(const SkinnyArgs& a, hipStream_t s) {
-    dim3 grid(a.N / 64, a.ksplit), block(256);
+    const int cfg = skinny_pick_cfg(a.N, a.K);
     const int mb = (a.M + 15) / 16;
-    if (mb <= 1) hipLaunchKernelGGL(skinny_kernel<1>, grid, block, 0, s, a);
-    else if (mb == 2) hipLaunchKernelGGL(skinny_kernel<2>, grid, block, 0, s, a);
-    else if (mb == 3) hipLaunchKernelGGL(skinny_kernel<3>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(skinny_kernel<4>, grid, block, 0, s, a);
+    if (cfg) {
+        if (mb <= 1) launch_skinny_xs<1>(a, cfg, s);
+        else if (mb == 2) launch_skinny_xs<2>(a, cfg, s);
+        else if (mb == 3) launch_skinny_xs<3>(a, cfg, s);
+        else launch_skinny_xs<4>(a, cfg, s);
+        return;
+    }
+    const int kw = skinny_pick_kw(a.K);
+    if (mb <= 1) launch_skinny_mb<1>(a, kw, s);
+    else if (mb == 2) launch_skinny_mb<2>(a, kw, s);
+    else if (mb == 3) launch_skinny_mb<3>(a, kw, s);
+    else launch_skinny_mb<4>(a, kw, s);
+}
+
+// W[N][K] row-major -> fragment-tiled: element (n, k) goes to ((n/16)*(K/32) + k/32)*512 + (((k%32)/8)*16 + n%16)*8 + k%8,
+// i.e. the 64 lanes of the MFMA A-operand of (row tile, k-step) read 64 consecutive 16-byte pieces.
+__global__ void tile_weights_kernel(const bf16_t* w, bf16_t* wt, int N, int K) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element piece per thread
+    if (e >= (long)N * (K >> 3)) return;
+    const int n = e / (K >> 3), kc = e % (K >> 3), k = kc * 8;
+    const long dst = ((long)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + ((((k & 31) >> 3) * 16) + (n & 15)) * 8;
+    *(bf16x8*)(wt + dst) = *(const bf16x8*)(w + (long)n * K + k);
+}
+void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s) {
+    const long n = (long)N * (K >> 3);
+    hipLaunchKernelGGL(tile_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wt, N, K);
 }

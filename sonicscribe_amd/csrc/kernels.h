@@ -17,9 +17,10 @@ struct FlashArgs {
 void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s);
 
 struct DecodeAttnArgs {
-    const bf16_t* Q;      // [B][Hq*128] (roped)
-    const bf16_t* Kc;     // [B][Hkv][ctx_max][128]
-    const bf16_t* Vc;     // [B][Hkv][ctx_max][128]
+    const bf16_t* Q;      // [B][Hq*128] (roped); used when P == null
+    const float* P; int ksplit, mpad; const float* cs;   // fused mode: QKV slabs [ks][mpad][(Hq+2Hkv)*128] + rope table [ctx][128]
+    bf16_t* Kc;           // [B][Hkv][ctx_max][128]
+    bf16_t* Vc;           // [B][Hkv][ctx_max][128]
     bf16_t* O;            // [B][Hq*128]
     const int* kv_len;    // [B] keys visible (new token included)
     int Hq, Hkv, ctx_max;
@@ -40,7 +41,8 @@ struct RopeAppendArgs {
 void launch_rope_append(const RopeAppendArgs& a, bool slab, hipStream_t s);
 
 struct GreedyArgs {
-    const float* logits;   // slab [mpad][V] fp32 accumulators of the lm_head (ksplit == 1)
+    const float* logits;   // slabs [ksplit][mpad][V] fp32 partial accumulators of the lm_head
+    int ksplit, mpad;
     int V, B;
     const bf16_t* table;   // embedding table (tied lm_head), for the next step's input row
     bf16_t* x; int d;      // [B][d] next-step hidden input

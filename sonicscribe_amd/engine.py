@@ -25,7 +25,7 @@ EXPORTS = [
     "sonic_device_count", "sonic_create", "sonic_destroy", "sonic_last_error", "sonic_load_tensor", "sonic_load_synthetic",
     "sonic_finalize_weights", "sonic_weight_bytes", "sonic_logmel", "sonic_encode", "sonic_transcribe_batch", "sonic_stage_pcm",
     "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
-    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm",
+    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option",
 ]
 
 
@@ -102,6 +102,8 @@ def load_library():
     lib.sonic_test_decode_attention.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 4
     lib.sonic_test_layernorm.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int]
     lib.sonic_bench_gemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.sonic_bench_skinny.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.sonic_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -309,6 +311,20 @@ class Engine:
         ms = C.c_float(0)
         self._check(self.lib.sonic_bench_gemm(self.h, M, N, K, epi, iters, C.byref(ms)))
         return float(ms.value)
+
+
+def _bench_skinny(self, M: int, N: int, K: int, variant: int, iters: int = 50) -> float:
+    us = C.c_float(0)
+    self._check(self.lib.sonic_bench_skinny(self.h, M, N, K, variant, iters, C.byref(us)))
+    return float(us.value)
+
+
+def _set_option(self, key: str, value: int):
+    self._check(self.lib.sonic_set_option(self.h, key.encode(), value))
+
+
+Engine.bench_skinny = _bench_skinny
+Engine.set_option = _set_option
 
 
 def device_count() -> int:

@@ -23,7 +23,7 @@ def bf(x):
 @pytest.fixture(scope="module")
 def eng():
     from sonicscribe_amd.engine import Engine
-    e = Engine(spec.TINY, 0, max_batch=8, max_ctx=512)
+    e = Engine(spec.TINY, 0, max_batch=16, max_ctx=512)
     e.load_synthetic(20260128)
     yield e
     e.close()
@@ -84,7 +84,7 @@ def test_gemm_epilogues(eng, orc):
     assert np.all(np.abs(got - ref) <= ulp_tol(ref, 4) + 1e-3), np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (32, 256, 256), (32, 1024, 512), (40, 512, 2048), (64, 128, 768)])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (32, 256, 256), (32, 1024, 512), (40, 512, 2048), (64, 128, 768), (33, 48, 1024), (32, 2048, 6144)])
 def test_skinny(eng, M, N, K):
     rng = np.random.default_rng(M * 7 + N)
     X = bf(rng.standard_normal((M, K))); W = bf(rng.standard_normal((N, K)) * 0.1)
