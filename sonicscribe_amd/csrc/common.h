@@ -16,7 +16,20 @@ __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }          // v_cvt_pk_bf16_f32: RNE, NaN-safe
 __device__ __forceinline__ float rbf(float x) { return (float)((bf16_t)x); }  // round-trip through bf16
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-form GELU 0.5*x*(1+erf(x/sqrt2)) with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): a dozen VALU ops
+// instead of libm erff (which cost ~25 % of the fc1 GEMM in its epilogue).  For x < 0 the complementary form
+// 1 + erf(x) = poly(t) * exp(-z^2) is used directly, so there is no cancellation in the tail.  The result is rounded to
+// bf16 by the caller, which is 3 orders of magnitude coarser than the approximation error.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float pe = p * t * __expf(-z * z);          // = 1 - erf(z) = erfc(z)
+    return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -62,4 +75,5 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
 void set_skinny_variant(int v);
+void set_gemm_force128(int v);
 void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);

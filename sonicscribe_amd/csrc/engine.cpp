@@ -73,7 +73,8 @@ struct sonic_engine {
     int *src = nullptr, *tok_seq = nullptr, *tok_pos_pf = nullptr, *q_off = nullptr, *q_len = nullptr, *last_row = nullptr;
     float* dump = nullptr; size_t dump_cap = 0; int dump_steps = 0;
     int* n_active_h = nullptr;  // pinned
-    int R = 0, max_steps = 0;
+    int R = 0, max_steps = 0, greedy_calls = 0;
+    std::vector<int> last_qlen, last_maxnew;
     std::map<int, hipGraphExec_t> graphs;
 
     // timing
@@ -746,7 +747,7 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     if (e->W < 1) return fail(e, SONIC_ERR_INVALID, "no PCM staged");
     HostPlan hp;
     TRY(plan_requests(e, req_win, R, prompt_ids, prompt_off, max_new, hp));
-    e->R = R; e->max_steps = hp.max_steps;
+    e->R = R; e->max_steps = hp.max_steps; e->last_qlen = hp.q_len; e->last_maxnew = hp.max_new;
     if (want_logits) {
         const size_t need_n = (size_t)hp.max_steps * R * d.vocab;
         if (need_n > e->dump_cap) {
@@ -808,6 +809,7 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
         t.gemm_flops += 2.0 * (double)e->W * e->T * d.enc_ff * d.enc_d;
     }
     t.decode_steps = steps_done;
+    e->greedy_calls = 1 + steps_done;
     return SONIC_OK;
 }
 
@@ -847,8 +849,18 @@ extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, 
 static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
     const int R = e->R;
     if (R < 1) return fail(e, SONIC_ERR_INVALID, "nothing to fetch");
-    std::vector<int> nn(64);
+    std::vector<int> nn(64), kvl(64), tps(64);
     HIPC(e, hipMemcpy(nn.data(), e->n_new, 64 * 4, hipMemcpyDeviceToHost));
+    HIPC(e, hipMemcpy(kvl.data(), e->kv_len, 64 * 4, hipMemcpyDeviceToHost));
+    HIPC(e, hipMemcpy(tps.data(), e->tok_pos, 64 * 4, hipMemcpyDeviceToHost));
+    // invariants of the greedy controller: every launch advances each row's context by exactly one token
+    for (int r = 0; r < R && r < (int)e->last_qlen.size(); ++r) {
+        const int want_kv = e->last_qlen[r] + e->greedy_calls;
+        const int want_new = e->greedy_calls < e->last_maxnew[r] ? e->greedy_calls : e->last_maxnew[r];
+        if (kvl[r] != want_kv || tps[r] != want_kv - 1 || nn[r] > e->last_maxnew[r] || (e->d.n_eos == 0 && nn[r] != want_new))
+            return fail(e, SONIC_ERR_HIP, "decoder state check failed for request %d: kv_len %d (expected %d), tok_pos %d, n_new %d (budget %d, greedy launches %d)",
+                        r, kvl[r], want_kv, tps[r], nn[r], e->last_maxnew[r], e->greedy_calls);
+    }
     for (int r = 0; r < R; ++r) {
         if (out_len) out_len[r] = nn[r];
         if (out_ids) {
@@ -1157,5 +1169,6 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!e || !key) return SONIC_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
+    if (!strcmp(key, "gemm_force128")) { set_gemm_force128(value); return SONIC_OK; }
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
 }

@@ -187,7 +187,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     }
 }
 
+bool gemm256_eligible(const GemmArgs& a, int epi);
+void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
+int g_gemm_force128 = 0;
+void set_gemm_force128(int v) { g_gemm_force128 = v; }
+
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
+    if (!g_gemm_force128 && gemm256_eligible(a, epi)) { launch_gemm256(a, epi, s); return; }
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), block(256);
     const size_t lds = 2 * STAGE_BYTES;

@@ -84,6 +84,37 @@ def test_gemm_epilogues(eng, orc):
     assert np.all(np.abs(got - ref) <= ulp_tol(ref, 4) + 1e-3), np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (777, 384, 512, 1), (2048, 256, 1280, 2), (600, 1280, 320, 0), (520, 512, 256, 3)])
+def test_gemm256_path(eng, M, N, K, epi):
+    """Shapes large enough for the 256x256 multi-phase kernel (M >= 512, N >= 256, K >= 256), ragged edges included."""
+    import math
+    rng = np.random.default_rng(M + N)
+    A = bf(rng.standard_normal((M, K)) * 0.5); W = bf(rng.standard_normal((N, K)) * 0.2); b = bf(rng.standard_normal(N) * 0.1)
+    lin = lambda bias: bf((A.astype(np.float64) @ W.T.astype(np.float64) + bias).astype(np.float32))
+    if epi == 0:
+        got, ref = eng.test_gemm(A, W, b), lin(b)
+    elif epi == 1:
+        l = lin(b); erf = np.vectorize(math.erf)
+        got, ref = eng.test_gemm(A, W, b, epi=1), bf((0.5 * l * (1.0 + erf(l.astype(np.float64) / math.sqrt(2.0)))).astype(np.float32))
+    elif epi == 2:
+        R = bf(rng.standard_normal((M, N)))
+        got, ref = eng.test_gemm(A, W, b, resid=R, epi=2), bf(lin(b) + R)
+        ref_mag = np.abs(lin(b)) + np.abs(R)      # the residual add can cancel: tolerance follows the addends
+    else:
+        ff = N // 2
+        g = lin(0.0)
+        idx_g = np.concatenate([np.arange(32 * i, 32 * i + 16) for i in range(ff // 16)]); idx_u = idx_g + 16
+        gg, uu = g[:, idx_g], g[:, idx_u]
+        got, ref = eng.test_gemm(A, W, epi=3), bf(bf(gg / (1.0 + np.exp(-gg))) * uu)
+    assert np.all(np.abs(got - ref) <= ulp_tol(ref_mag if epi == 2 else ref, 4) + 1e-3), np.abs(got - ref).max()
+    eng.set_option("gemm_force128", 1)
+    try:
+        old = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
+    finally:
+        eng.set_option("gemm_force128", 0)
+    assert np.mean(old != got) < 0.02      # same math, different summation order: only isolated bf16 flips
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 64, 256), (32, 256, 256), (32, 1024, 512), (40, 512, 2048), (64, 128, 768), (33, 48, 1024), (32, 2048, 6144)])
 def test_skinny(eng, M, N, K):
     rng = np.random.default_rng(M * 7 + N)
@@ -301,3 +332,36 @@ def test_asrmodel_facade_threads(golden_dir):
     assert not hasattr(m, "model")
     with pytest.raises(RuntimeError):
         m.transcribe(segs[0][None])
+
+
+def test_fullwidth_layer_vs_oracle(orc):
+    """Full-width GLM-ASR-Nano dimensions (d=1280/5120, 20 heads; decoder 2048/6144, GQA 16:4) with ONE encoder and ONE decoder
+    layer and a small vocab, two 20 s segments: drives every large-shape kernel instantiation (256x256 GEMM with the
+    QKV+V^T / GELU / residual / SwiGLU epilogues, T=1500 flash attention, prefill at M=520) against the bf16 oracle."""
+    from dataclasses import replace
+    from sonicscribe_amd.engine import Engine
+    d = replace(spec.FULL, enc_layers=1, dec_layers=1, vocab=1024, audio_token_id=1000, eos_ids=(990, 991, 992))
+    seed = 7
+    e = Engine(d, 0, max_batch=2, max_ctx=320)
+    e.load_synthetic(seed)
+    om = orc.Model(d, synth.synth_state_dict(d, seed, bf16=True), bf16=True)
+    segs = [synth.synth_pcm(60 + i, 320000) for i in range(2)]
+    n_audio = spec.audio_token_count(spec.valid_frames(320000))
+    prompt = [1, 17, 23, 5] + [d.audio_token_id] * n_audio + [7, 301, 302, 303, 9, 11]
+    n_new = 3
+    ids, logits = e.transcribe_batch(segs, [prompt, prompt], [n_new, n_new], want_logits=True)
+    feats_all, masks = e.logmel(segs)
+    emb, n_a, layers, enc_out = e.encode(feats_all, [int(m.sum()) for m in masks], want_layers=True, want_enc_out=True)
+    for i in range(2):
+        feats, mask = orc.logmel(segs[i])
+        r = om.transcribe(feats, int(mask.sum()), prompt, n_new, want=("enc_layers", "enc_out"))
+        el = np.abs(layers[i, 0] - r["enc_layers"][0])
+        assert el.max() < 0.5 and el.mean() < 8e-3, (el.max(), el.mean())
+        ee = np.abs(emb[i, :n_audio] - r["audio_embeds"][:n_audio])
+        assert ee.max() < 0.25 and ee.mean() < 8e-3, (ee.max(), ee.mean())
+        dl = np.abs(logits[0, i] - r["step_logits"][0])
+        assert dl.max() <= 6 * 2.0 ** -6, dl.max()            # prefill logits, bf16-derived bound
+        srt = np.sort(r["step_logits"][0]); margin = srt[-1] - srt[-2]
+        if margin > 12 * 2.0 ** -6:
+            assert ids[i][0] == r["new_ids"][0]
+    e.close()
