@@ -118,7 +118,10 @@ int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const 
 int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch);
 /* times the decode-step skinny GEMM (variant: 0 LDS-DMA nt, 1 LDS-DMA default policy, 2 registers nt, 3 registers plain, 9 pure-read floor) */
 int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int iters, float* us_per_launch);
-/* tuning knobs for experiments ("skinny_variant") */
+/* debug read-back of an internal bf16 activation buffer as fp32 ("prefill_tap" with index = 0 (embeddings) .. dec_layers,
+ * "pe", "dx", "dqkv", "dq", "datt", "dact", "enc_x"); tests / diagnostics only */
+int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
+/* tuning knobs for experiments ("skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps") */
 int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus

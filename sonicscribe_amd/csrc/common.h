@@ -76,4 +76,5 @@ void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
 void set_skinny_variant(int v);
 void set_gemm_force128(int v);
+void set_gemm256_stagger(int v);
 void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);

@@ -286,6 +286,16 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
 }
 
 // ---------------------------------------------------------------- misc
+// In-stream fill of small control words.  hipMemsetAsync of a few bytes was observed not to be reliably ordered against
+// the neighbouring kernels of a non-blocking stream (a stale per-segment log-mel maximum survived a reset on some runs);
+// a kernel on the stream is.
+__global__ void fill_i32_kernel(int* p, int value, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+void launch_fill_i32(int* p, int value, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, value, n);
+}
 __global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = f2bf(in[i]);

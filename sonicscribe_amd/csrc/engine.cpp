@@ -72,6 +72,7 @@ struct sonic_engine {
     int *out_ids = nullptr, *step_ctr = nullptr, *seq_iota = nullptr;
     int *src = nullptr, *tok_seq = nullptr, *tok_pos_pf = nullptr, *q_off = nullptr, *q_len = nullptr, *last_row = nullptr;
     float* dump = nullptr; size_t dump_cap = 0; int dump_steps = 0;
+    bf16_t* taps = nullptr; int taps_on = 0; int last_ntok = 0;   // debug: prefill hidden states after embedding + each layer
     int* n_active_h = nullptr;  // pinned
     int R = 0, max_steps = 0, greedy_calls = 0;
     std::vector<int> last_qlen, last_maxnew;
@@ -100,6 +101,15 @@ static int fail(sonic_engine* e, int code, const char* fmt, ...) {
                         oom ? "HIP out of memory: " : "", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
         }                                                                                                  \
     } while (0)
+
+// Host -> device copy on the ENGINE stream, complete on return.  Never use the null-stream hipMemcpy for uploads: the
+// engine stream is non-blocking, so a null-stream copy is not ordered against work still queued on it (dalloc's zero fill
+// once wiped parts of a freshly uploaded RoPE table that way).
+static hipError_t h2d(sonic_engine* e, void* dst, const void* src, size_t bytes) {
+    hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->st);
+    if (r != hipSuccess) return r;
+    return hipStreamSynchronize(e->st);
+}
 
 template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
     void* q = nullptr;
@@ -238,7 +248,7 @@ static int build_constants(sonic_engine* e) {
                 t[(size_t)p * rd + half + i] = bf16_round_host(sinf(ang));
             }
         TRY(dalloc(e, out, t.size()));
-        HIPC(e, hipMemcpy(*out, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        HIPC(e, h2d(e, *out, t.data(), t.size() * 4));
         return SONIC_OK;
     };
     TRY(rope_table(e->T, d.enc_rotary_dim, d.enc_theta, &e->enc_cs));
@@ -311,7 +321,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
     {
         int iota[64]; for (int i = 0; i < 64; ++i) iota[i] = i;
-        if (hipMemcpy(e->seq_iota, iota, sizeof iota, hipMemcpyHostToDevice) != hipSuccess) { e->err = "memcpy failed"; return bail(SONIC_ERR_HIP); }
+        if (h2d(e, e->seq_iota, iota, sizeof iota) != hipSuccess) { e->err = "memcpy failed"; return bail(SONIC_ERR_HIP); }
     }
     if (hipHostMalloc((void**)&e->n_active_h, 64, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return bail(SONIC_ERR_HIP); }
     for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
@@ -332,6 +342,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->dump) (void)hipFree(e->dump);
+    if (e->taps) (void)hipFree(e->taps);
     if (e->feats_f32) (void)hipFree(e->feats_f32);
     if (e->n_active_h) (void)hipHostFree(e->n_active_h);
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
@@ -375,11 +386,11 @@ extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* 
     DevTensor* t;
     TRY(raw_alloc(e, name, shp, &t));
     if (dtype == SONIC_DTYPE_BF16) {
-        HIPC(e, hipMemcpy(t->p, data, t->n * 2, hipMemcpyHostToDevice));
+        HIPC(e, h2d(e, t->p, data, t->n * 2));
     } else if (dtype == SONIC_DTYPE_F32) {
         float* tmp = nullptr;
         HIPC(e, hipMalloc((void**)&tmp, t->n * 4));
-        hipError_t r = hipMemcpy(tmp, data, t->n * 4, hipMemcpyHostToDevice);
+        hipError_t r = h2d(e, tmp, data, t->n * 4);
         if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st); r = hipStreamSynchronize(e->st); }
         (void)hipFree(tmp);
         HIPC(e, r);
@@ -707,12 +718,17 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     HIPC(e, hipMemcpyAsync(e->kv_len, hp.q_len.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(e->last_row, hp.last_row.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(e->max_new_d, hp.max_new.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemsetAsync(e->n_new, 0, 64 * 4, e->st));
-    HIPC(e, hipMemsetAsync(e->finished, 0, 64 * 4, e->st));
-    HIPC(e, hipMemsetAsync(e->step_ctr, 0, 64 * 4, e->st));
+    launch_fill_i32(e->n_new, 0, 64, e->st);
+    launch_fill_i32(e->finished, 0, 64, e->st);
+    launch_fill_i32(e->step_ctr, 0, 64, e->st);
     HIPC(e, hipMemcpyAsync(e->n_active, &R, 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipStreamSynchronize(e->st));   // host vectors go out of scope with the caller; tiny copies
     launch_assemble_embeds(e->src, e->embed, e->pe, e->dx, M, D, e->st);
+    e->last_ntok = M;
+    if (e->taps_on) {
+        if (!e->taps) HIPC(e, hipMalloc((void**)&e->taps, (size_t)(d.dec_layers + 1) * e->tok_cap * D * sizeof(bf16_t)));
+        HIPC(e, hipMemcpyAsync(e->taps, e->dx, (size_t)M * D * 2, hipMemcpyDeviceToDevice, e->st));
+    }
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
@@ -733,6 +749,7 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
         launch_rmsnorm(e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st);
         gemm(e, EPI_SWIGLU, e->dhn, D, L.wgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D);
         gemm(e, EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, nullptr, e->dx, D, M, D, d.dec_ff, e->dx, D);
+        if (e->taps_on) HIPC(e, hipMemcpyAsync(e->taps + (size_t)(l + 1) * e->tok_cap * D, e->dx, (size_t)M * D * 2, hipMemcpyDeviceToDevice, e->st));
     }
     // logits only for the last prompt position of each request (logits_to_keep=1, generation/utils.py:2612-2616)
     launch_rmsnorm(e->dx, e->dec_nw, e->shn, R, D, d.dec_rms_eps, e->last_row, e->st);
@@ -930,7 +947,7 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
     const size_t n = (size_t)B * d.n_mels * d.n_frames;
     float* tmp = nullptr;
     HIPC(e, hipMalloc((void**)&tmp, n * 4));
-    hipError_t r = hipMemcpy(tmp, feats, n * 4, hipMemcpyHostToDevice);
+    hipError_t r = h2d(e, tmp, feats, n * 4);
     if (r != hipSuccess) { (void)hipFree(tmp); HIPC(e, r); }
     const long per = (long)d.n_mels * d.n_frames;
     hipLaunchKernelGGL(feats_to_fm_kernel, dim3((per + 255) / 256, B), dim3(256), 0, e->st, tmp, e->feats_fm, d.n_mels, d.n_frames);
@@ -971,13 +988,13 @@ struct TmpBuf {
 static bf16_t* up_bf16(sonic_engine* e, TmpBuf& tb, const float* h, size_t n, size_t pad = 0) {
     float* f = tb.get<float>(n); bf16_t* b = tb.get<bf16_t>(n + pad);
     if (!f || !b) return nullptr;
-    if (hipMemcpy(f, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (h2d(e, f, h, n * 4) != hipSuccess) return nullptr;
     launch_f32_to_bf16(f, b, (long)n, e->st);
     return b;
 }
-static float* up_f32(TmpBuf& tb, const float* h, size_t n) {
+static float* up_f32(sonic_engine* e, TmpBuf& tb, const float* h, size_t n) {
     float* f = tb.get<float>(n);
-    if (f && hipMemcpy(f, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (f && h2d(e, f, h, n * 4) != hipSuccess) return nullptr;
     return f;
 }
 static int down_bf16(sonic_engine* e, TmpBuf& tb, const bf16_t* d, float* h, size_t n) {
@@ -999,7 +1016,7 @@ extern "C" int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, 
     TmpBuf tb(e->st);
     const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
     bf16_t* dA = up_bf16(e, tb, A, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
-    float* db = bias ? up_f32(tb, bias, N) : nullptr;
+    float* db = bias ? up_f32(e, tb, bias, N) : nullptr;
     bf16_t* dR = resid ? up_bf16(e, tb, resid, (size_t)M * Nout) : nullptr;
     bf16_t* dC = tb.get<bf16_t>((size_t)M * Nout);
     if (!dA || !dW || !dC) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
@@ -1066,7 +1083,7 @@ extern "C" int sonic_test_attention(sonic_engine* e, const float* q, const float
     if (Tq != Tk) {   // per-sequence lengths (decode-style offset: query t sits at position Tk - Tq + t)
         ql = tb.get<int>(B); kl = tb.get<int>(B);
         std::vector<int> a(B, Tq), b2(B, Tk);
-        HIPC(e, hipMemcpy(ql, a.data(), B * 4, hipMemcpyHostToDevice)); HIPC(e, hipMemcpy(kl, b2.data(), B * 4, hipMemcpyHostToDevice));
+        HIPC(e, h2d(e, ql, a.data(), B * 4)); HIPC(e, h2d(e, kl, b2.data(), B * 4));
         f.q_len = ql; f.kv_len = kl;
     }
     launch_flash(f, hd, causal != 0, B, Tq, e->st);
@@ -1089,7 +1106,7 @@ extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, cons
     bf16_t* dq = up_bf16(e, tb, q, (size_t)B * Hq * hd); bf16_t* dk = up_bf16(e, tb, kc.data(), kc.size()); bf16_t* dv = up_bf16(e, tb, vc.data(), vc.size());
     bf16_t* dO = tb.get<bf16_t>((size_t)B * Hq * hd); int* kl = tb.get<int>(B);
     if (!dq || !dk || !dv || !dO || !kl) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
-    std::vector<int> l(B, Tk); HIPC(e, hipMemcpy(kl, l.data(), B * 4, hipMemcpyHostToDevice));
+    std::vector<int> l(B, Tk); HIPC(e, h2d(e, kl, l.data(), B * 4));
     DecodeAttnArgs a{}; a.Q = dq; a.P = nullptr; a.Kc = dk; a.Vc = dv; a.O = dO; a.kv_len = kl; a.Hq = Hq; a.Hkv = Hkv; a.ctx_max = ctx; a.scale = 1.0f / sqrtf(128.f);
     launch_decode_attn(a, B, e->st);
     return down_bf16(e, tb, dO, out, (size_t)B * Hq * hd);
@@ -1101,7 +1118,7 @@ extern "C" int sonic_test_layernorm(sonic_engine* e, const float* x, const float
     HIPC(e, hipSetDevice(e->device));
     if (d % 8 || d > 2048) return fail(e, SONIC_ERR_INVALID, "d must be a multiple of 8 and <= 2048");
     TmpBuf tb(e->st);
-    bf16_t* dx = up_bf16(e, tb, x, (size_t)rows * d); float* dw = up_f32(tb, w, d); float* db = b ? up_f32(tb, b, d) : nullptr;
+    bf16_t* dx = up_bf16(e, tb, x, (size_t)rows * d); float* dw = up_f32(e, tb, w, d); float* db = b ? up_f32(e, tb, b, d) : nullptr;
     bf16_t* dy = tb.get<bf16_t>((size_t)rows * d);
     if (!dx || !dw || !dy) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     if (rms) launch_rmsnorm(dx, dw, dy, rows, d, eps, nullptr, e->st);
@@ -1118,18 +1135,26 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
     bf16_t* dA = tb.get<bf16_t>((size_t)M * K + 1024); bf16_t* dW = tb.get<bf16_t>((size_t)N * K); bf16_t* dC = tb.get<bf16_t>((size_t)M * Nout);
     float* db = tb.get<float>(N);
-    if (!dA || !dW || !dC || !db) return fail(e, SONIC_ERR_OOM, "HIP out of memory in gemm bench");
+    bf16_t* dVt = nullptr;
+    GemmArgs a{};
+    if (epi == EPI_QKV_VT) {   // encoder QKV shape: last third of the columns is V, written transposed per 1500-frame segment
+        if (N % 3 || M % 1500) return fail(e, SONIC_ERR_INVALID, "QKV bench needs N % 3 == 0 and M % 1500 == 0");
+        dVt = tb.get<bf16_t>((size_t)(M / 1500) * (N / 3) * 1536);
+        a.Vt = dVt; a.n_split = 2 * N / 3; a.seg_T = 1500; a.vt_ld = 1536; a.vt_seg_stride = (long)(N / 3) * 1536;
+    }
+    if (!dA || !dW || !dC || !db || (epi == EPI_QKV_VT && !dVt)) return fail(e, SONIC_ERR_OOM, "HIP out of memory in gemm bench");
     // random (not zero) operands: zero data reads high on this chip (cdna_hip_programming.md rule 25)
     launch_synth_fill(0x1234, (long)M * K, 1.0f, 0.f, dA, nullptr, e->st);
     launch_synth_fill(0x5678, (long)N * K, 0.05f, 0.f, dW, nullptr, e->st);
-    for (int i = 0; i < 2; ++i) gemm(e, epi, dA, K, dW, db, dC, Nout, M, N, K, dC, Nout);
-    hipEvent_t a, b; HIPC(e, hipEventCreate(&a)); HIPC(e, hipEventCreate(&b));
-    (void)hipEventRecord(a, e->st);
-    for (int i = 0; i < iters; ++i) gemm(e, epi, dA, K, dW, db, dC, Nout, M, N, K, dC, Nout);
-    (void)hipEventRecord(b, e->st);
+    a.A = dA; a.lda = K; a.W = dW; a.C = dC; a.ldc = (epi == EPI_QKV_VT) ? 2 * N / 3 : Nout; a.bias = db; a.R = dC; a.ldr = Nout; a.M = M; a.N = N; a.K = K; a.batch = 1;
+    for (int i = 0; i < 2; ++i) launch_gemm(a, epi, e->st);
+    hipEvent_t ea, eb; HIPC(e, hipEventCreate(&ea)); HIPC(e, hipEventCreate(&eb));
+    (void)hipEventRecord(ea, e->st);
+    for (int i = 0; i < iters; ++i) launch_gemm(a, epi, e->st);
+    (void)hipEventRecord(eb, e->st);
     hipError_t r = hipStreamSynchronize(e->st);
-    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     HIPC(e, r); HIPC(e, hipGetLastError());
     *ms_per_launch = ms / iters;
     return SONIC_OK;
@@ -1170,5 +1195,28 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     std::lock_guard<std::mutex> lk(e->mu);
     if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "gemm_force128")) { set_gemm_force128(value); return SONIC_OK; }
+    if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
+    if (!strcmp(key, "gemm256_stagger")) { set_gemm256_stagger(value); return SONIC_OK; }
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
+}
+
+// Debug read-back of an internal activation buffer as fp32 (tests / diagnostics only).
+extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n) {
+    if (!e || !name || !out) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    const sonic_dims& d = e->d;
+    const bf16_t* src = nullptr; size_t cap = 0;
+    if (!strcmp(name, "prefill_tap")) { if (!e->taps) return fail(e, SONIC_ERR_INVALID, "no taps recorded"); src = e->taps + (size_t)index * e->tok_cap * d.dec_d; cap = (size_t)e->tok_cap * d.dec_d; }
+    else if (!strcmp(name, "pe")) { src = e->pe; cap = (size_t)e->Bm * e->Ta * d.dec_d; }
+    else if (!strcmp(name, "dx")) { src = e->dx; cap = (size_t)e->tok_cap * d.dec_d; }
+    else if (!strcmp(name, "dqkv")) { src = e->dqkv; cap = (size_t)e->tok_cap * e->qkvN; }
+    else if (!strcmp(name, "dq")) { src = e->dq; cap = (size_t)e->tok_cap * e->QD; }
+    else if (!strcmp(name, "datt")) { src = e->datt; cap = (size_t)e->tok_cap * e->QD; }
+    else if (!strcmp(name, "dact")) { src = e->dact; cap = (size_t)e->tok_cap * d.dec_ff; }
+    else if (!strcmp(name, "enc_x")) { src = e->ln; cap = (size_t)e->Bm * e->T * d.enc_d; }
+    else return fail(e, SONIC_ERR_INVALID, "unknown buffer %s", name);
+    if (n < 0 || (size_t)n > cap) return fail(e, SONIC_ERR_INVALID, "read of %lld elements exceeds buffer %s", (long long)n, name);
+    TmpBuf tb(e->st);
+    return down_bf16(e, tb, src, out, (size_t)n);
 }

@@ -1,7 +1,7 @@
 // gemm256_kernel: 256x256x64 block tile, 8 waves (2 along M x 4 along N), each wave a 128x64 output as 8x4
 // v_mfma_f32_16x16x32_bf16 accumulators; the large-shape path of launch_gemm (encoder / projector / prefill linears).
 //
-// Pipeline (one K tile = 4 phases, one raw s_barrier per phase, no vmcnt(0) in the main loop):
+// Pipeline (STAGGER = false: one K tile = 4 phases, one raw s_barrier per phase, no vmcnt(0) in the main loop):
 //   * the block tile of each operand is cut into two "half-tiles" of 128 rows (16 KiB): A0/A1 hold the first/second 64 rows
 //     of each wave-row's 128 rows, B0/B1 the first/second 32 rows of each wave-column's 64 rows, so phase p of every wave
 //     computes one 64x32 quadrant of its output from one A half and one B half:
@@ -13,6 +13,14 @@
 //   * a phase waits only for the half-tile(s) it is about to read with a COUNTED s_waitcnt vmcnt(N) (12 / 10 / 12 in steady
 //     state: the number of younger DMA instructions this wave has issued), then the barrier makes the other waves' pieces
 //     visible (LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt + a barrier the reader has passed).
+// STAGGER = true (default): the two waves that share a SIMD (w and w+4) run half a phase apart -- waves 0-3 read a
+// phase's fragments while waves 4-7 issue the previous phase's MFMAs and vice versa -- so LDS reads overlap the
+// partner's matrix work instead of both waves of a SIMD reading, then both computing.  7 barriers per K tile:
+//     slot   0      1      2      3      4      5      6
+//     w0-3   R0     M0     R1     M1     R2     M2     M3          R0: A0,B0 frags  R1: B1  R2: A1
+//     w4-7   M3'    R0     M0     R1     M1     R2     M2          Mi: 16 MFMA of quadrant i (M3' = previous K tile's)
+//     DMA                  A0,B0         B1            A1           (refill for K tile t+2, after the last reader's barrier)
+//     wait          D1            D2                   D0(t+1)      (counted vmcnt 10 / 12 / 12, identical for all waves)
 // Swizzle, MFMA operand roles and epilogues are those of gemm_kernel (gemm.hip).
 #include <type_traits>
 
@@ -22,6 +30,7 @@
 #define TBK 64
 #define HT_BYTES (128 * TBK * 2)            // one half-tile: 128 rows x 128 B
 #define TILE_BYTES (4 * HT_BYTES)           // A0 A1 B0 B1
+#define LDS256_BYTES (256 * 528)            // >= 2 * TILE_BYTES; also holds the staged output tile of the epilogue
 #define SLOT_A0 0
 #define SLOT_A1 1
 #define SLOT_B0 2
@@ -32,7 +41,7 @@
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI>
+template <int EPI, bool STAGGER>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x TILE_BYTES, the only LDS object of the kernel
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,7 +117,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             for (int kk = 0; kk < 2; ++kk) b[ni][kk] = *(const bf16x8*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
         }
     };
-    auto quad = [&](int mh, int nh, const bf16x8 (&b)[2][2]) {
+    // vt (compile-time): transposed MFMA roles for the V tiles of the fused QKV GEMM; hoisted out of the K loop
+    auto quad = [&](auto vt, int mh, int nh, const bf16x8 (&b)[2][2]) {
+        constexpr bool VT = decltype(vt)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -116,13 +127,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    if (vtile) acc[nh * 2 + ni][mh * 4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], b[ni][kk], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
+                    if (VT) acc[nh * 2 + ni][mh * 4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], b[ni][kk], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
                     else acc[nh * 2 + ni][mh * 4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][kk], af[mi][kk], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
                 }
         __builtin_amdgcn_s_setprio(0);
     };
     // one K tile.  W0/W1/W2: vmcnt counts of ph0/ph1/ph2; ISSUE: refill this buffer with K tile kt+2
-    auto ktile = [&](int kt, auto w0, auto w1, auto w2, auto issue) {
+    auto ktile = [&](auto vt, int kt, auto w0, auto w1, auto w2, auto issue) {
         constexpr int W0 = decltype(w0)::value, W1 = decltype(w1)::value, W2 = decltype(w2)::value;
         constexpr bool ISSUE = decltype(issue)::value;
         const int buf = kt & 1, kn = (kt + 2) * TBK;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         read_b(buf, 0, b0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        quad(0, 0, b0);
+        quad(vt, 0, 0, b0);
         // ph1
         wait_vm<W1>();
         BARRIER();
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         read_b(buf, 1, b1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        quad(0, 1, b1);
+        quad(vt, 0, 1, b1);
         // ph2
         wait_vm<W2>();
         BARRIER();
@@ -149,11 +160,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         read_a(buf, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        quad(1, 1, b1);
+        quad(vt, 1, 1, b1);
         // ph3
         BARRIER();
         if (ISSUE) dma(srcA[1], kn, buf, SLOT_A1);
-        quad(1, 0, b0);
+        quad(vt, 1, 0, b0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I2 = std::integral_constant<int, 2>;
@@ -172,28 +183,89 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         dma(srcB[1], t * TBK, t, SLOT_B1);
         dma(srcA[1], t * TBK, t, SLOT_A1);
     }
-    int kt = 0;
-    for (; kt < nk - 2; ++kt) ktile(kt, I12{}, I10{}, I12{}, Yes{});
-    ktile(kt, I12{}, I10{}, I8{}, No{});      // K tile nk-2: nothing younger than tile nk-1's 8 DMA instructions
-    ++kt;
-    ktile(kt, I4{}, I2{}, I0{}, No{});        // K tile nk-1
+    if (!STAGGER) {
+        auto run0 = [&](auto vt) {
+            int kt = 0;
+            for (; kt < nk - 2; ++kt) ktile(vt, kt, I12{}, I10{}, I12{}, Yes{});
+            ktile(vt, kt, I12{}, I10{}, I8{}, No{});      // K tile nk-2: nothing younger than tile nk-1's 8 DMA instructions
+            ++kt;
+            ktile(vt, kt, I4{}, I2{}, I0{}, No{});        // K tile nk-1
+        };
+        if (EPI == EPI_QKV_VT && vtile) run0(Yes{}); else run0(No{});
+    } else {
+        auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+        // one K tile of one wave group (G0 = true: waves 0-3).  The two groups run separate straight-line loops (the branch
+        // on the group is hoisted out of the K loop) with the same barrier / DMA / vmcnt sequence.
+        // w1 / w2 / w0n: vmcnt before the barriers that open slots 2 / 4 / next tile's 0; first: no M3' yet
+        auto stile = [&](auto grp, auto vt, int kt, auto w1, auto w2, auto w0n, auto issue, bool first) {
+            constexpr bool G0 = decltype(grp)::value;
+            constexpr int W1 = decltype(w1)::value, W2 = decltype(w2)::value, W0N = decltype(w0n)::value;
+            constexpr bool ISSUE = decltype(issue)::value;
+            const int buf = kt & 1, kn = (kt + 2) * TBK;
+            BARRIER();                                                                   // slot 0
+            if (G0) { read_a(buf, 0); read_b(buf, 0, b0); lgkm0(); } else if (!first) quad(vt, 1, 0, b0);
+            BARRIER();                                                                   // slot 1
+            if (G0) quad(vt, 0, 0, b0); else { read_a(buf, 0); read_b(buf, 0, b0); lgkm0(); }
+            wait_vm<W1>();
+            BARRIER();                                                                   // slot 2
+            if (ISSUE) { dma(srcA[0], kn, buf, SLOT_A0); dma(srcB[0], kn, buf, SLOT_B0); }
+            if (G0) { read_b(buf, 1, b1); lgkm0(); } else quad(vt, 0, 0, b0);
+            BARRIER();                                                                   // slot 3
+            if (G0) quad(vt, 0, 1, b1); else { read_b(buf, 1, b1); lgkm0(); }
+            wait_vm<W2>();
+            BARRIER();                                                                   // slot 4
+            if (ISSUE) dma(srcB[1], kn, buf, SLOT_B1);
+            if (G0) { read_a(buf, 1); lgkm0(); } else quad(vt, 0, 1, b1);
+            BARRIER();                                                                   // slot 5
+            if (G0) quad(vt, 1, 1, b1); else { read_a(buf, 1); lgkm0(); }
+            BARRIER();                                                                   // slot 6
+            if (ISSUE) dma(srcA[1], kn, buf, SLOT_A1);
+            if (G0) quad(vt, 1, 0, b0); else quad(vt, 1, 1, b1);
+            if (W0N >= 0) wait_vm<(W0N >= 0 ? W0N : 0)>();
+        };
+        using IM1 = std::integral_constant<int, -1>;
+        auto run = [&](auto grp, auto vt) {
+            wait_vm<12>();                                                               // D0(0) landed
+            int kt = 0;
+            for (; kt < nk - 2; ++kt) stile(grp, vt, kt, I10{}, I12{}, I12{}, Yes{}, kt == 0);
+            stile(grp, vt, kt, I10{}, I8{}, I4{}, No{}, false);
+            ++kt;
+            stile(grp, vt, kt, I2{}, I0{}, IM1{}, No{}, false);
+            if (!decltype(grp)::value) quad(vt, 1, 0, b0);                               // waves 4-7: last K tile's quadrant 3
+        };
+        if (EPI == EPI_QKV_VT && vtile) { if (wid < 4) run(Yes{}, Yes{}); else run(No{}, Yes{}); }
+        else { if (wid < 4) run(Yes{}, No{}); else run(No{}, No{}); }
+    }
 
-    // ---- epilogue (as gemm_kernel): acc[nb][mb][j] = D[n = n0 + wc*64 + nb*16 + fg*4 + j][m = m0 + wr*128 + mb*16 + fr]
+    // ---- epilogue.  acc[nb][mb][j] = D[n = n0 + wc*64 + nb*16 + fg*4 + j][m = m0 + wr*128 + mb*16 + fr].
+    // Per-lane stores of that layout are 8-byte pieces on 16 different lines per instruction (measured: ~18 us per tile,
+    // a third of the kernel at K = 1280).  Instead the bf16 tile is staged in LDS (free once the K loop is done) with the
+    // op's rounding sequence applied in registers, then written as full 512-byte rows, 16 B per lane; the residual is read
+    // with the same coalesced pattern in that final pass.
+    __syncthreads();
+    constexpr int CLD = 528;                     // staged row pitch in bytes (256 bf16 + 16 B skew)
     if (vtile) {
+        // staged transposed: row = n (256), columns = m; V^T[seg][n - n_split][t .. t+3] leaves in 8-byte pieces (T % 4 == 0)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int n = n0 + wc * 64 + nb * 16 + fr;
+            const int nl = wc * 64 + nb * 16 + fr, n = n0 + nl;
             const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
-                const int m = m0 + wr * 128 + mb * 16 + fg * 4;
-                if (m < a.M && n < a.N) {
-                    const int seg = m / a.seg_T, t = m - seg * a.seg_T;
-                    bf16x4 o;
+                bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[nb][mb][j] + bv);
-                    *(bf16x4*)(a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
-                }
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[nb][mb][j] + bv);
+                *(bf16x4*)(smem + nl * CLD + (wr * 128 + mb * 16 + fg * 4) * 2) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int c = it * 512 + tid, nl = c >> 6, mc = c & 63;
+            const int m = m0 + mc * 4, n = n0 + nl;
+            if (m < a.M && n < a.N) {
+                const int seg = m / a.seg_T, t = m - seg * a.seg_T;
+                *(bf16x4*)(a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = *(const bf16x4*)(smem + nl * CLD + mc * 8);
             }
         }
         return;
@@ -201,63 +273,83 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int oc = ((n0 + wc * 64) >> 1) + q * 16 + fg * 4;
+            const int ol = wc * 32 + q * 16 + fg * 4;           // column in the 128-wide activated tile
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
-                const int m = m0 + wr * 128 + mb * 16 + fr;
-                if (m < a.M && (n0 + wc * 64 + q * 32) < a.N) {
-                    bf16x4 o;
+                bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float g = rbf(acc[2 * q][mb][j]), u = rbf(acc[2 * q + 1][mb][j]);
-                        o[j] = f2bf(rbf(silu_f(g)) * u);
-                    }
-                    *(bf16x4*)(C + (long)m * a.ldc + oc) = o;
+                for (int j = 0; j < 4; ++j) {
+                    const float g = rbf(acc[2 * q][mb][j]), u = rbf(acc[2 * q + 1][mb][j]);
+                    o[j] = f2bf(rbf(silu_f(g)) * u);
                 }
+                *(bf16x4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + ol * 2) = o;
             }
+        }
+        __syncthreads();
+        const int No = a.N >> 1, o0 = n0 >> 1;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 512 + tid, row = c >> 4, ch = c & 15;
+            const int m = m0 + row, oc = o0 + ch * 8;
+            if (m < a.M && oc < No) *(bf16x8*)(C + (long)m * a.ldc + oc) = *(const bf16x8*)(smem + row * CLD + ch * 16);
         }
         return;
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        const int n = n0 + wc * 64 + nb * 16 + fg * 4;
-        if (n >= a.N) continue;
+        const int nl = wc * 64 + nb * 16 + fg * 4, n = n0 + nl;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
+        if (a.bias && n < a.N) {
             const f32x4 b4 = *(const f32x4*)(a.bias + n);
             bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
         }
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
-            const int m = m0 + wr * 128 + mb * 16 + fr;
-            if (m >= a.M) continue;
             bf16x4 o;
-            if (EPI == EPI_BIAS_RESID) {
-                const bf16x4 rv = *(const bf16x4*)(R + (long)m * a.ldr + n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(rbf(acc[nb][mb][j] + bv[j]) + bf2f(rv[j]));
-            } else if (EPI == EPI_BIAS_GELU) {
+            if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(gelu_erf(rbf(acc[nb][mb][j] + bv[j])));
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[nb][mb][j] + bv[j]);
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[nb][mb][j] + bv[j]);   // RESID: the linear's own bf16 output; R is added below
             }
-            *(bf16x4*)(C + (long)m * a.ldc + n) = o;
+            *(bf16x4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int c = it * 512 + tid, row = c >> 5, ch = c & 31;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m < a.M && n < a.N) {
+            bf16x8 v = *(const bf16x8*)(smem + row * CLD + ch * 16);
+            if (EPI == EPI_BIAS_RESID) {
+                const bf16x8 rv = *(const bf16x8*)(R + (long)m * a.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(rv[j]));
+            }
+            *(bf16x8*)(C + (long)m * a.ldc + n) = v;
         }
     }
 }
 
-template <int EPI> static void launch256(const GemmArgs& a, hipStream_t s) {
+int g_gemm256_stagger = 1;
+void set_gemm256_stagger(int v) { g_gemm256_stagger = v; }
+
+template <int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES); attr = true; }
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), 2 * TILE_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS256_BYTES, s, a);
+}
+template <int EPI> static void launch256(const GemmArgs& a, hipStream_t s) {
+    if (g_gemm256_stagger) launch256v<EPI, true>(a, s); else launch256v<EPI, false>(a, s);
 }
 
 bool gemm256_eligible(const GemmArgs& a, int epi) {
     if (a.K % TBK || a.K / TBK < 4) return false;
     if (a.M < 512 || a.N < 256) return false;
+    if (a.N % 16 || a.ldc % 8 || (epi == EPI_BIAS_RESID && a.ldr % 8)) return false;   // 16-byte row pieces in the staged epilogue
     if (epi == EPI_QKV_VT && (a.n_split % T256)) return false;
     return true;
 }

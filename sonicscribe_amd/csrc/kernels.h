@@ -76,6 +76,7 @@ void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const f
 void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s);
 void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s);
 void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d, hipStream_t s);
+void launch_fill_i32(int* p, int value, int n, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
 void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s);
 void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s);

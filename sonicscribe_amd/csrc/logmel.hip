@@ -137,7 +137,7 @@ __global__ void logmel_finalize_kernel(const float* logspec, const int* segmax, 
 
 void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev, int max_samples, const LogmelConst& lc,
                    float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s) {
-    (void)hipMemsetAsync(segmax, 0x80, sizeof(int) * B, s);
+    launch_fill_i32(segmax, (int)0x80808080, B, s);   // ordered-int encoding of a very negative float
     const int n_pad = n_frames * LM_HOP;
     const int n = max_samples < n_pad ? max_samples : n_pad;
     int t_live = (n + LM_NFFT / 2 + LM_HOP - 1) / LM_HOP; if (t_live > n_frames) t_live = n_frames;

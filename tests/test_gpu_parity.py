@@ -252,7 +252,37 @@ def test_transcribe_vs_golden(eng, golden_dir):
         assert np.array_equal(ids[si][:n_safe], ref_ids[:n_safe]), (ids[si], ref_ids)
         same = int(np.argmin(ids[si][: len(ref_ids)] == ref_ids)) if not np.array_equal(ids[si][: len(ref_ids)], ref_ids) else len(ref_ids)
         for s in range(min(same + 1, len(ref_ids))):   # logits are comparable while the generated prefix is identical
-            np.testing.assert_allclose(logits[s, si], ref_logits[s], atol=tol, rtol=0)
+            dmax = float(np.abs(logits[s, si] - ref_logits[s]).max())
+            if dmax > tol:   # diagnostics for a rare flake seen on some boxes
+                from oracle import oracle as _orc
+                allsteps = np.abs(logits[: len(ref_ids), si] - ref_logits).max(axis=1)
+                ids2, logits2 = eng.transcribe_batch(segs, prompts, [n_new, n_new], want_logits=True)
+                rerun = float(np.abs(logits2 - logits).max())
+                rerun_ok = float(np.abs(logits2[: len(ref_ids), si] - ref_logits).max())
+                fgpu, _ = eng.logmel(segs)
+                fref = [_orc.logmel(x)[0] for x in segs]
+                dmel = [float(np.abs(fgpu[i] - fref[i]).max()) for i in range(2)]
+                emb, n_a, _, _ = eng.encode(np.stack(fref), [500, 2000])
+                demb = [float(np.abs(emb[i, : n_a[i]] - g[f"s{i}_audio_embeds"]).max()) for i in range(2)]
+                # localise inside the decoder prefill: hidden states after the embedding merge and after each layer vs the oracle
+                om = _orc.Model(spec.TINY, synth.synth_state_dict(spec.TINY, 20260128, bf16=True), bf16=True)
+                eng.set_option("prefill_taps", 1)
+                ids3, logits3 = eng.transcribe_batch(segs, prompts, [n_new, n_new], want_logits=True)
+                eng.set_option("prefill_taps", 0)
+                P0 = len(prompts[0]); P1 = len(prompts[1]); dd = spec.TINY.dec_d
+                r0 = om.transcribe(fref[0], 500, prompts[0], 1, want=("dec_layers",))
+                tapinfo = []
+                for li in range(spec.TINY.dec_layers + 1):
+                    tp = eng.debug_read("prefill_tap", (P0 + P1, dd), li)
+                    if li == 0:
+                        tapinfo.append(("emb", float(np.abs(tp[:P0]).max()), float(np.abs(tp[4:4 + n_a[0]] - g["s0_audio_embeds"]).max())))
+                    else:
+                        e0 = np.abs(tp[:P0] - r0["dec_layers"][li - 1])
+                        tapinfo.append((f"L{li - 1}", float(e0.max()), int(np.argmax(e0.max(axis=1))), np.round(e0.max(axis=1)[:8], 3).tolist()))
+                emb1, n_a1, _, _ = eng.encode(fref[0][None], [500])
+                demb1 = float(np.abs(emb1[0, : n_a1[0]] - g["s0_audio_embeds"]).max())
+                raise AssertionError(f"seg {si} step {s}: max|dlogit| {dmax:.4f} > {tol}; per-step {np.round(allsteps[:6], 3).tolist()}; rerun-vs-first {rerun:.4f}, "
+                                     f"rerun-vs-golden {rerun_ok:.4f}; logmel diff per seg {dmel}; embeds(B=2) diff {demb}; embeds(B=1, seg0) diff {demb1:.4f}; taps {tapinfo}; taps-run-vs-first {float(np.abs(logits3 - logits).max()):.4f}")
 
 
 def test_batch_matches_single_and_graph_matches_eager(eng, golden_dir):
