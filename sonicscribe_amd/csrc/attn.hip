@@ -212,26 +212,42 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 // ------------------------------------------------------------------------------------------------
 
 // HD = 128, group size G = Hq/Hkv <= 4.  One block (8 waves) per (sequence, kv head).
+//  0. the first 16-key slice of K and V of every wave is requested before anything else (addresses do not depend on kv_len:
+//     rows are clamped to the cache and masked later), so its HBM latency overlaps the prologue;
 //  1. prologue (fused RoPE + KV append, modeling_llama.py:121-143,261-262): sums the QKV skinny-GEMM slabs of this
 //     (sequence, kv head), rounds to bf16, applies rotate-half RoPE at the token's position, writes the new K / V rows
 //     into the cache and keeps q (4 heads), k, v in LDS;
-//  2. single pass over the cached keys with a per-wave online softmax: a wave-iteration covers 4 x 4 keys of K and V
-//     (8 KiB per wave, next iteration's rows prefetched into registers before the current one is consumed), lane
-//     (sub = lane>>4, ch = lane&15) owns key `sub` of each 4-key group and head-dim chunk `ch`;
+//  2. single pass over the cached keys, 16 keys per wave-iteration (next slice prefetched into registers):
+//     scores S^T[key][head] = K.q^T with 4 v_mfma_f32_16x16x32_bf16 (a K row piece per lane IS the A fragment; the q heads sit
+//     on 4 of the 16 B columns), per-wave online softmax, probabilities handed to the lanes that own the V pieces through a
+//     256-byte per-wave LDS record, P.V on the VALU (V is row-major in the cache);
 //  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
 // Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
 __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
-    constexpr int HD = 128, HALF = 64, GMAX = 4, U = 4, NW = 8;
+    constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
     __shared__ float s_acc[NW][GMAX][HD];
     __shared__ float s_m[NW][GMAX], s_l[NW][GMAX];
-    __shared__ float s_q[GMAX + 2][HD];     // q heads (scaled), then k, v of the new token
+    __shared__ float s_q[GMAX + 2][HD];                            // q heads (unscaled), then k, v of the new token
+    __shared__ __attribute__((aligned(16))) float s_p[NW][16][4];  // per wave: probabilities [key in slice][head]
+    __shared__ __attribute__((aligned(16))) float s_mn[NW][4];     // per wave: new running max per head
     const int G = a.Hq / a.Hkv;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;                        // MFMA: A row / k-chunk;  V pieces: hd chunk r of key 4u + g
     const int b = blockIdx.x, kvh = blockIdx.y;
-    const int n = a.kv_len[b];              // keys visible, the new token included at position n-1
-    const int sub = lane >> 4, ch = lane & 15;
     bf16_t* Kc = a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
     bf16_t* Vc = a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    const int cm1 = a.ctx_max - 1;
+
+    bf16x8 kf[4], vv[4], kfn[4], vvn[4];
+    auto load = [&](int k0, bf16x8 (&kd)[4], bf16x8 (&vd)[4]) {
+        const int kr = min(k0 + r, cm1);
+#pragma unroll
+        for (int hs = 0; hs < 4; ++hs) kd[hs] = *(const bf16x8*)(Kc + (long)kr * HD + hs * 32 + g * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vd[u] = *(const bf16x8*)(Vc + (long)min(k0 + 4 * u + g, cm1) * HD + r * 8);
+    };
+    load(wid * 16, kf, vv);
+    const int n = a.kv_len[b];              // keys visible, the new token included at position n-1
 
     if (a.P) {
         const int N = (a.Hq + 2 * a.Hkv) * HD, pos = n - 1;
@@ -250,124 +266,116 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
                 o1 = rbf(rbf(x1 * c) + rbf(-x2 * sn));
                 o2 = rbf(rbf(x2 * c) + rbf(x1 * sn));
             }
-            const float sc = vi < G ? a.scale : 1.0f;
-            s_q[vi < G ? vi : (vi == G ? GMAX : GMAX + 1)][i] = o1 * sc;
-            s_q[vi < G ? vi : (vi == G ? GMAX : GMAX + 1)][HALF + i] = o2 * sc;
+            const int row = vi < G ? vi : (vi == G ? GMAX : GMAX + 1);
+            s_q[row][i] = o1; s_q[row][HALF + i] = o2;
             if (vi == G) { Kc[(long)pos * HD + i] = f2bf(o1); Kc[(long)pos * HD + HALF + i] = f2bf(o2); }
             if (vi == G + 1) { Vc[(long)pos * HD + i] = f2bf(o1); Vc[(long)pos * HD + HALF + i] = f2bf(o2); }
         }
         __syncthreads();
     }
-    float q[GMAX][8];
+    // q as the MFMA B operand: column r = head (zero beyond the group), k = head-dim
+    bf16x8 qf[4];
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
+    for (int hs = 0; hs < 4; ++hs) {
         if (a.P) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[g][i] = s_q[g < G ? g : 0][ch * 8 + i];
+            for (int j = 0; j < 8; ++j) qf[hs][j] = f2bf(r < G ? s_q[r < G ? r : 0][hs * 32 + g * 8 + j] : 0.f);
         } else {
-            const int hq = kvh * G + (g < G ? g : 0);
-            const bf16x8 v = *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + hq * HD + ch * 8);
+            const bf16x8 t = *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + (kvh * G + (r < G ? r : 0)) * HD + hs * 32 + g * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[g][i] = bf2f(v[i]) * a.scale;
+            for (int j = 0; j < 8; ++j) qf[hs][j] = r < G ? t[j] : f2bf(0.f);
         }
     }
-    float m[GMAX], l[GMAX], acc[GMAX][8];
+    float m[GMAX], lsum = 0.f, acc[GMAX][8];
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-        m[g] = -1e30f; l[g] = 0.f;
+    for (int h = 0; h < GMAX; ++h) {
+        m[h] = -1e30f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
+        for (int i = 0; i < 8; ++i) acc[h][i] = 0.f;
     }
-    const int nc = a.P ? n - 1 : n;          // keys read from the cache
-    const bf16_t* Kr = Kc + ch * 8;
-    const bf16_t* Vr = Vc + ch * 8;
-    bf16x8 kv[U], vv[U], kn[U], vn[U];
-    auto load = [&](int k0, bf16x8 (&kd)[U], bf16x8 (&vd)[U]) {
+    auto step = [&](int k0, const bf16x8 (&kd)[4], const bf16x8 (&vd)[4], int limit) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int key = k0 + u * 4 + sub; key = key < nc ? key : (nc > 0 ? nc - 1 : 0);
-            kd[u] = *(const bf16x8*)(Kr + (long)key * HD);
-            vd[u] = *(const bf16x8*)(Vr + (long)key * HD);
+        for (int hs = 0; hs < 4; ++hs) st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kd[hs], qf[hs], st, 0, 0, 0);
+        float sc[4], mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = (k0 + g * 4 + j) < limit ? st[j] * a.scale : -1e30f; mx = fmaxf(mx, sc[j]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_r = r == 0 ? m[0] : r == 1 ? m[1] : r == 2 ? m[2] : m[3];
+        const float mn = fmaxf(m_r, mx);
+        float ps = 0.f, pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float pv = (k0 + g * 4 + j) < limit ? __expf(sc[j] - mn) : 0.f; ps += pv; pr[j] = rbf(pv); }
+        lsum = lsum * __expf(m_r - mn) + ps;
+        if (r < 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_p[wid][g * 4 + j][r] = pr[j];
+            if (g == 0) s_mn[wid][r] = mn;
         }
-    };
-    auto consume = [&](int k0, const bf16x8 (&kd)[U], const bf16x8 (&vd)[U], int limit) {
-        float sc[U][GMAX];
-        bool ok[U];
+        __builtin_amdgcn_wave_barrier();           // same-wave LDS traffic is in order; this only pins the compiler's schedule
+        const f32x4 mn4 = *(const f32x4*)s_mn[wid];
+        f32x4 pk[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ok[u] = (k0 + u * 4 + sub) < limit;
+        for (int u = 0; u < 4; ++u) pk[u] = *(const f32x4*)s_p[wid][4 * u + g];
 #pragma unroll
-            for (int g = 0; g < GMAX; ++g) {
-                float d = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) d += q[g][i] * bf2f(kd[u][i]);
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-                sc[u][g] = ok[u] ? d : -1e30f;
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            float mx = fmaxf(fmaxf(sc[0][g], sc[1][g]), fmaxf(sc[2][g], sc[3][g]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m[g], mx);
-            const float alpha = __expf(m[g] - mn);
-            m[g] = mn;
-            float ps = 0.f, pr[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const float p = ok[u] ? __expf(sc[u][g] - mn) : 0.f; ps += p; pr[u] = rbf(p); }
-            l[g] = l[g] * alpha + ps;
+        for (int h = 0; h < GMAX; ++h) {
+            const float alpha = __expf(m[h] - mn4[h]);
+            m[h] = mn4[h];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float t = acc[g][i] * alpha;
+                float t = acc[h][i] * alpha;
 #pragma unroll
-                for (int u = 0; u < U; ++u) t += pr[u] * bf2f(vd[u][i]);
-                acc[g][i] = t;
+                for (int u = 0; u < 4; ++u) t += pk[u][h] * bf2f(vd[u][i]);
+                acc[h][i] = t;
             }
         }
+        __builtin_amdgcn_wave_barrier();
     };
-    const int stride = NW * 4 * U;
-    int k0 = wid * (4 * U);
-    if (k0 < nc) load(k0, kv, vv);
-    for (; k0 < nc; k0 += stride) {
-        const bool more = k0 + stride < nc;
-        if (more) load(k0 + stride, kn, vn);
-        consume(k0, kv, vv, nc);
+    const int nc = a.P ? n - 1 : n;          // keys read from the cache
+    for (int k0 = wid * 16; k0 < nc; k0 += NW * 16) {
+        const bool more = k0 + NW * 16 < nc;
+        if (more) load(k0 + NW * 16, kfn, vvn);
+        step(k0, kf, vv, nc);
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) { kv[u] = kn[u]; vv[u] = vn[u]; }
+            for (int u = 0; u < 4; ++u) { kf[u] = kfn[u]; vv[u] = vvn[u]; }
         }
     }
-    if (a.P && wid == 0) {                   // the token being decoded: its k / v are still in LDS
+    if (a.P && wid == 0) {                   // the token being decoded: its k / v are still in LDS (slice key 0 only)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int hs = 0; hs < 4; ++hs)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { kv[u][i] = f2bf(s_q[GMAX][ch * 8 + i]); vv[u][i] = f2bf(s_q[GMAX + 1][ch * 8 + i]); }
-        consume(0, kv, vv, 1);                // only (u = 0, sub = 0) is in range
+            for (int j = 0; j < 8; ++j) kf[hs][j] = f2bf(s_q[GMAX][hs * 32 + g * 8 + j]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vv[u][i] = f2bf(s_q[GMAX + 1][r * 8 + i]);
+        step(0, kf, vv, 1);
     }
-    // merge the 4 key sub-groups of the wave, then the 8 waves
+    // merge: per wave the row sums over the 4 key quarters, the outputs over the 4 V-owner groups; then the 8 waves
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (g == 0 && r < 4) s_l[wid][r] = lsum;
+    if (lane == 0) { s_m[wid][0] = m[0]; s_m[wid][1] = m[1]; s_m[wid][2] = m[2]; s_m[wid][3] = m[3]; }
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-        float lv = l[g];
-        lv += __shfl_xor(lv, 16, 64); lv += __shfl_xor(lv, 32, 64);
+    for (int h = 0; h < GMAX; ++h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float v = acc[g][i];
+            float v = acc[h][i];
             v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (sub == 0) s_acc[wid][g][ch * 8 + i] = v;
+            if (g == 0) s_acc[wid][h][r * 8 + i] = v;
         }
-        if (lane == 0) { s_m[wid][g] = m[g]; s_l[wid][g] = lv; }
-    }
     __syncthreads();
     for (int idx = tid; idx < G * HD; idx += 512) {
-        const int g = idx / HD, e = idx % HD;
+        const int h = idx / HD, e = idx % HD;
         float M = -1e30f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][g]);
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][h]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][g] - M); num += f * s_acc[w][g][e]; den += f * s_l[w][g]; }
-        a.O[(long)b * a.Hq * HD + (kvh * G + g) * HD + e] = f2bf(num / den);
+        for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][h] - M); num += f * s_acc[w][h][e]; den += f * s_l[w][h]; }
+        a.O[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = f2bf(num / den);
     }
 }
 

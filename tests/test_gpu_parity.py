@@ -395,3 +395,20 @@ def test_fullwidth_layer_vs_oracle(orc):
         if margin > 12 * 2.0 ** -6:
             assert ids[i][0] == r["new_ids"][0]
     e.close()
+
+
+def test_checkpoint_loader_equals_synthetic(tmp_path):
+    """ASRModel(checkpoint_dir): config.json + bf16 safetensors in the on-disk HF layout -> same tokens as the device-side generator."""
+    from sonicscribe_amd import weights
+    from sonicscribe_amd.asr import ASRModel
+    seed = 11
+    weights.save_synthetic_checkpoint(str(tmp_path), spec.TINY, seed)
+    m1 = ASRModel(str(tmp_path), device="cuda", mode="native", max_batch=2, max_ctx=512)
+    m2 = ASRModel.from_synthetic(spec.TINY, seed=seed, max_batch=2, max_ctx=512)
+    assert m1.dims == spec.TINY
+    wav = synth.synth_pcm(70, 80000).astype(np.float32) / 32768.0
+    t1 = m1.transcribe(wav[None], 16000, max_new_tokens=10)
+    t2 = m2.transcribe(wav[None], 16000, max_new_tokens=10)
+    assert t1 == t2 and len(t1.split()) == 10
+    assert m1.transcribe_batch([wav, wav[:40000]], max_new_tokens=[4, 6])[0] == " ".join(t1.split()[:4])
+    m1.close(); m2.close()
