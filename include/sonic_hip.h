@@ -109,6 +109,7 @@ int sonic_synchronize(sonic_engine* e);
 int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float* bias, const float* resid, float* C,
                     int M, int N, int K, int epi);
 int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K);
+int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K);
 int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
                          int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal);
 int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,

@@ -646,8 +646,13 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         launch_decode_attn(da, R, e->st);
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st);
-        skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
-        launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st);
+        if (skinny_gu_eligible(R, 2 * d.dec_ff, D)) {          // gate/up + SwiGLU in one kernel, no slabs
+            SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
+            launch_skinny_gu(ga, e->sact, e->st);
+        } else {
+            skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
+            launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st);
+        }
         skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks);
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st);
@@ -1195,6 +1200,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     std::lock_guard<std::mutex> lk(e->mu);
     if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "gemm_force128")) { set_gemm_force128(value); return SONIC_OK; }
+    if (!strcmp(key, "no_fused_gu")) { set_skinny_no_fused_gu(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { set_gemm256_stagger(value); return SONIC_OK; }
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
@@ -1219,4 +1225,19 @@ extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, fl
     if (n < 0 || (size_t)n > cap) return fail(e, SONIC_ERR_INVALID, "read of %lld elements exceeds buffer %s", (long long)n, name);
     TmpBuf tb(e->st);
     return down_bf16(e, tb, src, out, (size_t)n);
+}
+
+extern "C" int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPC(e, hipSetDevice(e->device));
+    if (!skinny_gu_eligible(M, N, K)) return fail(e, SONIC_ERR_INVALID, "shape not handled by the fused gate/up kernel");
+    TmpBuf tb(e->st);
+    bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, Wgu_interleaved, (size_t)N * K);
+    bf16_t* dWt = tb.get<bf16_t>((size_t)N * K); bf16_t* dA = tb.get<bf16_t>((size_t)M * (N / 2));
+    if (!dX || !dW || !dWt || !dA) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    launch_tile_weights(dW, dWt, N, K, e->st);
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.M = M; a.N = N; a.K = K; a.ksplit = 1;
+    launch_skinny_gu(a, dA, e->st);
+    return down_bf16(e, tb, dA, act, (size_t)M * (N / 2));
 }

@@ -332,6 +332,101 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     }
 }
 
+int g_skinny_no_fused_gu = 0;
+void set_skinny_no_fused_gu(int v) { g_skinny_no_fused_gu = v; }
+
+// skinny_gu_kernel: decode-step gate/up projection with SwiGLU fused (modeling_llama.py:163-176).  A block owns 32 output columns
+// = 64 interleaved weight rows (16 gate + 16 up, twice) over the WHOLE K, so no partial slabs leave the block: the full
+// activation matrix X [M <= 32][K] is DMA'd once into LDS (128 KiB at K = 2048), the 8 waves are 2 (column pairs) x 4 (K quarters),
+// each streams its gate and up tiles from the fragment-tiled weights straight to VGPRs, the K quarters are summed through LDS and
+// the epilogue writes act = bf16(bf16(silu(bf16 g)) * bf16 u) directly.  Replaces skinny GEMM (2 slabs) + swiglu_slab_kernel.
+template <int MB, int KSW>
+__global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* act, int ff) {
+    constexpr int K = KSW * 128, NKB = K / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048;
+    static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wn = wid & 1, wk = wid >> 1;
+    const int t0 = blockIdx.x * 4 + wn * 2;                       // 16-row tiles: t0 = gate rows, t0 + 1 = up rows of the same columns
+    bf16x8 wg[KSW], wu[KSW];
+    {
+        const bf16_t* wp = a.W + ((long)t0 * (K >> 5) + wk * KSW) * 512 + lane * 8;
+#pragma unroll
+        for (int u = 0; u < KSW; ++u) {
+            wg[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
+            wu[u] = __builtin_nontemporal_load((const bf16x8*)(wp + (long)(K >> 5) * 512 + u * 512));
+        }
+    }
+    {
+        const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+#pragma unroll
+        for (int t = 0; t < NI / 8; ++t) {
+            const int ii = wid * (NI / 8) + t, kblock = ii / RG, rg = ii % RG;
+            int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
+            const bf16_t* src = a.X + (long)row * a.ldx + kblock * 64 + lc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
+        }
+    }
+    f32x4 ag[MB], au[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { ag[mb] = (f32x4){0.f, 0.f, 0.f, 0.f}; au[mb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KSW; ++u) {
+        const int kg = wk * KSW + u, kblock = kg >> 1, half = kg & 1;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = mb * 16 + r;
+            const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+            ag[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[u], xf, ag[mb], 0, 0, 0);
+            au[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[u], xf, au[mb], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    f32x4* red = (f32x4*)smem;   // [wk 4][wn 2][gate/up 2][MB][64]
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        red[(((wk * 2 + wn) * 2 + 0) * MB + mb) * 64 + lane] = ag[mb];
+        red[(((wk * 2 + wn) * 2 + 1) * MB + mb) * 64 + lane] = au[mb];
+    }
+    __syncthreads();
+    constexpr int mpad = MB * 16;
+    for (int o = tid; o < 32 * mpad; o += 512) {
+        const int m = o >> 5, cl = o & 31, wn2 = cl >> 4, nloc = cl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3, mb = m >> 4;
+        float gs = 0.f, us = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gs += red[(((k * 2 + wn2) * 2 + 0) * MB + mb) * 64 + ln][j];
+            us += red[(((k * 2 + wn2) * 2 + 1) * MB + mb) * 64 + ln][j];
+        }
+        if (m < a.M) act[(long)m * ff + blockIdx.x * 32 + cl] = f2bf(rbf(silu_f(rbf(gs))) * rbf(us));
+    }
+}
+
+template <int MB, int KSW> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, hipStream_t s) {
+    const size_t lds = (size_t)(KSW * 2) * MB * 2048;
+    static bool attr = false;
+    if (!attr && lds > 65536) { (void)hipFuncSetAttribute((const void*)skinny_gu_kernel<MB, KSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    const size_t need = lds > (size_t)32 * MB * 1024 ? lds : (size_t)32 * MB * 1024;
+    hipLaunchKernelGGL((skinny_gu_kernel<MB, KSW>), dim3(a.N / 64), dim3(512), need, s, a, act, a.N / 2);
+}
+// true if the fused kernel handles this shape (else: skinny GEMM + swiglu_slab_kernel)
+bool skinny_gu_eligible(int M, int N, int K) {
+    if (g_skinny_no_fused_gu) return false;
+    const int mb = (M + 15) / 16;
+    if (mb > 2 || N % 64 || N / 64 < 128) return false;
+    return K == 256 || K == 512 || K == 1024 || K == 2048;
+}
+void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s) {
+    const int mb = (a.M + 15) / 16;
+#define GU(KSW) do { if (mb <= 1) launch_gu_v<1, KSW>(a, act, s); else launch_gu_v<2, KSW>(a, act, s); } while (0)
+    switch (a.K) { case 256: GU(2); break; case 512: GU(4); break; case 1024: GU(8); break; default: GU(16); break; }
+#undef GU
+}
+
 int g_skinny_variant = 0;   // 0: shared-X kernel where the shape allows, else one-shot; 2: one-shot nt; 3: one-shot plain loads; 9: read floor (bench only)
 void set_skinny_variant(int v) { g_skinny_variant = v; }
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "sonic_device_count", "sonic_create", "sonic_destroy", "sonic_last_error", "sonic_load_tensor", "sonic_load_synthetic",
     "sonic_finalize_weights", "sonic_weight_bytes", "sonic_logmel", "sonic_encode", "sonic_transcribe_batch", "sonic_stage_pcm",
     "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
-    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read",
+    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_test_skinny_gu",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library():
     lib.sonic_bench_skinny.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.sonic_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.sonic_debug_read.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int64]
+    lib.sonic_test_skinny_gu.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -330,6 +331,15 @@ def _debug_read(self, name: str, shape, index: int = 0) -> np.ndarray:
     return out
 
 
+def _test_skinny_gu(self, X, Wi):
+    X = np.ascontiguousarray(X, np.float32); Wi = np.ascontiguousarray(Wi, np.float32)
+    M, K = X.shape; N = Wi.shape[0]
+    out = np.empty((M, N // 2), np.float32)
+    self._check(self.lib.sonic_test_skinny_gu(self.h, _p(X), _p(Wi), _p(out), M, N, K))
+    return out
+
+
+Engine.test_skinny_gu = _test_skinny_gu
 Engine.debug_read = _debug_read
 Engine.bench_skinny = _bench_skinny
 Engine.set_option = _set_option

@@ -124,6 +124,19 @@ def test_skinny(eng, M, N, K):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-3 * np.sqrt(K) * 0.1)
 
 
+@pytest.mark.parametrize("M,ff,K", [(32, 6144, 2048), (5, 4096, 256), (17, 4096, 512)])
+def test_skinny_fused_gate_up(eng, M, ff, K):
+    rng = np.random.default_rng(ff + K + M)
+    X = bf(rng.standard_normal((M, K))); Wg = bf(rng.standard_normal((ff, K)) * 0.05); Wu = bf(rng.standard_normal((ff, K)) * 0.05)
+    Wi = np.empty((2 * ff, K), np.float32)
+    for g in range(ff // 16):
+        Wi[32 * g:32 * g + 16] = Wg[16 * g:16 * g + 16]; Wi[32 * g + 16:32 * g + 32] = Wu[16 * g:16 * g + 16]
+    got = eng.test_skinny_gu(X, Wi)
+    gg = bf((X.astype(np.float64) @ Wg.T.astype(np.float64)).astype(np.float32)); uu = bf((X.astype(np.float64) @ Wu.T.astype(np.float64)).astype(np.float32))
+    ref = bf(bf(gg / (1.0 + np.exp(-gg))) * uu)
+    assert np.all(np.abs(got - ref) <= ulp_tol(ref, 4) + 1e-3), np.abs(got - ref).max()
+
+
 @pytest.mark.parametrize("hd,Hq,Hkv,Tq,Tk,causal", [(64, 2, 2, 1500, 1500, False), (64, 3, 3, 100, 100, False), (128, 4, 1, 264, 264, True),
                                                     (128, 2, 1, 72, 72, True), (128, 4, 2, 130, 130, True)])
 def test_flash_attention(eng, orc, hd, Hq, Hkv, Tq, Tk, causal):
