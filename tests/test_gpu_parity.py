@@ -425,3 +425,37 @@ def test_checkpoint_loader_equals_synthetic(tmp_path):
     assert t1 == t2 and len(t1.split()) == 10
     assert m1.transcribe_batch([wav, wav[:40000]], max_new_tokens=[4, 6])[0] == " ".join(t1.split()[:4])
     m1.close(); m2.close()
+
+
+def test_streaming_sessions_coalesced():
+    """Config 5's call pattern (transcription_manager.py:19-65): every session turns int16 chunk bytes into a float [1,N] tensor and
+    calls transcribe() -- partials on the last 20 chunks (1.28 s, 15 tokens), finals on the whole segment with
+    min(50 + 5*duration, 200) tokens -- from concurrent threads.  Results must equal the one-at-a-time results."""
+    import threading
+    from sonicscribe_amd import frontend
+    from sonicscribe_amd.asr import ASRModel
+    m = ASRModel.from_synthetic(spec.TINY, max_batch=16, max_ctx=512)
+    chunk = 2048                                                   # AUDIO_CHUNK_SIZE bytes (config.py:24)
+    sessions = []
+    for sidx in range(6):
+        pcm = synth.synth_pcm(80 + sidx, 16000 * (3 + sidx))     # 3..8 s of speech
+        data = pcm.tobytes()
+        n_chunks = len(data) // chunk
+        partial = data[(n_chunks - 20) * chunk: n_chunks * chunk]  # audio_manager.py:106-114: last <= 20 chunks
+        sessions.append((partial, data, len(pcm) / 16000.0))
+
+    def call(audio_bytes, max_new):
+        t = frontend.pcm_bytes_to_float(audio_bytes)               # transcription_manager.py:45-54
+        return m.transcribe(t, sampling_rate=16000, max_new_tokens=max_new).strip()
+
+    want = [(call(p, 15), call(f, min(frontend.max_new_tokens_committed(d), 40))) for p, f, d in sessions]
+    got = [[None, None] for _ in sessions]
+
+    def worker(i, which):
+        p, f, d = sessions[i]
+        got[i][which] = call(p, 15) if which == 0 else call(f, min(frontend.max_new_tokens_committed(d), 40))
+    ts = [threading.Thread(target=worker, args=(i, w)) for i in range(len(sessions)) for w in (0, 1)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert [tuple(x) for x in got] == want
+    assert all(len(a.split()) == 15 for a, _ in want)
+    m.close()
