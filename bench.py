@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--max-new", type=int, default=MAX_NEW)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="engine tuning knob for experiments (sonic_set_option)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -148,6 +149,9 @@ def main():
     B = a.batch
     eng = Engine(dims, local_rank, max_batch=B, max_ctx=512)
     eng.load_synthetic(20260128)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
 
     lo, hi = shard_range(n_gpus * B, rank, n_gpus)           # shard g gets segments g*B .. g*B+B-1
     n_samples = SEG_SECONDS * 16000

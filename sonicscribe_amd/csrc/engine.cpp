@@ -66,7 +66,7 @@ struct sonic_engine {
     bf16_t *dx = nullptr, *dhn = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dact = nullptr;
     bf16_t *Kc = nullptr, *Vc = nullptr, *Vts = nullptr;
     float* dec_cs = nullptr;
-    float *slab = nullptr, *lslab = nullptr;
+    float *slab = nullptr, *lslab = nullptr, *ssq = nullptr;
     bf16_t *sx = nullptr, *shn = nullptr, *sq = nullptr, *satt = nullptr, *sact = nullptr;
     int *kv_len = nullptr, *tok_pos = nullptr, *n_new = nullptr, *finished = nullptr, *max_new_d = nullptr, *n_active = nullptr;
     int *out_ids = nullptr, *step_ctr = nullptr, *seq_iota = nullptr;
@@ -311,6 +311,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->Kc, kvn)); A(dalloc(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
     long mx = 2L * d.dec_ff; if (e->qkvN > mx) mx = e->qkvN; if (d.dec_d > mx) mx = d.dec_d;
     e->slabN = mx;
+    A(dalloc(e, &e->ssq, (size_t)256 * 64));
     A(dalloc(e, &e->slab, (size_t)8 * 64 * mx)); A(dalloc(e, &e->lslab, (size_t)8 * 64 * d.vocab));
     A(dalloc(e, &e->sx, (size_t)64 * d.dec_d)); A(dalloc(e, &e->shn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->sq, (size_t)64 * e->QD));
     A(dalloc(e, &e->satt, (size_t)64 * e->QD)); A(dalloc(e, &e->sact, (size_t)64 * d.dec_ff));
@@ -644,6 +645,15 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_decode_attn(da, R, e->st);
+        const bool fuse_o = skinny_o_eligible(R, D, e->QD) && skinny_gu_eligible(R, 2 * d.dec_ff, D);
+        if (fuse_o) {
+            // o_proj + residual add (+ row sum-of-squares partials) -> gate/up with RMSNorm applied while staging X + SwiGLU:
+            // two kernels instead of o_proj, add+RMSNorm, gate/up, SwiGLU
+            SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1;
+            launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
+            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
+            launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 32, L.ln2, d.dec_rms_eps, e->st);
+        } else {
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st);
         if (skinny_gu_eligible(R, 2 * d.dec_ff, D)) {          // gate/up + SwiGLU in one kernel, no slabs
@@ -652,6 +662,7 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         } else {
             skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
             launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st);
+        }
         }
         skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks);
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
@@ -1201,6 +1212,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "gemm_force128")) { set_gemm_force128(value); return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { set_skinny_no_fused_gu(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
+    if (!strcmp(key, "o_rowsplit")) { set_skinny_o_rowsplit(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { set_gemm256_stagger(value); return SONIC_OK; }
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
