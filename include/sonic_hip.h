@@ -122,7 +122,7 @@ int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int it
 /* debug read-back of an internal bf16 activation buffer as fp32 ("prefill_tap" with index = 0 (embeddings) .. dec_layers,
  * "pe", "dx", "dqkv", "dq", "datt", "dact", "enc_x"); tests / diagnostics only */
 int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
-/* tuning knobs for experiments ("skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu", "o_rowsplit") */
+/* tuning knobs for experiments ("skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu") */
 int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus

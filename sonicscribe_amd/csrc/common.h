@@ -76,7 +76,6 @@ void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
 void set_skinny_variant(int v);
 void set_skinny_no_fused_gu(int v);
-void set_skinny_o_rowsplit(int v);
 bool skinny_gu_eligible(int M, int N, int K);
 void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s);
 void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, int nblk, const float* w, float eps, hipStream_t s);
@@ -85,3 +84,4 @@ void launch_skinny_o(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipS
 void set_gemm_force128(int v);
 void set_gemm256_stagger(int v);
 void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);
+void launch_tile_weights_gu8(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);   // gate/up: 16-row interleaved source -> 8-row interleaved tiles

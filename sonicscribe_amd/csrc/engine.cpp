@@ -29,7 +29,7 @@ struct DevTensor {
 
 struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; };
 struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          // row-major (prefill GEMM)
-                   bf16_t *wqkv_t, *wo_t, *wgu_t, *wdown_t; };                 // fragment-tiled copies (decode skinny GEMM)
+                   bf16_t *wqkv_t, *wo_t, *wgu_t, *wgu_t8, *wdown_t; };                 // fragment-tiled copies (decode skinny GEMM)
 
 struct sonic_engine {
     sonic_dims d;
@@ -506,6 +506,12 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         };
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
         TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
+        L.wgu_t8 = nullptr;
+        if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave)
+            TRY(dalloc(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
+            launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
+            e->weight_bytes += (int64_t)2 * d.dec_ff * d.dec_d * 2;
+        }
     }
     TRY(dalloc(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
     launch_tile_weights(e->embed, e->embed_t, d.vocab, d.dec_d, e->st);
@@ -645,19 +651,20 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_decode_attn(da, R, e->st);
-        const bool fuse_o = skinny_o_eligible(R, D, e->QD) && skinny_gu_eligible(R, 2 * d.dec_ff, D);
+        const bool fuse_gu = L.wgu_t8 && skinny_gu_eligible(R, 2 * d.dec_ff, D);
+        const bool fuse_o = fuse_gu && skinny_o_eligible(R, D, e->QD);
         if (fuse_o) {
             // o_proj + residual add (+ row sum-of-squares partials) -> gate/up with RMSNorm applied while staging X + SwiGLU:
             // two kernels instead of o_proj, add+RMSNorm, gate/up, SwiGLU
             SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1;
             launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
-            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
-            launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 32, L.ln2, d.dec_rms_eps, e->st);
+            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
+            launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 16, L.ln2, d.dec_rms_eps, e->st);
         } else {
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st);
-        if (skinny_gu_eligible(R, 2 * d.dec_ff, D)) {          // gate/up + SwiGLU in one kernel, no slabs
-            SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
+        if (fuse_gu) {          // gate/up + SwiGLU in one kernel, no slabs
+            SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
             launch_skinny_gu(ga, e->sact, e->st);
         } else {
             skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
@@ -1212,7 +1219,6 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "gemm_force128")) { set_gemm_force128(value); return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { set_skinny_no_fused_gu(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
-    if (!strcmp(key, "o_rowsplit")) { set_skinny_o_rowsplit(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { set_gemm256_stagger(value); return SONIC_OK; }
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
@@ -1248,7 +1254,7 @@ extern "C" int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float
     bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, Wgu_interleaved, (size_t)N * K);
     bf16_t* dWt = tb.get<bf16_t>((size_t)N * K); bf16_t* dA = tb.get<bf16_t>((size_t)M * (N / 2));
     if (!dX || !dW || !dWt || !dA) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
-    launch_tile_weights(dW, dWt, N, K, e->st);
+    launch_tile_weights_gu8(dW, dWt, N, K, e->st);
     SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.M = M; a.N = N; a.K = K; a.ksplit = 1;
     launch_skinny_gu(a, dA, e->st);
     return down_bf16(e, tb, dA, act, (size_t)M * (N / 2));

@@ -335,40 +335,48 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
 int g_skinny_no_fused_gu = 0;
 void set_skinny_no_fused_gu(int v) { g_skinny_no_fused_gu = v; }
 
-// skinny_gu_kernel: decode-step gate/up projection with SwiGLU fused (modeling_llama.py:163-176).  A block owns 32 output columns
-// = 64 interleaved weight rows (16 gate + 16 up, twice) over the WHOLE K, so no partial slabs leave the block: the full
-// activation matrix X [M <= 32][K] is DMA'd once into LDS (128 KiB at K = 2048), the 8 waves are 2 (column pairs) x 4 (K quarters),
-// each streams its gate and up tiles from the fragment-tiled weights straight to VGPRs, the K quarters are summed through LDS and
-// the epilogue writes act = bf16(bf16(silu(bf16 g)) * bf16 u) directly.  Replaces skinny GEMM (2 slabs) + swiglu_slab_kernel.
-struct GuNorm { const float* SS; int nblk; const float* w; float eps; };   // NORM: X is the raw residual; scale from SS partials, weight w
+// skinny_gu_kernel: decode-step gate/up projection with SwiGLU fused (modeling_llama.py:163-176).
+// Weights are fragment-tiled with gate and up rows interleaved in groups of 8 (launch_tile_weights_gu8): one 16-row MFMA tile holds
+// gate rows [8t, 8t+8) and up rows [8t, 8t+8) and so yields 8 finished SwiGLU columns.  A block owns TPB consecutive tiles and sees
+// the whole K: X [M <= 32][K] sits in LDS once, the 8 waves split K in eighths (each wave: all TPB tiles of its eighth, one X
+// fragment read feeds TPB MFMAs), the eighths are summed through LDS in fixed order and the epilogue writes
+// act = bf16(bf16(silu(bf16 g)) * bf16 u).  TPB = 3 makes the full-size layer (768 tiles) exactly 256 blocks: the bound of these
+// decode kernels is the per-CU vector-memory pipe (~65 GB/s measured for W + the X image), so every CU has to pull its share.
+//
+// NORM: X is the raw residual stream.  The block turns the o_proj kernel's sum-of-squares partials into the row scale and applies
+// RMSNorm (modeling_llama.py:60-65) in place on the staged image, hn = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))); half of the W
+// loads are issued up front, the rest go out between the pieces of the normalise pass, so a wave alternates vector-memory issue
+// with the VALU work instead of queueing every load first and normalising with the memory pipe idle.
+struct GuNorm { const float* SS; int nblk; const float* w; float eps; };   // SS[nblk / 4][32][4] partials, norm weight w
 
-template <int MB, int KSW, bool NORM>
+template <int MB, int KS8, int TPB, bool NORM>
 __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* act, int ff, GuNorm nm) {
-    constexpr int K = KSW * 128, NKB = K / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048;
+    constexpr int K = KS8 * 256, NKB = K / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048, WTOT = TPB * KS8;
     static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;   // wave = K eighth
     const int r = lane & 15, g = lane >> 4;
-    const int wn = wid & 1, wk = wid >> 1;
-    const int t0 = blockIdx.x * 4 + wn * 2;                       // 16-row tiles: t0 = gate rows, t0 + 1 = up rows of the same columns
     constexpr int PW = NI / 8, KBW = PW / RG > 0 ? PW / RG : 1;     // X pieces / 64-wide K blocks staged by one wave
     static_assert(PW % RG == 0 || RG % PW == 0, "a wave's pieces must tile whole K blocks or sit inside one");
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-    f32x4 ssv[KSW / 2 > 0 ? KSW / 2 : 1];
+    constexpr int SSN = KS8 * 2;                                    // f32x4 of partials per lane: K/16 blocks, two lane halves
+    f32x4 ssv[SSN];
     f32x4 nw[NORM ? KBW * 2 : 1];
     if (NORM) {
-        // sum-of-squares partials first: vmcnt retires in order, so they can be consumed while X / W are still in flight
-        constexpr int NBLK = K / 32, mpad_ = MB * 16;
-        const int rl = (lane & 31) < mpad_ ? (lane & 31) : 0;
-        const float* sp = nm.SS + (long)rl * NBLK + (lane >> 5) * (NBLK / 2);
+        // sum-of-squares partials first: vmcnt retires in order, so they can be consumed while X / W are still in flight.
         // (asm loads + explicit counted waits: with LDS-DMA and plain loads both in flight the compiler's waitcnt pass falls back
         //  to vmcnt(0) at the first use, which would serialise the W fetch behind this pass)
+        // SS is [block / 4][32 rows][4]: one load instruction covers 32 rows x 16 B contiguous per lane half (8 cache lines, like a W
+        // load); a row-major [row][block] layout would touch 64 lines per instruction and cost as much pipe time as the W fetch.
+        const int rl = lane & 31;
+        const float* sp = nm.SS + ((long)(lane >> 5) * SSN * 32 + rl) * 4;
 #pragma unroll
-        for (int i = 0; i < KSW / 2; ++i) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ssv[i]) : "v"(sp), "n"(i * 16) : "memory");
+        for (int i = 0; i < SSN; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ssv[i]) : "v"(sp + (i / 8) * 8 * 128), "n"((i % 8) * 512) : "memory");
     }
 #pragma unroll
     for (int t = 0; t < PW; ++t) {                                   // X (NORM: the raw residual) -> LDS by DMA, lane-linear pieces
-        const int ii = wid * PW + t, kblock = ii / RG, rg = ii % RG;
+        const int ii = wk * PW + t, kblock = ii / RG, rg = ii % RG;
         int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
         const bf16_t* src = a.X + (long)row * a.ldx + kblock * 64 + lc * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -377,45 +385,41 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
     if (NORM) {
 #pragma unroll
         for (int kb = 0; kb < KBW; ++kb) {
-            const int k0 = ((wid * PW) / RG + kb) * 64 + lc * 8;
+            const int k0 = ((wk * PW) / RG + kb) * 64 + lc * 8;
             asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                          : "=&v"(nw[kb * 2]), "=&v"(nw[kb * 2 + 1]) : "v"(nm.w + k0) : "memory");
         }
     }
-    bf16x8 wg[KSW], wu[KSW];
-    {
-        const bf16_t* wp = a.W + ((long)t0 * (K >> 5) + wk * KSW) * 512 + lane * 8;
+    constexpr int WPRE = NORM ? WTOT / 2 : WTOT, WREM = WTOT - WPRE;
+    bf16x8 wf[WTOT];                                                 // [tile j][k-step u] of this wave's K eighth
+    const bf16_t* wp = a.W + ((long)blockIdx.x * TPB * (K >> 5) + wk * KS8) * 512 + lane * 8;
+#define GU_WADDR(f) (wp + ((long)((f) / KS8) * (K >> 5) + (f) % KS8) * 512)
 #pragma unroll
-        for (int u = 0; u < KSW; ++u) {
-            wg[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
-            wu[u] = __builtin_nontemporal_load((const bf16x8*)(wp + (long)(K >> 5) * 512 + u * 512));
-        }
-    }
+    for (int f = 0; f < WPRE; ++f) wf[f] = __builtin_nontemporal_load((const bf16x8*)GU_WADDR(f));
     if (NORM) {
-        // RMSNorm (modeling_llama.py:60-65) applied in place on the staged image: hn = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))).
         // Every lane rewrites exactly the 16 bytes its own DMA deposited, so only this wave's vmcnt orders it - no barrier.
         __builtin_amdgcn_sched_barrier(0);            // keep all loads above in flight (the scheduler would sink W below the rewrite)
         // All LDS traffic of this pass is inline asm: the compiler's waitcnt pass treats a DS instruction behind an outstanding
         // LDS-DMA as aliasing it and inserts vmcnt(0), which would also wait for W.
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < KSW / 2; ++i) {
-            if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + 2 * KBW + 2 * KSW) : "memory");   // partials landed
-            asm volatile("" : "+v"(ssv[i]));                                                            // (uses stay below the wait)
+        for (int i = 0; i < SSN; ++i) {
+            if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + 2 * KBW + WPRE) : "memory");   // partials landed
+            asm volatile("" : "+v"(ssv[i]));                                                         // (uses stay below the wait)
             t += ssv[i][0]; t += ssv[i][1]; t += ssv[i][2]; t += ssv[i][3];
         }
         float t2;
         asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t2) : "v"((lane ^ 32) << 2), "v"(t) : "memory");
         t = t + t2;
         const float rl_scale = 1.0f / sqrtf(t / (float)K + nm.eps);      // lane l holds the scale of row l & 31
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KBW + 2 * KSW) : "memory");   // X pieces landed; norm weight + W still in flight
-        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (wid * PW) * 1024 + lane * 16;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KSW) : "memory");                                  // norm weight landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KBW + WPRE) : "memory");   // X pieces landed; norm weight + W still in flight
+        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (wk * PW) * 1024 + lane * 16;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPRE) : "memory");             // norm weight landed
 #pragma unroll
         for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));
 #pragma unroll
         for (int tt = 0; tt < PW; ++tt) {
-            const int ii = wid * PW + tt, rg = ii % RG, kb = tt / RG;
+            const int ii = wk * PW + tt, rg = ii % RG, kb = tt / RG;
             int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
             float rr; bf16x8 xv;
             asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_read_b128 %1, %4\n\ts_waitcnt lgkmcnt(0)"
@@ -425,182 +429,168 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 #pragma unroll
             for (int j = 0; j < 4; ++j) { o[j] = f2bf(w0[j] * rbf(bf2f(xv[j]) * rr)); o[4 + j] = f2bf(w1[j] * rbf(bf2f(xv[4 + j]) * rr)); }
             asm volatile("ds_write_b128 %0, %1" ::"v"(lbase + tt * 1024), "v"(o) : "memory");
+#pragma unroll
+            for (int f = WPRE + tt * WREM / PW; f < WPRE + (tt + 1) * WREM / PW; ++f)      // the next W fragment(s) go out behind this piece
+                wf[f] = __builtin_nontemporal_load((const bf16x8*)GU_WADDR(f));
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    f32x4 ag[MB], au[MB];
+#undef GU_WADDR
+    f32x4 acc[TPB][MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) { ag[mb] = (f32x4){0.f, 0.f, 0.f, 0.f}; au[mb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < TPB; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < KSW; ++u) {
-        const int kg = wk * KSW + u, kblock = kg >> 1, half = kg & 1;
+    for (int u = 0; u < KS8; ++u) {
+        const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int m = mb * 16 + r;
             const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
-            ag[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[u], xf, ag[mb], 0, 0, 0);
-            au[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[u], xf, au[mb], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPB; ++j) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xf, acc[j][mb], 0, 0, 0);
         }
     }
     __syncthreads();
-    f32x4* red = (f32x4*)smem;   // [wk 4][wn 2][gate/up 2][MB][64]
+    f32x4* red = (f32x4*)smem;   // [wk 8][tile TPB][MB][64]
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        red[(((wk * 2 + wn) * 2 + 0) * MB + mb) * 64 + lane] = ag[mb];
-        red[(((wk * 2 + wn) * 2 + 1) * MB + mb) * 64 + lane] = au[mb];
-    }
+    for (int j = 0; j < TPB; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) red[((wk * TPB + j) * MB + mb) * 64 + lane] = acc[j][mb];
     __syncthreads();
-    constexpr int mpad = MB * 16;
-    for (int o = tid; o < 32 * mpad; o += 512) {
-        const int m = o >> 5, cl = o & 31, wn2 = cl >> 4, nloc = cl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3, mb = m >> 4;
+    constexpr int mpad = MB * 16, NC = 8 * TPB;
+    for (int o = tid; o < NC * mpad; o += 512) {
+        // D[n][m]: lane = 16 * (n / 4) + m, element n % 4; gate column c of a tile is n = c, its up partner n = c + 8
+        const int m = o / NC, c = o % NC, j = c >> 3, cc = c & 7, mb = m >> 4;
+        const int lg = (cc >> 2) * 16 + (m & 15), lu = lg + 32, e = cc & 3;
         float gs = 0.f, us = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            gs += red[(((k * 2 + wn2) * 2 + 0) * MB + mb) * 64 + ln][j];
-            us += red[(((k * 2 + wn2) * 2 + 1) * MB + mb) * 64 + ln][j];
+        for (int k = 0; k < 8; ++k) {
+            gs += red[((k * TPB + j) * MB + mb) * 64 + lg][e];
+            us += red[((k * TPB + j) * MB + mb) * 64 + lu][e];
         }
-        if (m < a.M) act[(long)m * ff + blockIdx.x * 32 + cl] = f2bf(rbf(silu_f(rbf(gs))) * rbf(us));
+        if (m < a.M) act[(long)m * ff + blockIdx.x * NC + c] = f2bf(rbf(silu_f(rbf(gs))) * rbf(us));
     }
 }
 
 // skinny_o_kernel: decode-step o_proj with the residual add fused (modeling_llama.py:306-309).  Like skinny_gu_kernel the block sees the
-// whole K (X = attention output [M <= 32][K] resident in LDS), owns 32 output columns (2 tiles x 4 K quarters), sums the quarters
-// through LDS and then writes x = bf16(x + bf16(acc)) in place.  It also emits, per block, the partial sum of squares of its 32
-// columns of every updated row (SS[row][block], fixed summation order): the consumer (skinny_gu_kernel<NORM>) turns them into the
+// whole K (X = attention output, one 16-row group per blockIdx.y, resident in LDS), owns one 16-column tile, sums the 8 K eighths
+// through LDS and then writes x = bf16(x + bf16(acc)) in place.  It also emits, per block, the partial sum of squares of its 16
+// columns of every updated row (SS[block / 4][row][4], fixed summation order): the consumer (skinny_gu_kernel<NORM>) turns them into the
 // RMSNorm scale, so the separate add+RMSNorm kernel between o_proj and gate/up disappears.
-template <int MB, int KSW>
+template <int KS8>
 __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, int ldxres, float* SS) {
-    constexpr int K = KSW * 128, NKB = K / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048, mpad = MB * 16;
+    constexpr int K = KS8 * 256, NKB = K / 64, RG = 2, NI = NKB * RG, KBS = 2048, mpad = 16;
     static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int wn = wid & 1, wk = wid >> 1;
-    const int t0 = blockIdx.x * 2 + wn;
-    // blockIdx.y: 16-row groups handled by separate blocks (row-split launch); M is the row count of this block's group
     const int row0 = blockIdx.y * mpad, M = a.M - row0 < mpad ? a.M - row0 : mpad;
     const bf16_t* X = a.X + (long)row0 * a.ldx;
     x += (long)row0 * ldxres;
-    bf16x8 wf[KSW];
+    bf16x8 wf[KS8];
     {
-        const bf16_t* wp = a.W + ((long)t0 * (K >> 5) + wk * KSW) * 512 + lane * 8;
+        const bf16_t* wp = a.W + ((long)blockIdx.x * (K >> 5) + wk * KS8) * 512 + lane * 8;
 #pragma unroll
-        for (int u = 0; u < KSW; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
+        for (int u = 0; u < KS8; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
     }
     {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
 #pragma unroll
         for (int t = 0; t < NI / 8; ++t) {
-            const int ii = wid * (NI / 8) + t, kblock = ii / RG, rg = ii % RG;
+            const int ii = wk * (NI / 8) + t, kblock = ii / RG, rg = ii % RG;
             int row = rg * 8 + lr; row = row < M ? row : M - 1;
             const bf16_t* src = X + (long)row * a.ldx + kblock * 64 + lc * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
         }
     }
-    bf16_t xres[MB];                                 // residual values this thread updates in the epilogue, fetched up front
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int o = tid + i * 512, m = o >> 5, cl = o & 31;
-        xres[i] = x[(long)(m < M ? m : M - 1) * ldxres + blockIdx.x * 32 + cl];
-    }
-    f32x4 acc[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // residual value this thread updates in the epilogue (threads 0..255: row tid / 16, column tid % 16), fetched up front
+    const int em = (tid >> 4) & 15, ec = tid & 15;
+    const bf16_t xres = x[(long)(em < M ? em : M - 1) * ldxres + blockIdx.x * 16 + ec];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < KSW; ++u) {
-        const int kg = wk * KSW + u, kblock = kg >> 1, half = kg & 1;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int m = mb * 16 + r;
-            const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[mb], 0, 0, 0);
-        }
+    for (int u = 0; u < KS8; ++u) {
+        const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
+        const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + r * 128 + (((half * 4 + g) ^ (r & 7)) << 4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc, 0, 0, 0);
     }
     __syncthreads();
-    f32x4* red = (f32x4*)smem;                       // [wk 4][wn 2][MB][64]
-    float* sq = (float*)(smem + 8 * MB * 1024);      // [mpad][32] squares of the updated residual
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) red[((wk * 2 + wn) * MB + mb) * 64 + lane] = acc[mb];
+    f32x4* red = (f32x4*)smem;                       // [wk 8][64]
+    float* sq = (float*)(smem + 8 * 1024);           // [16 rows][16 cols] squares of the updated residual
+    red[wk * 64 + lane] = acc;
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int o = tid + i * 512;
-        const int m = o >> 5, cl = o & 31, wn2 = cl >> 4, nloc = cl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3, mb = m >> 4;
+    if (tid < 256) {
+        const int ln = (ec >> 2) * 16 + em, j = ec & 3;
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v += red[((k * 2 + wn2) * MB + mb) * 64 + ln][j];
+        for (int k = 0; k < 8; ++k) v += red[k * 64 + ln][j];
         float xn = 0.f;
-        if (m < M) {
-            xn = rbf(bf2f(xres[i]) + rbf(v));
-            x[(long)m * ldxres + blockIdx.x * 32 + cl] = f2bf(xn);
+        if (em < M) {
+            xn = rbf(bf2f(xres) + rbf(v));
+            x[(long)em * ldxres + blockIdx.x * 16 + ec] = f2bf(xn);
         }
-        sq[m * 32 + cl] = xn * xn;
+        sq[em * 16 + ec] = xn * xn;
     }
     __syncthreads();
     if (tid < mpad) {
         float t = 0.f;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) t += sq[tid * 32 + c];
-        SS[(long)(row0 + tid) * gridDim.x + blockIdx.x] = t;
+        for (int c = 0; c < 16; ++c) t += sq[tid * 16 + c];
+        SS[((long)(blockIdx.x >> 2) * 32 + row0 + tid) * 4 + (blockIdx.x & 3)] = t;      // [block / 4][32 rows][4], see skinny_gu_kernel
     }
 }
 
-template <int MB, int KSW, bool NORM> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
-    const size_t lds = (size_t)(KSW * 2) * MB * 2048 + 256;          // X image (+ row scales)
-    const size_t need = lds > (size_t)32 * MB * 1024 ? lds : (size_t)32 * MB * 1024;
+template <int MB, int KS8, int TPB, bool NORM> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
+    const size_t lds = (size_t)(KS8 * 4) * MB * 2048;               // X image
+    const size_t redb = (size_t)8 * TPB * MB * 1024;
+    const size_t need = lds > redb ? lds : redb;
     static bool attr = false;
-    if (!attr && need > 65536) { (void)hipFuncSetAttribute((const void*)skinny_gu_kernel<MB, KSW, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); attr = true; }
-    hipLaunchKernelGGL((skinny_gu_kernel<MB, KSW, NORM>), dim3(a.N / 64), dim3(512), need, s, a, act, a.N / 2, nm);
+    if (!attr && need > 65536) { (void)hipFuncSetAttribute((const void*)skinny_gu_kernel<MB, KS8, TPB, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); attr = true; }
+    hipLaunchKernelGGL((skinny_gu_kernel<MB, KS8, TPB, NORM>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, act, a.N / 2, nm);
 }
 // true if the fused kernel handles this shape (else: skinny GEMM + swiglu_slab_kernel)
 bool skinny_gu_eligible(int M, int N, int K) {
     if (g_skinny_no_fused_gu) return false;
     const int mb = (M + 15) / 16;
-    if (mb > 2 || N % 64 || N / 64 < 128) return false;
+    if (mb > 2 || N % 32 || N / 32 < 128) return false;
     return K == 256 || K == 512 || K == 1024 || K == 2048;
 }
-void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s) {
+template <bool NORM> static void launch_gu_any(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
     const int mb = (a.M + 15) / 16;
-    const GuNorm nm{};
-#define GU(KSW) do { if (mb <= 1) launch_gu_v<1, KSW, false>(a, act, nm, s); else launch_gu_v<2, KSW, false>(a, act, nm, s); } while (0)
-    switch (a.K) { case 256: GU(2); break; case 512: GU(4); break; case 1024: GU(8); break; default: GU(16); break; }
+    const bool t3 = (a.N / 16) % 3 == 0;                             // 3 tiles per block where the tile count allows (768 tiles -> 256 blocks)
+#define GU(KS8) do { if (mb <= 1) { if (t3) launch_gu_v<1, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<1, KS8, 2, NORM>(a, act, nm, s); } \
+                     else { if (t3) launch_gu_v<2, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM>(a, act, nm, s); } } while (0)
+    switch (a.K) { case 256: GU(1); break; case 512: GU(2); break; case 1024: GU(4); break; default: GU(8); break; }
 #undef GU
 }
-// gate/up on the raw residual: RMSNorm scale from the o_proj kernel's sum-of-squares partials
+// W: launch_tile_weights_gu8 layout
+void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s) { launch_gu_any<false>(a, act, GuNorm{}, s); }
+// gate/up on the raw residual: RMSNorm scale from the o_proj kernel's sum-of-squares partials (nblk = K / 16 per row)
 void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, int nblk, const float* w, float eps, hipStream_t s) {
-    const int mb = (a.M + 15) / 16;
-    const GuNorm nm{SS, nblk, w, eps};
-#define GU(KSW) do { if (mb <= 1) launch_gu_v<1, KSW, true>(a, act, nm, s); else launch_gu_v<2, KSW, true>(a, act, nm, s); } while (0)
-    switch (a.K) { case 256: GU(2); break; case 512: GU(4); break; case 1024: GU(8); break; default: GU(16); break; }
-#undef GU
+    launch_gu_any<true>(a, act, GuNorm{SS, nblk, w, eps}, s);
 }
-template <int MB, int KSW> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, int ygroups, hipStream_t s) {
-    const size_t lds = (size_t)(KSW * 2) * MB * 2048;
-    const size_t need = lds > (size_t)(8 * MB * 1024 + MB * 16 * 32 * 4) ? lds : (size_t)(8 * MB * 1024 + MB * 16 * 32 * 4);
+template <int KS8> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
+    const size_t lds = (size_t)(KS8 * 4) * 2048;
+    const size_t need = lds > (size_t)(8 * 1024 + 1024) ? lds : (size_t)(8 * 1024 + 1024);
     static bool attr = false;
-    if (!attr && need > 65536) { (void)hipFuncSetAttribute((const void*)skinny_o_kernel<MB, KSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); attr = true; }
-    hipLaunchKernelGGL((skinny_o_kernel<MB, KSW>), dim3(a.N / 32, ygroups), dim3(512), need, s, a, x, ldxres, SS);
+    if (!attr && need > 65536) { (void)hipFuncSetAttribute((const void*)skinny_o_kernel<KS8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); attr = true; }
+    hipLaunchKernelGGL((skinny_o_kernel<KS8>), dim3(a.N / 16, (a.M + 15) / 16), dim3(512), need, s, a, x, ldxres, SS);
 }
 bool skinny_o_eligible(int M, int N, int K) {
     if (g_skinny_no_fused_gu) return false;
-    const int mb = (M + 15) / 16;
-    if (mb > 2 || N % 32 || N / 32 > 256) return false;
+    if (M > 32 || N % 16) return false;
     return K == 256 || K == 512 || K == 1024 || K == 2048;
 }
-int g_skinny_o_rowsplit = 1;
-void set_skinny_o_rowsplit(int v) { g_skinny_o_rowsplit = v; }   // 1: M > 16 runs as two 16-row block groups (halves the X image a CU stages; W is read by both)
 void launch_skinny_o(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
-    const int mb = (a.M + 15) / 16;
-    const bool split = mb == 2 && g_skinny_o_rowsplit;
-#define OO(KSW) do { if (mb <= 1) launch_o_v<1, KSW>(a, x, ldxres, SS, 1, s); else if (split) launch_o_v<1, KSW>(a, x, ldxres, SS, 2, s); \
-                     else launch_o_v<2, KSW>(a, x, ldxres, SS, 1, s); } while (0)
-    switch (a.K) { case 256: OO(2); break; case 512: OO(4); break; case 1024: OO(8); break; default: OO(16); break; }
-#undef OO
+    switch (a.K) { case 256: launch_o_v<1>(a, x, ldxres, SS, s); break; case 512: launch_o_v<2>(a, x, ldxres, SS, s); break;
+                   case 1024: launch_o_v<4>(a, x, ldxres, SS, s); break; default: launch_o_v<8>(a, x, ldxres, SS, s); break; }
 }
 
 int g_skinny_variant = 0;   // 0: shared-X kernel where the shape allows, else one-shot; 2: one-shot nt; 3: one-shot plain loads; 9: read floor (bench only)
@@ -678,6 +668,21 @@ __global__ void tile_weights_kernel(const bf16_t* w, bf16_t* wt, int N, int K) {
     const int n = e / (K >> 3), kc = e % (K >> 3), k = kc * 8;
     const long dst = ((long)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + ((((k & 31) >> 3) * 16) + (n & 15)) * 8;
     *(bf16x8*)(wt + dst) = *(const bf16x8*)(w + (long)n * K + k);
+}
+// gate/up variant: the source has gate and up rows interleaved in groups of 16 (the prefill GEMM's SwiGLU epilogue layout); the tiled
+// copy interleaves them in groups of 8, so tile t = gate rows [8t, 8t+8) followed by up rows [8t, 8t+8)
+__global__ void tile_weights_gu8_kernel(const bf16_t* w, bf16_t* wt, int N, int K) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * (K >> 3)) return;
+    const int n = e / (K >> 3), kc = e % (K >> 3), k = kc * 8;       // n = destination row
+    const int t = n >> 4, i = n & 15, q = t * 8 + (i & 7);           // q = gate/up row index
+    const int src = (q >> 4) * 32 + (i >> 3) * 16 + (q & 15);
+    const long dst = ((long)t * (K >> 5) + (k >> 5)) * 512 + ((((k & 31) >> 3) * 16) + i) * 8;
+    *(bf16x8*)(wt + dst) = *(const bf16x8*)(w + (long)src * K + k);
+}
+void launch_tile_weights_gu8(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s) {
+    const long n = (long)N * (K >> 3);
+    hipLaunchKernelGGL(tile_weights_gu8_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wt, N, K);
 }
 void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s) {
     const long n = (long)N * (K >> 3);
