@@ -223,11 +223,28 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 //     256-byte per-wave LDS record, P.V on the VALU (V is row-major in the cache);
 //  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
 // Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
+// reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with gfx950's permlane swaps: VALU only, no LDS round
+// trip (ds_bpermute).  permlane16_swap exchanges the odd rows of one operand with the even rows of the other, permlane32_swap the
+// upper half of one with the lower half of the other; with both operands equal the two results hold the two partners in every lane.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_sum(float v) {
+    u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+    u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
     __shared__ float s_acc[NW][GMAX][HD];
     __shared__ float s_m[NW][GMAX], s_l[NW][GMAX];
-    __shared__ float s_q[GMAX + 2][HD];                            // q heads (unscaled), then k, v of the new token
+    __shared__ __attribute__((aligned(16))) bf16_t s_q[GMAX + 2][HD];   // q heads (unscaled), then k, v of the new token (all bf16 values)
     __shared__ __attribute__((aligned(16))) float s_p[NW][16][4];  // per wave: probabilities [key in slice][head]
     __shared__ __attribute__((aligned(16))) float s_mn[NW][4];     // per wave: new running max per head
     const int G = a.Hq / a.Hkv;
@@ -247,18 +264,24 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         for (int u = 0; u < 4; ++u) vd[u] = *(const bf16x8*)(Vc + (long)min(k0 + 4 * u + g, cm1) * HD + r * 8);
     };
     load(wid * 16, kf, vv);
-    const int n = a.kv_len[b];              // keys visible, the new token included at position n-1
 
+    int n;                                   // keys visible, the new token included at position n-1
     if (a.P) {
-        const int N = (a.Hq + 2 * a.Hkv) * HD, pos = n - 1;
-        for (int w = tid; w < (G + 2) * HALF; w += 512) {
-            const int vi = w / HALF, i = w % HALF;          // vector (q heads.., k, v), index in the first half
+        // QKV slab sum of this (segment, kv head): issued before kv_len is needed, so the two latencies overlap
+        const int N = (a.Hq + 2 * a.Hkv) * HD;
+        const int w = tid, vi = w / HALF, i = w % HALF;      // vector (q heads.., k, v), index in the first half; (G + 2) * 64 <= 384 threads
+        const bool act = w < (G + 2) * HALF;
+        float x1 = 0.f, x2 = 0.f;
+        if (act) {
             const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
-            float x1 = 0.f, x2 = 0.f;
             for (int ks = 0; ks < a.ksplit; ++ks) {
                 const float* p = a.P + ((long)ks * a.mpad + b) * N + col;
                 x1 += p[0]; x2 += p[HALF];
             }
+        }
+        n = a.kv_len[b];
+        if (act) {
+            const int pos = n - 1;
             x1 = rbf(x1); x2 = rbf(x2);
             float o1 = x1, o2 = x2;
             if (vi <= G) {
@@ -267,24 +290,23 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
                 o2 = rbf(rbf(x2 * c) + rbf(x1 * sn));
             }
             const int row = vi < G ? vi : (vi == G ? GMAX : GMAX + 1);
-            s_q[row][i] = o1; s_q[row][HALF + i] = o2;
-            if (vi == G) { Kc[(long)pos * HD + i] = f2bf(o1); Kc[(long)pos * HD + HALF + i] = f2bf(o2); }
-            if (vi == G + 1) { Vc[(long)pos * HD + i] = f2bf(o1); Vc[(long)pos * HD + HALF + i] = f2bf(o2); }
+            const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
+            s_q[row][i] = b1; s_q[row][HALF + i] = b2;
+            if (vi == G) { Kc[(long)pos * HD + i] = b1; Kc[(long)pos * HD + HALF + i] = b2; }
+            if (vi == G + 1) { Vc[(long)pos * HD + i] = b1; Vc[(long)pos * HD + HALF + i] = b2; }
         }
         __syncthreads();
+    } else {
+        n = a.kv_len[b];
     }
     // q as the MFMA B operand: column r = head (zero beyond the group), k = head-dim
     bf16x8 qf[4];
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
-        if (a.P) {
+        const bf16x8 t = a.P ? *(const bf16x8*)&s_q[r < G ? r : 0][hs * 32 + g * 8]
+                             : *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + (kvh * G + (r < G ? r : 0)) * HD + hs * 32 + g * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[hs][j] = f2bf(r < G ? s_q[r < G ? r : 0][hs * 32 + g * 8 + j] : 0.f);
-        } else {
-            const bf16x8 t = *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + (kvh * G + (r < G ? r : 0)) * HD + hs * 32 + g * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[hs][j] = r < G ? t[j] : f2bf(0.f);
-        }
+        for (int j = 0; j < 8; ++j) qf[hs][j] = r < G ? t[j] : f2bf(0.f);
     }
     float m[GMAX], lsum = 0.f, acc[GMAX][8];
 #pragma unroll
@@ -300,8 +322,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         float sc[4], mx = -1e30f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { sc[j] = (k0 + g * 4 + j) < limit ? st[j] * a.scale : -1e30f; mx = fmaxf(mx, sc[j]); }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         const float m_r = r == 0 ? m[0] : r == 1 ? m[1] : r == 2 ? m[2] : m[3];
         const float mn = fmaxf(m_r, mx);
         float ps = 0.f, pr[4];
@@ -344,26 +365,20 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     }
     if (a.P && wid == 0) {                   // the token being decoded: its k / v are still in LDS (slice key 0 only)
 #pragma unroll
-        for (int hs = 0; hs < 4; ++hs)
+        for (int hs = 0; hs < 4; ++hs) kf[hs] = *(const bf16x8*)&s_q[GMAX][hs * 32 + g * 8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kf[hs][j] = f2bf(s_q[GMAX][hs * 32 + g * 8 + j]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vv[u][i] = f2bf(s_q[GMAX + 1][r * 8 + i]);
+        for (int u = 0; u < 4; ++u) vv[u] = *(const bf16x8*)&s_q[GMAX + 1][r * 8];
         step(0, kf, vv, 1);
     }
     // merge: per wave the row sums over the 4 key quarters, the outputs over the 4 V-owner groups; then the 8 waves
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
+    lsum = rows_sum(lsum);
     if (g == 0 && r < 4) s_l[wid][r] = lsum;
     if (lane == 0) { s_m[wid][0] = m[0]; s_m[wid][1] = m[1]; s_m[wid][2] = m[2]; s_m[wid][3] = m[3]; }
 #pragma unroll
     for (int h = 0; h < GMAX; ++h)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float v = acc[h][i];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            const float v = rows_sum(acc[h][i]);
             if (g == 0) s_acc[wid][h][r * 8 + i] = v;
         }
     __syncthreads();
