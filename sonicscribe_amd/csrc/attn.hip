@@ -18,6 +18,7 @@
 // rows, fp32 scores in LDS, one block per (sequence, kv head) serving its 4 query heads together.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 
 template <int HD> __device__ __forceinline__ int kswz(int row) {  // swizzle term for the K tile (rows = keys)
@@ -127,48 +128,59 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
                 st[ks][sb][1] = s1;
             }
 
-        // ---- online softmax per query (= per lane), P^T fragments
+        // ---- online softmax per query (= per lane), P^T fragments.  Statistics are kept on the RAW scores (scale > 0, so the max
+        // commutes with the scaling) and the scale is folded into the exponent: p = exp2(s * c - m * c), c = scale * log2(e), one FMA
+        // and one v_exp_f32 per score.  Tiles that need no masking (all but the last key tile / the causal diagonal) take a branch
+        // without the per-element compares and selects.
         const bool edge = (key0 + 64 > kv_len) || (CAUSAL && (key0 + 63 > q0 + wid * 32 + qpos_off));
         bf16x8 pf[2][2];
+        const float cexp = a.scale * 1.44269504088896341f;
+        auto softmax = [&](auto masked) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float mx = -1e30f;
+            for (int qb = 0; qb < 2; ++qb) {
+                if (decltype(masked)::value) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
+                        for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float s = st[ks][sb][qb][j] * a.scale;
-                        if (edge) {
-                            const int key = key0 + ks * 32 + 8 * fg + 4 * sb + j;
-                            bool ok = key < kv_len;
-                            if (CAUSAL) ok = ok && (key <= qrow[qb] + qpos_off);
-                            s = ok ? s : -1e30f;
+                            for (int j = 0; j < 4; ++j) {
+                                const int key = key0 + ks * 32 + 8 * fg + 4 * sb + j;
+                                bool ok = key < kv_len;
+                                if (CAUSAL) ok = ok && (key <= qrow[qb] + qpos_off);
+                                st[ks][sb][qb][j] = ok ? st[ks][sb][qb][j] : -1e30f;
+                            }
+                }
+                float mx = -1e30f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, st[ks][sb][qb][j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrun[qb], mx);
+                const float alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * cexp);
+                mrun[qb] = mnew;
+                const float moff = -mnew * cexp;
+                float psum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[ks][sb][qb][j], cexp, moff));
+                            psum += p;
+                            pf[qb][ks][sb * 4 + j] = f2bf(p);
                         }
-                        st[ks][sb][qb][j] = s;
-                        mx = fmaxf(mx, s);
-                    }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrun[qb], mx);
-            const float alpha = __expf(mrun[qb] - mnew);
-            mrun[qb] = mnew;
-            float psum = 0.f;
+                lrun[qb] = lrun[qb] * alpha + psum;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float p = __expf(st[ks][sb][qb][j] - mnew);
-                        psum += p;
-                        pf[qb][ks][sb * 4 + j] = f2bf(p);
-                    }
-            lrun[qb] = lrun[qb] * alpha + psum;
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb) oacc[qb][hb] *= alpha;
-        }
+                for (int hb = 0; hb < HB; ++hb) oacc[qb][hb] *= alpha;
+            }
+        };
+        if (edge) softmax(std::true_type{}); else softmax(std::false_type{});
 
         // ---- O^T += V^T . P^T
 #pragma unroll

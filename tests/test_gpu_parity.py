@@ -115,7 +115,8 @@ def test_gemm256_path(eng, M, N, K, epi):
     assert np.mean(old != got) < 0.02      # same math, different summation order: only isolated bf16 flips
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (32, 256, 256), (32, 1024, 512), (40, 512, 2048), (64, 128, 768), (33, 48, 1024), (32, 2048, 6144)])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (32, 256, 256), (32, 1024, 512), (40, 512, 2048), (64, 128, 768), (33, 48, 1024), (32, 2048, 6144),
+                                   (32, 3072, 2048), (17, 2048, 6144), (64, 3072, 2048), (5, 4096, 1024)])   # one-block-per-CU tilings
 def test_skinny(eng, M, N, K):
     rng = np.random.default_rng(M * 7 + N)
     X = bf(rng.standard_normal((M, K))); W = bf(rng.standard_normal((N, K)) * 0.1)
