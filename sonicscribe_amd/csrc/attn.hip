@@ -21,6 +21,23 @@
 #include <type_traits>
 
 
+// reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with gfx950's permlane swaps: VALU only, no LDS round
+// trip (ds_bpermute).  permlane16_swap exchanges the odd rows of one operand with the even rows of the other, permlane32_swap the
+// upper half of one with the lower half of the other; with both operands equal the two results hold the two partners in every lane.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_sum(float v) {
+    u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+    u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 template <int HD> __device__ __forceinline__ int kswz(int row) {  // swizzle term for the K tile (rows = keys)
     if (HD == 64) return ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
     return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
@@ -64,6 +81,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
         for (int hs = 0; hs < HS; ++hs) qf[qb][hs] = *(const bf16x8*)(Q + (long)qr * a.q_ld + hs * 32 + fg * 8);
     }
 
+    // Make the compiler retire the Q loads HERE: otherwise its waitcnt bookkeeping carries them into the tile loop as "possibly
+    // pending" and every iteration waits for vmcnt(0) in front of the first MFMAs - i.e. for the K/V prefetch it has just issued.
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int hs = 0; hs < HS; ++hs) asm volatile("" : "+v"(qf[qb][hs]));
     f32x4 oacc[2][HB];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -158,8 +181,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) mx = fmaxf(mx, st[ks][sb][qb][j]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = rows_max(mx);
                 const float mnew = fmaxf(mrun[qb], mx);
                 const float alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * cexp);
                 mrun[qb] = mnew;
@@ -198,9 +220,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     bf16_t* O = a.O + obase + (long)h * HD;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        float l = lrun[qb];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = rows_sum(lrun[qb]);
         if (qrow[qb] < q_len) {
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
@@ -235,23 +255,6 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 //     256-byte per-wave LDS record, P.V on the VALU (V is row-major in the cache);
 //  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
 // Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
-// reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with gfx950's permlane swaps: VALU only, no LDS round
-// trip (ds_bpermute).  permlane16_swap exchanges the odd rows of one operand with the even rows of the other, permlane32_swap the
-// upper half of one with the lower half of the other; with both operands equal the two results hold the two partners in every lane.
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float rows_sum(float v) {
-    u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-__device__ __forceinline__ float rows_max(float v) {
-    u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-
 __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
     __shared__ float s_acc[NW][GMAX][HD];
