@@ -285,11 +285,7 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     const int wn = wid % WN, wk = wid / WN;
     const int n0 = blockIdx.x * (WN * 16) + wn * 16;
     const int kb = blockIdx.y * BKk;
-    // weights first: they come from HBM
-    const bf16_t* wp = a.W + ((long)(n0 >> 4) * (a.K >> 5) + ((kb + wk * (KSW * 32)) >> 5)) * 512 + lane * 8;
-    bf16x8 wf[KSW];
-#pragma unroll
-    for (int u = 0; u < KSW; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
+    // X slice first (small, out of L2): it has to be complete in LDS - for all waves - before the first MFMA
     {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
 #pragma unroll
@@ -301,13 +297,24 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
                                              (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
         }
     }
+    // then the weights (HBM, nontemporal): asm loads with hand-counted waits, so that k-step u is multiplied as soon as ITS fragment
+    // has landed (vmcnt retires in order) instead of after the whole slice - the compiler's own bookkeeping falls back to vmcnt(0)
+    // when LDS-DMA and register loads are in flight together
+    const bf16_t* wp = a.W + ((long)(n0 >> 4) * (a.K >> 5) + ((kb + wk * (KSW * 32)) >> 5)) * 512 + lane * 8;
+    bf16x8 wf[KSW];
+#pragma unroll
+    for (int u = 0; u < KSW; ++u) {
+        if (u < 4) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp), "n"(u * 1024) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp + (u / 4) * 2048), "n"((u % 4) * 1024) : "memory");
+    }
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KSW) : "memory");      // this wave's X pieces are in LDS
+    __builtin_amdgcn_s_barrier();                                    // (raw barrier: __syncthreads would add a vmcnt(0) fence)
 #pragma unroll
     for (int u = 0; u < KSW; ++u) {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[u]) : "n"(KSW - 1 - u) : "memory");
         const int kg = wk * KSW + u, kblock = kg >> 1, half = kg & 1;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
