@@ -289,10 +289,16 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         float x1 = 0.f, x2 = 0.f;
         if (act) {
             const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
-            for (int ks = 0; ks < a.ksplit; ++ks) {
-                const float* p = a.P + ((long)ks * a.mpad + b) * N + col;
-                x1 += p[0]; x2 += p[HALF];
+            // all slab loads in flight at once (a rolled loop would serialise one L2 round trip per slab); fixed summation order
+            float v1[8], v2[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float* p = a.P + ((long)(ks < a.ksplit ? ks : 0) * a.mpad + b) * N + col;
+                v1[ks] = p[0]; v2[ks] = p[HALF];
             }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                if (ks < a.ksplit) { x1 += v1[ks]; x2 += v2[ks]; }
         }
         n = a.kv_len[b];
         if (act) {
