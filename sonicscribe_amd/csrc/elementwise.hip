@@ -93,14 +93,28 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(bf16_t* x, const float
     float s = 0.f;
     if (c < nv) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < ksplit; ++ks) {
-            const float* p = P + ((long)ks * mpad + row) * d + c * 8;
-            const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
-        }
         bf16_t* xr = x + (long)row * d + c * 8;
         const bf16x8 t = *(const bf16x8*)xr;
+        // every slab load is issued before the first add (a rolled ksplit loop costs one L2 round trip per slab); the sum keeps its
+        // fixed order ks = 0, 1, ...
+        f32x4 a0[8], a1[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float* p = P + ((long)(ks < ksplit ? ks : 0) * mpad + row) * d + c * 8;
+            a0[ks] = *(const f32x4*)p; a1[ks] = *(const f32x4*)(p + 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < ksplit) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += a0[ks][j]; acc[4 + j] += a1[ks][j]; }
+            }
+        for (int ks = 8; ks < ksplit; ++ks) {                         // (not reached by the current tilings: ksplit <= 8)
+            const float* p = P + ((long)ks * mpad + row) * d + c * 8;
+            const f32x4 b0 = *(const f32x4*)p, b1 = *(const f32x4*)(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += b0[j]; acc[4 + j] += b1[j]; }
+        }
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o[j] = f2bf(bf2f(t[j]) + rbf(acc[j])); v[j] = bf2f(o[j]); s += v[j] * v[j]; }
@@ -245,14 +259,29 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
     const long ks_stride = (long)a.mpad * a.V;
     float* dump = a.logits_dump ? a.logits_dump + (long)a.step_counter[b] * a.dump_stride_step + (long)b * a.V : nullptr;
     float best = -INFINITY; int bi = 0x7fffffff;
-    for (int i = tid * 4; i < a.V; i += 1024 * 4) {
-        f32x4 v = *(const f32x4*)(lg + i);
-        for (int ks = 1; ks < a.ksplit; ++ks) v += *(const f32x4*)(lg + ks * ks_stride + i);
+    // four strides per trip with all their slab loads issued first (the rolled form paid one L2 round trip per stride)
+    constexpr int U = 4;
+    for (int i0 = tid * 4; i0 < a.V; i0 += 1024 * 4 * U) {
+        f32x4 v[U], w[U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float r = rbf(v[j]);          // logits are bf16 in the reference, compared as fp32
-            if (dump) dump[i + j] = r;
-            if (r > best) { best = r; bi = i + j; }   // strict > keeps the first maximum within a thread
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 4096, ic = i < a.V ? i : 0;
+            v[u] = *(const f32x4*)(lg + ic);
+            w[u] = *(const f32x4*)(lg + (a.ksplit > 1 ? ks_stride : 0) + ic);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 4096;
+            if (i >= a.V) break;
+            f32x4 t = v[u];
+            if (a.ksplit > 1) t += w[u];
+            for (int ks = 2; ks < a.ksplit; ++ks) t += *(const f32x4*)(lg + ks * ks_stride + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = rbf(t[j]);          // logits are bf16 in the reference, compared as fp32
+                if (dump) dump[i + j] = r;
+                if (r > best) { best = r; bi = i + j; }   // strict > keeps the first maximum within a thread
+            }
         }
     }
 #pragma unroll
