@@ -192,8 +192,35 @@ void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
 int g_gemm_force128 = 0;
 void set_gemm_force128(int v) { g_gemm_force128 = v; }
 
+static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s);
+static int device_cus() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t p; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    return n;
+}
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if (!g_gemm_force128 && gemm256_eligible(a, epi)) { launch_gemm256(a, epi, s); return; }
+    if (!g_gemm_force128 && gemm256_eligible(a, epi)) {
+        // Wave quantisation: a 256x256 tile occupies a whole CU, so (tiles mod CUs) small means a nearly empty extra round (prefill at
+        // M = 8320: 33 x 8 = 264 tiles on 256 CUs, two rounds for 1.03).  If cutting the ragged last <= 128 rows off saves a round, those
+        // rows go to the 128x128 kernel instead (same math per row; rows are independent in every epilogue but QKV+V^T).
+        const int cus = device_cus(), ntn = (a.N + 255) / 256, Mm = (a.M / 256) * 256, tail = a.M - Mm;
+        if (tail > 0 && tail <= 128 && Mm >= 512 && epi != EPI_QKV_VT && a.batch <= 1) {
+            const long full = (long)((a.M + 255) / 256) * ntn, main_tiles = (long)(Mm / 256) * ntn;
+            if ((main_tiles + cus - 1) / cus < (full + cus - 1) / cus) {
+                GemmArgs m = a; m.M = Mm;
+                launch_gemm256(m, epi, s);
+                GemmArgs t = a; t.M = tail; t.A = a.A + (long)Mm * a.lda; t.C = a.C + (long)Mm * a.ldc;
+                if (a.R) t.R = a.R + (long)Mm * a.ldr;
+                launch_gemm128(t, epi, s);
+                return;
+            }
+        }
+        launch_gemm256(a, epi, s);
+        return;
+    }
+    launch_gemm128(a, epi, s);
+}
+static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s) {
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), block(256);
     const size_t lds = 2 * STAGE_BYTES;

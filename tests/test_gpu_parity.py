@@ -84,7 +84,8 @@ def test_gemm_epilogues(eng, orc):
     assert np.all(np.abs(got - ref) <= ulp_tol(ref, 4) + 1e-3), np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (777, 384, 512, 1), (2048, 256, 1280, 2), (600, 1280, 320, 0), (520, 512, 256, 3)])
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (777, 384, 512, 1), (2048, 256, 1280, 2), (600, 1280, 320, 0), (520, 512, 256, 3),
+                                       (8320, 2048, 256, 2), (8300, 2048, 256, 3)])   # last two: ragged tail rows cut off to the 128x128 kernel
 def test_gemm256_path(eng, M, N, K, epi):
     """Shapes large enough for the 256x256 multi-phase kernel (M >= 512, N >= 256, K >= 256), ragged edges included."""
     import math
