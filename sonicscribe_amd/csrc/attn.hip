@@ -384,7 +384,8 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
             for (int u = 0; u < 4; ++u) { kf[u] = kfn[u]; vv[u] = vvn[u]; }
         }
     }
-    if (a.P && wid == 0) {                   // the token being decoded: its k / v are still in LDS (slice key 0 only)
+    if (a.P && wid == NW - 1) {              // the token being decoded: its k / v are still in LDS (slice key 0 only); the last wave has
+                                             // the fewest cached slices (slices go round-robin from wave 0), so it takes the extra step
 #pragma unroll
         for (int hs = 0; hs < 4; ++hs) kf[hs] = *(const bf16x8*)&s_q[GMAX][hs * 32 + g * 8];
 #pragma unroll
