@@ -86,8 +86,8 @@ def _cpu_reference_worker():
     enc_layer = (meas[(4, 2)][0] - meas[(2, 2)][0]) / 2.0
     dec_layer_pf = (meas[(2, 4)][0] - meas[(2, 2)][0]) / 2.0
     dec_layer_tok = (meas[(2, 4)][1] - meas[(2, 2)][1]) / 2.0
-    fixed_pf = meas[(2, 2)][0] - 2 * enc_layer - 2 * dec_layer_pf
-    fixed_tok = meas[(2, 2)][1] - 2 * dec_layer_tok
+    fixed_pf = max(meas[(2, 2)][0] - 2 * enc_layer - 2 * dec_layer_pf, 0.0)      # (timing noise can push the intercepts below zero)
+    fixed_tok = max(meas[(2, 2)][1] - 2 * dec_layer_tok, 0.0)
     first = fixed_pf + 32 * max(enc_layer, 0.0) + 28 * max(dec_layer_pf, 0.0)
     per_tok = fixed_tok + 28 * max(dec_layer_tok, 0.0)
     total = first + per_tok * (MAX_NEW - 1)
