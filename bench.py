@@ -170,7 +170,8 @@ def main():
     for _ in range(max(0, a.warmup - 1)):
         eng.rerun_staged()
     barrier()
-    stage = {"mel_ms": 0.0, "encoder_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "gemm_ms": 0.0, "gemm_launches": 0, "gemm_flops": 0.0}
+    stage = {"mel_ms": 0.0, "encoder_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "gemm_ms": 0.0, "gemm_launches": 0, "gemm_flops": 0.0,
+             "enc_gemm_ms": 0.0, "enc_gemm_flops": 0.0}
     t0 = time.perf_counter()
     for _ in range(a.steps):
         eng.rerun_staged()                                     # synchronous: returns after the stream drained
@@ -214,6 +215,11 @@ def main():
                          "traffic": traffic, "kernel": "gemm256_kernel<EPI_BIAS_GELU> (encoder fc1, [B*1500 x 1280] x [1280 x 5120])", "avg_launch_ms": gemm_ms,
                          "flops_per_launch": flops_per_launch, "launches_timed": stage["gemm_launches"]},
         }
+        if stage["enc_gemm_ms"] > 0:
+            # SURVEY.md 8d "encoder GEMM MFMA utilisation": all encoder-layer GEMM launches (QKV, o, fc1, fc2), HIP events around each
+            eg = stage["enc_gemm_flops"] / (stage["enc_gemm_ms"] * 1e-3) / 1e12
+            out["encoder_gemms"] = {"achieved": eg, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": eg / PEAK_BF16_TFLOPS,
+                                    "ms_per_step": stage["enc_gemm_ms"] / a.steps, "flops_per_step": stage["enc_gemm_flops"] / a.steps}
         if n_gpus == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_reference_baseline()

@@ -63,6 +63,8 @@ typedef struct {
     int32_t gemm_launches;  /* ... and how many launches that was */
     double gemm_flops;      /* algorithmic FLOPs of those launches */
     int32_t decode_steps;
+    float enc_gemm_ms;      /* summed duration of ALL encoder-layer GEMM launches (QKV, o, fc1, fc2) of the last run */
+    double enc_gemm_flops;  /* ... and their algorithmic FLOPs (SURVEY.md 8d "encoder GEMM MFMA utilisation") */
 } sonic_timings;
 
 /* ---- lifetime ---- */

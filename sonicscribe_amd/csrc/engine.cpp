@@ -326,7 +326,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     }
     if (hipHostMalloc((void**)&e->n_active_h, 64, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return bail(SONIC_ERR_HIP); }
     for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
-    e->gemm_ev.resize(2 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));
+    e->gemm_ev.resize(8 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));   // per layer: [start, end] of the QKV, o, fc1, fc2 GEMM launches
     for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
     A(build_constants(e));
 #undef A
@@ -564,11 +564,15 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
     for (int l = 0; l < d.enc_layers; ++l) {
         const EncLayerW& L = e->enc[l];
         launch_layernorm(e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, e->st);
+        const bool tev = (size_t)(8 * l + 7) < e->gemm_ev.size();
+        auto mark = [&](int i) { if (tev) (void)hipEventRecord(e->gemm_ev[8 * l + i], e->st); };
         {
             GemmArgs a{};
             a.A = e->ln; a.lda = C; a.W = L.wqkv; a.bias = L.bqkv; a.C = e->qk; a.ldc = 2L * C; a.M = M; a.N = 3 * C; a.K = C; a.batch = 1;
             a.Vt = e->vt; a.n_split = 2 * C; a.seg_T = T; a.vt_ld = e->Tp; a.vt_seg_stride = (long)C * e->Tp;
+            mark(0);
             launch_gemm(a, EPI_QKV_VT, e->st);
+            mark(1);
         }
         launch_rope_enc(e->qk, 2L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st);
         {
@@ -579,13 +583,17 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
             f.T = T; f.Hq = H; f.Hkv = H; f.scale = 1.0f / sqrtf((float)e->hd_e);
             launch_flash(f, 64, false, W, T, e->st);
         }
+        mark(2);
         gemm(e, EPI_BIAS_RESID, e->att, C, L.wo, L.bo, e->x, C, M, C, C, e->x, C);
+        mark(3);
         launch_layernorm(e->x, L.ln2w, L.ln2b, e->ln, M, C, d.enc_ln_eps, e->st);
-        const bool tev = (size_t)(2 * l + 1) < e->gemm_ev.size();
-        if (tev) (void)hipEventRecord(e->gemm_ev[2 * l], e->st);
+        mark(4);
         gemm(e, EPI_BIAS_GELU, e->ln, C, L.w1, L.b1, e->ff, d.enc_ff, M, d.enc_ff, C);
-        if (tev) { (void)hipEventRecord(e->gemm_ev[2 * l + 1], e->st); e->gemm_ev_used = l + 1; }
+        mark(5);
+        if (tev) e->gemm_ev_used = l + 1;
+        mark(6);
         gemm(e, EPI_BIAS_RESID, e->ff, d.enc_ff, L.w2, L.b2, e->x, C, M, C, d.enc_ff, e->x, C);
+        mark(7);
         if (enc_layers_out) {
             launch_bf16_to_f32(e->x, tap, (long)M * C, e->st);
             HIPC(e, hipStreamSynchronize(e->st));
@@ -844,9 +852,12 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     (void)hipEventElapsedTime(&t.decode_ms, e->ev[3], e->ev[4]);
     (void)hipEventElapsedTime(&t.total_ms, e->ev[0], e->ev[4]);
     for (int l = 0; l < e->gemm_ev_used; ++l) {
-        float ms = 0; (void)hipEventElapsedTime(&ms, e->gemm_ev[2 * l], e->gemm_ev[2 * l + 1]);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e->gemm_ev[8 * l + 4], e->gemm_ev[8 * l + 5]);
         t.gemm_ms += ms; t.gemm_launches += 1;
-        t.gemm_flops += 2.0 * (double)e->W * e->T * d.enc_ff * d.enc_d;
+        const double MT = (double)e->W * e->T, C = d.enc_d, F = d.enc_ff;
+        t.gemm_flops += 2.0 * MT * F * C;
+        for (int g = 0; g < 4; ++g) { float m2 = 0; (void)hipEventElapsedTime(&m2, e->gemm_ev[8 * l + 2 * g], e->gemm_ev[8 * l + 2 * g + 1]); t.enc_gemm_ms += m2; }
+        t.enc_gemm_flops += 2.0 * MT * C * (3 * C) + 2.0 * MT * C * C + 4.0 * MT * F * C;      // QKV, o, fc1, fc2
     }
     t.decode_steps = steps_done;
     e->greedy_calls = 1 + steps_done;

@@ -46,6 +46,7 @@ class SonicTimings(C.Structure):
     _fields_ = [
         ("mel_ms", C.c_float), ("encoder_ms", C.c_float), ("prefill_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
         ("gemm_ms", C.c_float), ("gemm_launches", C.c_int32), ("gemm_flops", C.c_double), ("decode_steps", C.c_int32),
+        ("enc_gemm_ms", C.c_float), ("enc_gemm_flops", C.c_double),
     ]
 
 
