@@ -6,9 +6,10 @@
 // logmel_power_kernel: one block = 32 consecutive frames of one segment.
 //   * PCM window (31*160+400 = 5360 samples) loaded once with coalesced int16 loads, converted to fp32 in LDS
 //     (frame stride skewed to 161 words so the 32 frame rows of an MFMA A-operand read hit 32 banks);
-//   * windowed real DFT as an exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32): frames[32 x 400] . twiddle[400 x bins];
+//   * windowed real DFT as an exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) on inputs folded by both symmetries of the real
+//     400-point transform (see the kernel): four 100-long sums for bins 0..100, bins 101..200 by mirroring;
 //     the twiddle matrix is never materialised: B-operand values come from 400-entry cos/sin tables in LDS,
-//     indexed (k*bin) mod 400 with an incremental index;
+//     indexed (n*bin) mod 400 with an incremental index;
 //   * power -> LDS, sparse triangular mel bank (CSR, <= ~27 taps per filter), log10, per-segment max via
 //     one ordered-int atomicMax per wave.
 //   Frames that lie entirely in the zero padding are skipped (their log-mel is the clamp floor).
@@ -29,11 +30,27 @@
 __device__ __forceinline__ int ord_enc(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord_dec(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
+// DFT with both symmetries of a real 400-point transform folded out before the GEMM (4x fewer MACs than the plain
+// frames[32 x 400] . twiddle[400 x 402] product).  With y = window * samples:
+//   E[n] = y[n] + y[400-n],  O[n] = y[n] - y[400-n]   (n = 1..199)            input symmetry of cos / sin
+//   Re X[k] = y[0] + (-1)^k y[200] + sum_n E[n] cos(2 pi k n / 400),   Im X[k] = - sum_n O[n] sin(2 pi k n / 400)
+//   cos(2 pi (200-k) n / 400) = (-1)^n cos(2 pi k n / 400),  sin(...) = -(-1)^n sin(...)          bin symmetry k <-> 200-k
+// so with the sums split by the parity of n,  Ae/Ao = sum over even/odd n of E cos,  Be/Bo = ... of O sin  (k = 0..100):
+//   Re X[k] = c + Ae + Ao,  Re X[200-k] = c + Ae - Ao,  |Im X[k]| = |Be + Bo|,  |Im X[200-k]| = |Be - Bo|,  c = y[0] + (-1)^k y[200].
+// Four 100-long sums for 101 bins: wave w owns bins 32w .. 32w+31, four fp32 MFMA accumulators, 50 k-steps of v_mfma_f32_32x32x2_f32.
+#define LM_FOLD_LD 401                 // per-frame stride of the folded vectors [4][100] (+1: 32 frame rows hit 32 banks)
+#define LM_DYN_LDS ((LM_SMP + 40 + LM_FT * LM_FOLD_LD + 3 * LM_NFFT + 2 * LM_FT) * 4)
+
 __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, long pcm_stride, const int* n_samples, LogmelConst lc,
                                                             float* logspec /* [B][n_frames][n_mels] */, int* segmax, int n_frames, int n_mels) {
-    __shared__ float smp[LM_SMP + 40];
-    __shared__ float s_win[LM_NFFT], s_cos[LM_NFFT], s_sin[LM_NFFT];
-    __shared__ float pw[LM_FT * LM_PWLD];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* smp = lds;                                   // [LM_SMP + 40] raw samples, frame stride skewed to 161
+    float* fold = smp + LM_SMP + 40;                    // [32][4][100]: E even-n, E odd-n, O even-n, O odd-n
+    float* s_win = fold + LM_FT * LM_FOLD_LD;
+    float* s_cos = s_win + LM_NFFT;
+    float* s_sin = s_cos + LM_NFFT;
+    float* s_y0 = s_sin + LM_NFFT;                      // [32] y[0], then [32] y[200]
+    float* pw = lds;                                    // [32][LM_PWLD] power spectrum, aliases smp/fold after the DFT
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * LM_FT;
     const int n_pad = n_frames * LM_HOP;
@@ -52,44 +69,64 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     }
     for (int i = tid; i < LM_NFFT; i += 256) { s_win[i] = lc.win[i]; s_cos[i] = lc.cos_t[i]; s_sin[i] = lc.sin_t[i]; }
     __syncthreads();
-
-    // ---- DFT: wave w owns bin blocks {w, w+4} (7 blocks of 32 bins cover 0..223 >= 201)
-    const int fi = lane & 31, kh = lane >> 5;
-    f32x16 re[2], im[2];
-    int idx[2], stp[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { re[q][r] = 0.f; im[q][r] = 0.f; }
-        const int bin = (wid + 4 * q) * 32 + fi;
-        idx[q] = (kh * bin) % LM_NFFT;
-        stp[q] = (2 * bin) % LM_NFFT;
-    }
-    const int nblk = (wid + 4 < 7) ? 2 : 1;
-    const int abase = fi * (LM_HOP + 1);
-    for (int s = 0; s < LM_NFFT / 2; ++s) {
-        const int k = 2 * s + kh;
-        const float av = smp[abase + k + k / LM_HOP] * s_win[k];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (q < nblk) {
-                const float cv = s_cos[idx[q]], sv = s_sin[idx[q]];
-                re[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cv, re[q], 0, 0, 0);
-                im[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sv, im[q], 0, 0, 0);
-                idx[q] += stp[q];
-                idx[q] = idx[q] >= LM_NFFT ? idx[q] - LM_NFFT : idx[q];
-            }
+    // fold: one (frame, n) pair per item, n = 1..199; n = 0 and n = 200 go to s_y0
+    for (int i = tid; i < LM_FT * 200; i += 256) {
+        const int f = i / 200, nn = i % 200;
+        const float* fs = smp + f * (LM_HOP + 1);
+        if (nn == 0) {
+            s_y0[f] = fs[0] * s_win[0];
+            s_y0[LM_FT + f] = fs[200 + 200 / LM_HOP] * s_win[200];
+            fold[f * LM_FOLD_LD + 0] = 0.f; fold[f * LM_FOLD_LD + 200] = 0.f;       // the j = 0 slots of the even-n vectors
+        } else {
+            const int m = LM_NFFT - nn;
+            const float ya = fs[nn + nn / LM_HOP] * s_win[nn], yb = fs[m + m / LM_HOP] * s_win[m];
+            const int cls = nn & 1, j = nn >> 1;
+            fold[f * LM_FOLD_LD + cls * 100 + j] = ya + yb;                          // E
+            fold[f * LM_FOLD_LD + 200 + cls * 100 + j] = ya - yb;                    // O
         }
     }
+    __syncthreads();
+
+    const int fi = lane & 31, kh = lane >> 5;
+    const int bin = wid * 32 + fi;
+    f32x16 ae, ao, be, bo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ae[r] = 0.f; ao[r] = 0.f; be[r] = 0.f; bo[r] = 0.f; }
+    int ie = (bin * (2 * kh)) % LM_NFFT, io = (bin * (2 * kh + 1)) % LM_NFFT;       // table index of n = 4s + 2kh (+1)
+    const int stp = (4 * bin) % LM_NFFT;
+    const float* fr = fold + fi * LM_FOLD_LD;
+    for (int s2 = 0; s2 < 50; ++s2) {
+        const int j = 2 * s2 + kh;
+        const float e0 = fr[j], e1 = fr[100 + j], o0 = fr[200 + j], o1 = fr[300 + j];
+        const float ce = s_cos[ie], se = s_sin[ie], co = s_cos[io], so = s_sin[io];
+        ae = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, ce, ae, 0, 0, 0);
+        ao = __builtin_amdgcn_mfma_f32_32x32x2f32(e1, co, ao, 0, 0, 0);
+        be = __builtin_amdgcn_mfma_f32_32x32x2f32(o0, se, be, 0, 0, 0);
+        bo = __builtin_amdgcn_mfma_f32_32x32x2f32(o1, so, bo, 0, 0, 0);
+        ie += stp; ie = ie >= LM_NFFT ? ie - LM_NFFT : ie;
+        io += stp; io = io >= LM_NFFT ? io - LM_NFFT : io;
+    }
+    // y[0], y[200] of this lane's 16 frames before pw overwrites the staging area
+    float cc[16];
+    const float sgn = (bin & 1) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        cc[r] = s_y0[f] + sgn * s_y0[LM_FT + f];
+    }
+    __syncthreads();                                    // every wave is done with fold / smp: pw may overwrite them
     // C/D map of the 32x32 MFMA: col = lane & 31 (bin), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (frame)
+    if (bin <= 100) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (q < nblk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int fr = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float mag = sqrtf(re[q][r] * re[q][r] + im[q][r] * im[q][r]);   // stft.abs() ** 2
-                pw[fr * LM_PWLD + (wid + 4 * q) * 32 + fi] = mag * mag;
+        for (int r = 0; r < 16; ++r) {
+            const int f = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float re1 = cc[r] + ae[r] + ao[r], im1 = be[r] + bo[r];
+            const float m1 = sqrtf(re1 * re1 + im1 * im1);                          // stft.abs() ** 2
+            pw[f * LM_PWLD + bin] = m1 * m1;
+            if (bin < 100) {
+                const float re2 = cc[r] + ae[r] - ao[r], im2 = be[r] - bo[r];
+                const float m2 = sqrtf(re2 * re2 + im2 * im2);
+                pw[f * LM_PWLD + 200 - bin] = m2 * m2;
             }
         }
     }
@@ -142,7 +179,9 @@ void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev
     const int n = max_samples < n_pad ? max_samples : n_pad;
     int t_live = (n + LM_NFFT / 2 + LM_HOP - 1) / LM_HOP; if (t_live > n_frames) t_live = n_frames;
     const int tiles = (t_live + LM_FT - 1) / LM_FT;
-    if (tiles > 0) hipLaunchKernelGGL(logmel_power_kernel, dim3(tiles, B), dim3(256), 0, s, pcm, pcm_stride, n_samples_dev, lc, logspec, segmax, n_frames, n_mels);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)logmel_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LM_DYN_LDS); attr_done = true; }
+    if (tiles > 0) hipLaunchKernelGGL(logmel_power_kernel, dim3(tiles, B), dim3(256), LM_DYN_LDS, s, pcm, pcm_stride, n_samples_dev, lc, logspec, segmax, n_frames, n_mels);
     const long tot = (long)n_frames * n_mels;
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3((tot + 255) / 256, B), dim3(256), 0, s, logspec, segmax, n_samples_dev, n_frames, n_mels, feats_fm, feats_f32);
 }
