@@ -215,6 +215,24 @@ def main():
                          "traffic": traffic, "kernel": "gemm256_kernel<EPI_BIAS_GELU> (encoder fc1, [B*1500 x 1280] x [1280 x 5120])", "avg_launch_ms": gemm_ms,
                          "flops_per_launch": flops_per_launch, "launches_timed": stage["gemm_launches"]},
         }
+        # the other two rooflines SURVEY.md 8d names, from the same timed region (stage times are HIP events on the engine stream):
+        #   mel front-end vs HBM: 1.408 MB of algorithmic bytes per 20 s segment (int16 PCM in, bf16 features out)
+        #   decode loop vs HBM: per step the decoder's bf16 weights + tied lm_head once, plus the KV cache of every sequence
+        PEAK_HBM_GBS = 8000.0
+        mel_bytes = B * (n_samples * 2 + 128 * 3000 * 2)
+        mel_gbs = mel_bytes / (stage["mel_ms"] / a.steps * 1e-3) / 1e9 if stage["mel_ms"] > 0 else 0.0
+        out["mel_frontend"] = {"bound": "hbm", "achieved": mel_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": mel_gbs / PEAK_HBM_GBS,
+                               "bytes_per_step": mel_bytes, "ms_per_step": stage["mel_ms"] / a.steps}
+        d_ = dims
+        qd, kvd = d_.dec_heads * d_.dec_head_dim, d_.dec_kv_heads * d_.dec_head_dim
+        w_bytes = 2 * (d_.dec_layers * (d_.dec_d * (qd + 2 * kvd) + qd * d_.dec_d + 3 * d_.dec_d * d_.dec_ff) + d_.vocab * d_.dec_d)
+        n_dec = max(1, a.max_new - 1)                                  # token 1 comes out of prefill
+        avg_ctx = len(prompt) + (n_dec + 1) / 2.0
+        kv_bytes = B * d_.dec_layers * 2 * kvd * 2 * avg_ctx
+        dec_ms = stage["decode_ms"] / a.steps / n_dec
+        dec_gbs = (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        out["decode_loop"] = {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dec_gbs / PEAK_HBM_GBS,
+                              "bytes_per_token_step": w_bytes + kv_bytes, "ms_per_token_step": dec_ms, "token_steps": n_dec}
         if stage["enc_gemm_ms"] > 0:
             # SURVEY.md 8d "encoder GEMM MFMA utilisation": all encoder-layer GEMM launches (QKV, o, fc1, fc2), HIP events around each
             eg = stage["enc_gemm_flops"] / (stage["enc_gemm_ms"] * 1e-3) / 1e12
