@@ -217,6 +217,23 @@ def test_logmel_vs_golden_and_oracle(eng, orc, golden_dir):
     assert np.allclose(feats[len(gold) + 1], -1.5, atol=1e-5) and mask[len(gold) + 1].sum() == 0   # empty input
 
 
+def test_logmel_length_sweep_vs_oracle(eng, orc):
+    """Segment lengths on and around every boundary the kernel cares about: hop (160), window (400), the 32-frame block (5120), the
+    reflect padding, the 30 s cap - plus full-scale and alternating-sign inputs (the folded DFT adds and subtracts mirrored samples)."""
+    lens = [1, 2, 159, 160, 161, 199, 200, 201, 399, 400, 401, 5119, 5120, 5121, 5279, 31999, 32000, 479839, 479999, 480000]
+    segs = [synth.synth_pcm(300 + i, n) for i, n in enumerate(lens)]
+    sq = np.full(20000, 32767, np.int16); sq[1::2] = -32768
+    segs.append(sq)                                               # Nyquist square wave at full scale
+    segs.append(np.full(7777, -32768, np.int16))                  # DC at full scale
+    for lo in range(0, len(segs), 8):
+        part = segs[lo:lo + 8]
+        feats, mask = eng.logmel(part)
+        for i, pcm in enumerate(part):
+            ref, m2 = orc.logmel(pcm)
+            assert np.array_equal(mask[i], m2), len(pcm)
+            assert np.abs(feats[i] - ref).max() < 1e-3, (len(pcm), float(np.abs(feats[i] - ref).max()))
+
+
 # ------------------------------------------------------------------------------------------ encoder + full path (TINY)
 def _golden_case(golden_dir, si, tag="bf16"):
     g = np.load(os.path.join(golden_dir, f"tiny_{tag}.npz"))
