@@ -441,6 +441,37 @@ def test_fullwidth_layer_vs_oracle(orc):
     e.close()
 
 
+@pytest.mark.parametrize("R", [5, 17, 32])
+def test_fused_decode_rows_vs_unfused(R):
+    """Fused decode kernels (o_proj + residual + partials, gate/up with in-LDS RMSNorm) at ragged row counts: full decoder width,
+    two layers, R sequences of different prompt lengths, against the slab + add/RMSNorm path that the skinny-GEMM tests pin."""
+    from dataclasses import replace
+    from sonicscribe_amd.engine import Engine
+    d = replace(spec.FULL, enc_layers=1, dec_layers=2, vocab=1024, audio_token_id=1000, eos_ids=())
+    e = Engine(d, 0, max_batch=32, max_ctx=384)
+    e.load_synthetic(11)
+    lens = [16000 * (1 + (i % 5)) + 37 * i for i in range(R)]                 # 1..5 s: 12..62 audio tokens
+    segs = [synth.synth_pcm(400 + i, n) for i, n in enumerate(lens)]
+    prompts = [[1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(n)) + [7, 301, 302, 303, 9, 11][: 3 + i % 4]
+               for i, n in enumerate(lens)]
+    n_new = 6
+    ids_f, log_f = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
+    ids_g, _ = e.transcribe_batch(segs, prompts, [n_new] * R)                  # graph replay of the same fused path
+    e.set_option("no_fused_gu", 1)
+    try:
+        ids_u, log_u = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
+    finally:
+        e.set_option("no_fused_gu", 0)
+    same = 0
+    for i in range(R):
+        assert np.array_equal(ids_f[i], ids_g[i])
+        if np.array_equal(ids_f[i], ids_u[i]):
+            same += 1
+            assert np.abs(log_f[:, i] - log_u[:, i]).max() <= 4 * 2.0 ** -6, i
+    assert same >= R - 1          # a near-tie may flip one history between the two summation orders, not more
+    e.close()
+
+
 def test_checkpoint_loader_equals_synthetic(tmp_path):
     """ASRModel(checkpoint_dir): config.json + bf16 safetensors in the on-disk HF layout -> same tokens as the device-side generator."""
     from sonicscribe_amd import weights
