@@ -120,18 +120,21 @@ template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool
     *p = (Tt*)q;
     return SONIC_OK;
 }
-// Decode-step activation buffers (x, slabs, partials: a few MB written by one kernel and read by the next) are allocated uncached
-// (MTYPE UC): they then never sit dirty in an XCD's L2, which shortens every kernel boundary of the decode graph a little
-// (measured: -0.1 .. -0.2 us on each of the 171 kernels of a token step, 208.1 -> 204.8 ms per 149 steps).  Falls back to hipMalloc.
-template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) {
+// Uncached (MTYPE UC) allocations for everything the decode graph streams exactly once per token step or hands from one kernel to the
+// next: the per-step activation buffers (x, slabs, partials - a few MB written by one kernel and read by the next), the fragment-tiled
+// weight copies and the KV cache.  Nothing of theirs then sits in (or has to be written back from) an XCD's L2 at a kernel boundary,
+// and the L2 keeps the X images the blocks of a kernel share.  Measured on the 149-step decode of the bench: 208.1 -> 204.8 ms with
+// the activation buffers alone, a further -1.8 ms with the KV cache and -0.6 ms with the tiled weights.  Falls back to hipMalloc.
+template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
     void* q = nullptr;
     const size_t bytes = (n ? n : 1) * sizeof(Tt);
-    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return dalloc(e, p, n); }
+    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return dalloc(e, p, n, zero); }
     e->allocs.push_back(q);
-    HIPC(e, hipMemsetAsync(q, 0, bytes, e->st));
+    if (zero) HIPC(e, hipMemsetAsync(q, 0, bytes, e->st));
     *p = (Tt*)q;
     return SONIC_OK;
 }
+template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) { return dalloc_uc(e, p, n, true); }
 #define TRY(x) do { int _s = (x); if (_s != SONIC_OK) return _s; } while (0)
 
 static inline float bf16_round_host(float x) {
@@ -320,7 +323,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->dx, tc * d.dec_d)); A(dalloc(e, &e->dhn, tc * d.dec_d)); A(dalloc(e, &e->dqkv, tc * e->qkvN));
     A(dalloc(e, &e->dq, tc * e->QD)); A(dalloc(e, &e->datt, tc * e->QD)); A(dalloc(e, &e->dact, tc * d.dec_ff));
     const size_t kvn = (size_t)d.dec_layers * Bm * d.dec_kv_heads * max_ctx * d.dec_head_dim;
-    A(dalloc(e, &e->Kc, kvn)); A(dalloc(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
+    A(dalloc_uc(e, &e->Kc, kvn)); A(dalloc_uc(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
     long mx = 2L * d.dec_ff; if (e->qkvN > mx) mx = e->qkvN; if (d.dec_d > mx) mx = d.dec_d;
     e->slabN = mx;
     A(dalloc_act(e, &e->ssq, (size_t)256 * 64));
@@ -511,7 +514,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         e->weight_bytes += (int64_t)g->n * 4;
         TRY(keep_raw(e, p + "mlp.down_proj.weight", &L.wdown));
         auto tiled = [&](const bf16_t* w, bf16_t** out, int N, int K) -> int {
-            TRY(dalloc(e, out, (size_t)N * K, false));
+            TRY(dalloc_uc(e, out, (size_t)N * K, false));
             launch_tile_weights(w, *out, N, K, e->st);
             e->weight_bytes += (int64_t)N * K * 2;
             return SONIC_OK;
@@ -520,12 +523,12 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
         L.wgu_t8 = nullptr;
         if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave)
-            TRY(dalloc(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
+            TRY(dalloc_uc(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
             launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
             e->weight_bytes += (int64_t)2 * d.dec_ff * d.dec_d * 2;
         }
     }
-    TRY(dalloc(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
+    TRY(dalloc_uc(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
     launch_tile_weights(e->embed, e->embed_t, d.vocab, d.dec_d, e->st);
     e->weight_bytes += (int64_t)d.vocab * d.dec_d * 2;
     TRY(to_f32(e, lm + "norm.weight", &e->dec_nw));
