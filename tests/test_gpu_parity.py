@@ -317,6 +317,40 @@ def test_transcribe_vs_golden(eng, golden_dir):
                                      f"rerun-vs-golden {rerun_ok:.4f}; logmel diff per seg {dmel}; embeds(B=2) diff {demb}; embeds(B=1, seg0) diff {demb1:.4f}; taps {tapinfo}; taps-run-vs-first {float(np.abs(logits3 - logits).max()):.4f}")
 
 
+def test_random_cases_vs_oracle(eng, orc):
+    """Seeded random sweep at TINY dimensions: segment lengths from 0.2 s to 30 s, prompt prefixes / suffixes of different lengths,
+    different budgets, mixed in batches of 6 - every row against the bf16 oracle (token IDs while the reference margin allows, logits
+    while the histories agree)."""
+    d = spec.TINY
+    om = orc.Model(d, synth.synth_state_dict(d, 20260128, bf16=True), bf16=True)
+    rng = np.random.default_rng(77)
+    tol = 4 * 2.0 ** -6
+    checked = 0
+    for batch in range(3):
+        lens = [int(rng.integers(3200, 480000)) for _ in range(6)]
+        segs = [synth.synth_pcm(500 + batch * 6 + i, n) for i, n in enumerate(lens)]
+        prompts, budgets = [], []
+        for n in lens:
+            pre = [1] + [int(x) for x in rng.integers(2, 900, int(rng.integers(1, 6)))]
+            suf = [int(x) for x in rng.integers(2, 900, int(rng.integers(1, 8)))]
+            prompts.append(pre + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(n)) + suf)
+            budgets.append(int(rng.integers(1, 9)))
+        ids, logits = eng.transcribe_batch(segs, prompts, budgets, want_logits=True)
+        for i, pcm in enumerate(segs):
+            feats, mask = orc.logmel(pcm)
+            r = om.transcribe(feats, int(mask.sum()), prompts[i], budgets[i])
+            ref_ids, ref_logits = np.asarray(r["new_ids"]), np.asarray(r["step_logits"])
+            assert len(ids[i]) == budgets[i]
+            for st in range(budgets[i]):
+                srt = np.sort(ref_logits[st]); margin = srt[-1] - srt[-2]
+                assert np.abs(logits[st, i] - ref_logits[st]).max() <= tol, (batch, i, st)
+                checked += 1
+                if margin <= 2 * tol or ids[i][st] != ref_ids[st]:
+                    assert margin <= 2 * tol, (batch, i, st, ids[i], ref_ids)      # a flip is only legitimate on a near-tie
+                    break
+    assert checked >= 30
+
+
 def test_batch_matches_single_and_graph_matches_eager(eng, golden_dir):
     g = np.load(os.path.join(golden_dir, "tiny_bf16.npz"))
     segs = [synth.synth_pcm(20 + i, n) for i, n in enumerate((80000, 320000, 20480, 123457))]
