@@ -311,7 +311,35 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
     }
     __syncthreads();
     const bf16_t* row = a.table + (long)s_tok * a.d;
-    for (int c = tid; c < (a.d >> 3); c += 1024) *(bf16x8*)(a.x + (long)b * a.d + c * 8) = *(const bf16x8*)(row + c * 8);
+    if (!a.y || (a.d >> 3) > 1024) {
+        for (int c = tid; c < (a.d >> 3); c += 1024) *(bf16x8*)(a.x + (long)b * a.d + c * 8) = *(const bf16x8*)(row + c * 8);
+        return;
+    }
+    // next step's input row and, in the same pass, the first decoder layer's input RMSNorm of it (modeling_llama.py:60-65, :306):
+    // one launch less per token step
+    const int c = tid, nv = a.d >> 3;
+    bf16x8 xv;
+    float ss = 0.f;
+    if (c < nv) {
+        xv = *(const bf16x8*)(row + c * 8);
+        *(bf16x8*)(a.x + (long)b * a.d + c * 8) = xv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = bf2f(xv[j]); ss += f * f; }
+    }
+    ss = wave_sum(ss);
+    __syncthreads();                         // sv is reused below
+    if (lane == 0) sv[wid] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += sv[w];
+    const float r = 1.0f / sqrtf(tot / a.d + a.norm_eps);
+    if (c < nv) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(a.norm_w[c * 8 + j] * rbf(bf2f(xv[j]) * r));
+        *(bf16x8*)(a.y + (long)b * a.d + c * 8) = o;
+    }
 }
 
 // ---------------------------------------------------------------- misc

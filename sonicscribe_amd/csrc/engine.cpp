@@ -656,6 +656,7 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     g.max_new = e->max_new_d; g.n_active = e->n_active; g.n_eos = d.n_eos; g.pad_id = d.n_eos > 0 ? d.eos[0] : 0;
     for (int i = 0; i < d.n_eos; ++i) g.eos[i] = d.eos[i];
     g.logits_dump = dump ? e->dump : nullptr; g.dump_stride_step = (long)R * d.vocab; g.step_counter = dump ? e->step_ctr : nullptr;
+    g.norm_w = e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
     return g;
 }
 
@@ -664,7 +665,7 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
     const sonic_dims& d = e->d;
     const int D = d.dec_d, mpad = ((R + 15) / 16) * 16;
     int ks;
-    launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st);
+    if (D > 8192) launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st);   // else: done by the greedy kernel of the previous step
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
