@@ -79,7 +79,7 @@ struct sonic_engine {
     std::map<int, hipGraphExec_t> graphs;
 
     // timing
-    hipEvent_t ev[6]{};      // stage boundaries 0..4, 5 = early-exit poll
+    hipEvent_t ev[5]{};
     std::vector<hipEvent_t> gemm_ev;
     int gemm_ev_used = 0;
     sonic_timings tim{};
@@ -848,17 +848,13 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
         } else gx = it->second;
     }
     int steps_done = 0;
-    bool poll_pending = false;
     for (int s = 1; s < hp.max_steps; ++s) {
         if (gx) HIPC(e, hipGraphLaunch(gx, e->st)); else decode_step(e, R, want_logits);
         ++steps_done;
         if ((s & 15) == 0 && s + 1 < hp.max_steps) {   // ragged termination: stop once every row hit EOS / its budget
-            // pipelined poll: the count copied 16 steps ago is examined while the GPU keeps working on the steps queued since, so the
-            // stream never drains in the loop (finished rows only emit padding, a late stop costs idle steps, not results)
-            if (poll_pending) { HIPC(e, hipEventSynchronize(e->ev[5])); if (*e->n_active_h <= 0) break; }
             HIPC(e, hipMemcpyAsync(e->n_active_h, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
-            HIPC(e, hipEventRecord(e->ev[5], e->st));
-            poll_pending = true;
+            HIPC(e, hipStreamSynchronize(e->st));
+            if (*e->n_active_h <= 0) break;
         }
     }
     (void)hipEventRecord(e->ev[4], e->st);
