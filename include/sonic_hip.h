@@ -104,6 +104,10 @@ int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets,
 int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                      const int32_t* max_new, int want_step_logits);
 int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+/* Teacher forcing (parity tests; mirrors the oracle's force_ids): while set, token n of request r is ids[r * ld + n] instead of
+ * the argmax -- logits are still computed and returned, EOS / budget rules apply to the forced token (HF:generation/utils.py:2925-2936
+ * with next_tokens replaced).  ids == NULL clears.  Forced runs use the eager decode loop. */
+int sonic_set_forced_ids(sonic_engine* e, const int32_t* ids, int R, int ld);
 int sonic_get_timings(sonic_engine* e, sonic_timings* out);
 int sonic_synchronize(sonic_engine* e);
 
@@ -112,6 +116,9 @@ int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float
                     int M, int N, int K, int epi);
 int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K);
 int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K);
+/* the argmax + greedy controller on caller-provided lm_head partial slabs [ksplit][mpad][V] fp32: token picked per row
+ * (first maximum of the bf16-rounded slab sum) and optionally the bf16 logits [B][V] it compared */
+int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit, int mpad, int V, int B, int32_t* tok_out, float* logits_out);
 int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
                          int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal);
 int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
@@ -124,7 +131,8 @@ int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int it
 /* debug read-back of an internal bf16 activation buffer as fp32 ("prefill_tap" with index = 0 (embeddings) .. dec_layers,
  * "pe", "dx", "dqkv", "dq", "datt", "dact", "enc_x"); tests / diagnostics only */
 int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
-/* tuning knobs for experiments ("skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu") */
+/* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
+ * "no_graph" (eager decode loop), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*) */
 int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus

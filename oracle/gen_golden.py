@@ -19,7 +19,14 @@ Fixture families (small files, committed):
                    prefill / per-step logits, greedy token ids, top-1/top-2 margins
   tiny_bf16.npz    same in bf16 (the reference's `mode="native"` dtype)
 
-Usage:  python oracle/gen_golden.py [--out tests/golden]
+  tiny_forced_*.npz  the same model decoding under TEACHER FORCING (a LogitsProcessor pins each step's token to a seeded, varying id
+                   sequence): raw per-step logits of generate()'s incremental decode.  The free-running trajectories above
+                   collapse to one repeated id with random weights, which cannot see a stale-token / position bug.
+  tiny_multi_*.npz   one 35 s request = two 30 s windows in one prompt (processing_glmasr.py:136-157)
+  full_*.npz       F-full: FULL-WIDTH GLM-ASR-Nano layers (d=1280/5120/20 heads; 2048/6144, GQA 16:4; vocab 59264) at
+                   depth 1+1, one 20 s segment, weights from the portable generator: sampled slices + checksums per stage
+
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--only mel|tiny|forced|multi|full]
 """
 from __future__ import annotations
 
@@ -90,9 +97,9 @@ def gen_mel(out_dir: str):
     np.savez_compressed(os.path.join(out_dir, "normalise.npz"), x=x, q=normalise_to_int16(x))
 
 
-def build_tiny(dtype: torch.dtype):
+def build_tiny(dtype: torch.dtype, d=None, seed=SEED):
     from transformers import GlmAsrConfig, GlmAsrForConditionalGeneration
-    d = spec.TINY
+    d = d or spec.TINY
     cfg = GlmAsrConfig(
         audio_config=dict(hidden_size=d.enc_d, intermediate_size=d.enc_ff, num_hidden_layers=d.enc_layers,
                           num_attention_heads=d.enc_heads, num_mel_bins=d.n_mels),
@@ -103,7 +110,7 @@ def build_tiny(dtype: torch.dtype):
         audio_token_id=d.audio_token_id,
     )
     model = GlmAsrForConditionalGeneration(cfg)
-    sd = synth.synth_state_dict(d, SEED, bf16=(dtype == torch.bfloat16))
+    sd = synth.synth_state_dict(d, seed, bf16=(dtype == torch.bfloat16))
     tsd = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
     tsd["lm_head.weight"] = tsd["model.language_model.embed_tokens.weight"]
     missing, unexpected = model.load_state_dict(tsd, strict=False)
@@ -184,6 +191,148 @@ def gen_tiny(out_dir: str, dtype: torch.dtype, tag: str, n_new: int = 24):
     np.savez_compressed(os.path.join(out_dir, f"tiny_{tag}.npz"), **rec)
 
 
+class ForceTokens:
+    """LogitsProcessor: step n of the (single) sequence may only pick ids[n] -- teacher forcing through generate() itself, so the
+    logits recorded with output_logits=True are those of the reference's incremental decode loop (generation/utils.py:2876-2943)."""
+
+    def __init__(self, ids, prompt_len):
+        self.ids, self.P = list(map(int, ids)), prompt_len
+
+    def __call__(self, input_ids, scores):
+        step = input_ids.shape[1] - self.P
+        out = torch.full_like(scores, float("-inf"))
+        out[:, self.ids[step]] = 0.0
+        return out
+
+
+def forced_ids_for(d, rng, n):
+    bad = set(d.eos_ids) | {d.audio_token_id}
+    out = []
+    while len(out) < n:
+        t = int(rng.integers(2, d.vocab))
+        if t not in bad:
+            out.append(t)
+    return np.asarray(out, np.int32)
+
+
+def run_forced(model, d, dtype, feats, mask, ids, force):
+    from transformers import LogitsProcessorList
+    input_ids = torch.tensor([ids], dtype=torch.long)
+    feats_t = torch.from_numpy(np.ascontiguousarray(feats)).to(dtype)
+    if feats_t.dim() == 2:
+        feats_t = feats_t[None]
+    mask_t = torch.from_numpy(np.ascontiguousarray(mask)).long()
+    if mask_t.dim() == 1:
+        mask_t = mask_t[None]
+    with torch.no_grad():
+        gen = model.generate(input_ids=input_ids, input_features=feats_t, input_features_mask=mask_t,
+                             attention_mask=torch.ones_like(input_ids), max_new_tokens=len(force), do_sample=False,
+                             logits_processor=LogitsProcessorList([ForceTokens(force, len(ids))]),
+                             return_dict_in_generate=True, output_logits=True)
+    got = gen.sequences[0, len(ids):].numpy().astype(np.int32)
+    assert np.array_equal(got, force), (got, force)
+    return torch.stack([l[0] for l in gen.logits]).float().numpy()
+
+
+def gen_forced(out_dir: str, dtype: torch.dtype, tag: str, n_new: int = 24):
+    d = spec.TINY
+    fe = feature_extractor()
+    model, cfg = build_tiny(dtype)
+    rng = np.random.default_rng(4242)
+    rec = {"seed": SEED, "n_new": n_new}
+    for si, (i, n) in enumerate([(10, 80000), (11, 320000)]):
+        pcm = synth.synth_pcm(i, n)
+        feats, mask = mel_case(fe, pcm)
+        n_audio = spec.audio_token_count(int(mask.sum()))
+        ids = PROMPT_PREFIX + [d.audio_token_id] * n_audio + PROMPT_SUFFIX
+        force = forced_ids_for(d, rng, n_new)
+        logits = run_forced(model, d, dtype, feats, mask, ids, force)
+        p = f"s{si}_"
+        rec[p + "seg_index"], rec[p + "n_samples"] = i, n
+        rec[p + "prompt_ids"] = np.asarray(ids, np.int32)
+        rec[p + "force_ids"] = force
+        rec[p + "step_logits"] = logits
+        print(f"forced[{tag}] seg{si}: P={len(ids)} force={force[:6]}... logit range=[{logits.min():.2f},{logits.max():.2f}] "
+              f"argmax per step={logits.argmax(1)[:8]}")
+    np.savez_compressed(os.path.join(out_dir, f"tiny_forced_{tag}.npz"), **rec)
+
+
+def gen_multi(out_dir: str, dtype: torch.dtype, tag: str, n_new: int = 8):
+    """35 s of audio -> windows of 30 s + 5 s in ONE request; processor-side counting restated from processing_glmasr.py:136-176."""
+    d = spec.TINY
+    fe = feature_extractor()
+    model, cfg = build_tiny(dtype)
+    pcm = synth.synth_pcm(40, 560000)
+    wins = [pcm[:480000], pcm[480000:]]
+    fm = [mel_case(fe, w) for w in wins]
+    feats = np.stack([f for f, _ in fm]); mask = np.stack([m for _, m in fm])
+    total_frames = int(mask.sum())
+    n_audio = spec.audio_token_count(total_frames)            # the processor counts on the SUMMED frames (:166-169)
+    ids = [1] + [d.audio_token_id] * n_audio + [7]
+    rng = np.random.default_rng(99)
+    force = forced_ids_for(d, rng, n_new)
+    logits = run_forced(model, d, dtype, feats, mask, ids, force)
+    np.savez_compressed(os.path.join(out_dir, f"tiny_multi_{tag}.npz"), seg_index=40, n_samples=560000, prompt_ids=np.asarray(ids, np.int32),
+                        n_audio=n_audio, frames=mask.sum(-1).astype(np.int32), force_ids=force, step_logits=logits)
+    print(f"multi[{tag}]: windows frames={mask.sum(-1)} n_audio={n_audio} logits range=[{logits.min():.2f},{logits.max():.2f}]")
+
+
+FULL_SEED = 7
+
+
+def full_dims():
+    from dataclasses import replace
+    return replace(spec.FULL, enc_layers=1, dec_layers=1)
+
+
+def gen_full(out_dir: str, dtype: torch.dtype, tag: str, n_new: int = 4):
+    d = full_dims()
+    fe = feature_extractor()
+    model, cfg = build_tiny(dtype, d=d, seed=FULL_SEED)
+    pcm = synth.synth_pcm(60, 320000)
+    feats, mask = mel_case(fe, pcm)
+    n_audio = spec.audio_token_count(int(mask.sum()))
+    ids = PROMPT_PREFIX + [d.audio_token_id] * n_audio + PROMPT_SUFFIX
+    acts = {}
+
+    def save(name):
+        def fn(_m, _inp, out):
+            o = out[0] if isinstance(out, tuple) else out
+            if hasattr(o, "last_hidden_state"):
+                o = o.last_hidden_state
+            acts[name] = o.detach().float().numpy()
+        return fn
+    enc = model.model.audio_tower
+    hooks = [enc.conv2.register_forward_hook(save("conv2")), enc.layers[0].register_forward_hook(save("enc_layer0")),
+             enc.register_forward_hook(save("enc_out")), model.model.language_model.layers[0].register_forward_hook(save("dec_layer0"))]
+    input_ids = torch.tensor([ids], dtype=torch.long)
+    with torch.no_grad():
+        fw = model(input_ids=input_ids, input_features=torch.from_numpy(feats)[None].to(dtype), input_features_mask=torch.from_numpy(mask)[None].long(),
+                   attention_mask=torch.ones_like(input_ids))
+    for h in hooks:
+        h.remove()
+    rng = np.random.default_rng(2026)
+    force = forced_ids_for(d, rng, n_new)
+    logits = run_forced(model, d, dtype, feats, mask, ids, force)
+
+    def stat(a):
+        a = a.astype(np.float64)
+        return np.asarray([a.sum(), (a * a).sum(), np.abs(a).max()])
+    emb = fw.audio_hidden_states.float().numpy()
+    rec = dict(seed=FULL_SEED, seg_index=60, n_samples=320000, prompt_ids=np.asarray(ids, np.int32), n_audio=n_audio, force_ids=force,
+               conv2_sub=acts["conv2"][0][::40, ::53], conv2_stat=stat(acts["conv2"][0]),
+               enc_layer0_sub=acts["enc_layer0"][0][::97], enc_layer0_stat=stat(acts["enc_layer0"][0]),
+               enc_out_sub=acts["enc_out"][0][::97], enc_out_stat=stat(acts["enc_out"][0]),
+               audio_embeds_sub=emb[::25], audio_embeds_stat=stat(emb),
+               dec_layer0_sub=acts["dec_layer0"][0][::37], dec_layer0_stat=stat(acts["dec_layer0"][0]),
+               step_logits_sub=logits[:, ::16], step_logits_stat=np.stack([stat(l) for l in logits]),
+               step_argmax=logits.argmax(1).astype(np.int32), step_max=logits.max(1),
+               step_top2_margin=np.asarray([np.sort(l)[-1] - np.sort(l)[-2] for l in logits], np.float32),
+               step_logits_forced=np.asarray([logits[s, force[s]] for s in range(n_new)], np.float32))
+    np.savez_compressed(os.path.join(out_dir, f"full_{tag}.npz"), **rec)
+    print(f"full[{tag}]: P={len(ids)} logits range=[{logits.min():.2f},{logits.max():.2f}] argmax={logits.argmax(1)} margins={rec['step_top2_margin']}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -197,6 +346,15 @@ def main():
     if a.only in ("", "tiny"):
         gen_tiny(a.out, torch.float32, "fp32")
         gen_tiny(a.out, torch.bfloat16, "bf16")
+    if a.only in ("", "forced"):
+        gen_forced(a.out, torch.float32, "fp32")
+        gen_forced(a.out, torch.bfloat16, "bf16")
+    if a.only in ("", "multi"):
+        gen_multi(a.out, torch.float32, "fp32")
+        gen_multi(a.out, torch.bfloat16, "bf16")
+    if a.only in ("", "full"):
+        gen_full(a.out, torch.float32, "fp32")
+        gen_full(a.out, torch.bfloat16, "bf16")
 
 
 if __name__ == "__main__":

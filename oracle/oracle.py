@@ -57,6 +57,8 @@ def lib():
         _lib.oracle_model_destroy.argtypes = [C.c_void_p]
         _lib.oracle_transcribe.restype = C.c_int
         _lib.oracle_transcribe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(Outputs)]
+        _lib.oracle_transcribe_multi.restype = C.c_int
+        _lib.oracle_transcribe_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(Outputs)]
         _lib.oracle_audio_features.restype = C.c_int
         _lib.oracle_audio_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Outputs)]
         _lib.oracle_logmel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -135,12 +137,16 @@ class Model:
         except Exception:
             pass
 
-    def transcribe(self, feats: np.ndarray, n_valid_frames: int, prompt, max_new: int, want=(), force_ids=None):
+    def transcribe(self, feats: np.ndarray, n_valid_frames, prompt, max_new: int, want=(), force_ids=None):
+        """feats [n_mels][n_frames] with an int n_valid_frames, or (multi-window request) [W][n_mels][n_frames] with a list."""
         d = self.dims
         feats = np.ascontiguousarray(feats, dtype=np.float32)
+        nv = np.ascontiguousarray(np.atleast_1d(n_valid_frames), dtype=np.int32)
+        W = int(nv.size)
+        assert feats.size == W * d.n_mels * d.n_frames
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         P = prompt.size
-        n_audio_max = d.enc_T // d.merge
+        n_audio_max = W * (d.enc_T // d.merge)
         bufs = {
             "conv1": np.zeros((d.enc_d, d.n_frames), np.float32) if "conv1" in want else None,
             "conv2": np.zeros((d.enc_d, d.enc_T), np.float32) if "conv2" in want else None,
@@ -160,7 +166,7 @@ class Model:
         if force_ids is not None:
             force_ids = np.ascontiguousarray(force_ids, dtype=np.int32)
             o.force_ids = force_ids.ctypes.data
-        rc = lib().oracle_transcribe(self.h, _p(feats), int(n_valid_frames), _p(prompt), P, int(max_new), C.byref(o))
+        rc = lib().oracle_transcribe_multi(self.h, _p(feats), _p(nv), W, _p(prompt), P, int(max_new), C.byref(o))
         if rc != 0:
             raise ValueError("Audio features and audio tokens do not match")
         res = {k: v for k, v in bufs.items() if v is not None}

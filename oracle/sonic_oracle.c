@@ -92,6 +92,7 @@ static uint64_t fnv1a64(const char *s) {
 void oracle_synth_fill(uint64_t seed, const char *name, long n, float scale, float offset, int bf16, float *out) {
     const uint64_t G = 0x9E3779B97F4A7C15ULL;
     uint64_t key = mix64(seed * G + fnv1a64(name));
+    #pragma omp parallel for schedule(static) if (n > (1L << 16))
     for (long i = 0; i < n; ++i) {
         uint64_t z = mix64(key + (uint64_t)(i + 1) * G);
         int32_t bits = (int32_t)(z >> 40);
@@ -440,12 +441,17 @@ static void lm_head(const oracle_model *m, const float *x /* [dec_d] */, float *
 }
 static int argmax_first(const float *x, int n) { int b = 0; for (int i = 1; i < n; ++i) if (x[i] > x[b]) b = i; return b; }
 
-/* Full path for one segment.  Returns 0, or -1 when placeholders != audio rows (modeling_glmasr.py:426-429). */
-int oracle_transcribe(const oracle_model *m, const float *feats, int n_valid_frames, const int *prompt, int P,
-                      int max_new, oracle_outputs *o) {
+/* Full path for one request of W >= 1 windows (HF:processing_glmasr.py:136-157 cuts audio longer than 30 s into windows; the
+ * encoder runs per window and the kept rows of all windows are concatenated, modeling_glmasr.py:380-408).  feats: [W][n_mels][n_frames].
+ * Per-stage taps (conv*, enc_layers, enc_out) record the LAST window.  Returns 0, or -1 when placeholders != audio rows (:426-429). */
+int oracle_transcribe_multi(const oracle_model *m, const float *feats, const int *n_valid_frames, int W, const int *prompt, int P,
+                            int max_new, oracle_outputs *o) {
     const oracle_dims *d = &m->d; int D = d->dec_d, KD = d->dec_kv_heads * d->dec_head_dim;
-    float *emb = (float *)malloc(sizeof(float) * (long)(d->enc_T / d->merge) * D);
-    int n_audio = oracle_audio_features(m, feats, n_valid_frames, emb, o);
+    int Tm = d->enc_T / d->merge;
+    float *emb = (float *)malloc(sizeof(float) * (long)W * Tm * D);
+    int n_audio = 0;
+    for (int w = 0; w < W; ++w)
+        n_audio += oracle_audio_features(m, feats + (long)w * d->n_mels * d->n_frames, n_valid_frames[w], emb + (long)n_audio * D, o);
     if (o && o->audio_embeds) memcpy(o->audio_embeds, emb, sizeof(float) * (long)n_audio * D);
     int n_ph = 0; for (int i = 0; i < P; ++i) n_ph += (prompt[i] == d->audio_token_id);
     if (n_ph != n_audio) { free(emb); return -1; }
@@ -479,6 +485,10 @@ int oracle_transcribe(const oracle_model *m, const float *feats, int n_valid_fra
     for (int l = 0; l < d->dec_layers; ++l) { free(kv[l].k); free(kv[l].v); }
     free(kv); free(emb); free(x); free(logits); free(xt);
     return 0;
+}
+int oracle_transcribe(const oracle_model *m, const float *feats, int n_valid_frames, const int *prompt, int P,
+                      int max_new, oracle_outputs *o) {
+    return oracle_transcribe_multi(m, feats, &n_valid_frames, 1, prompt, P, max_new, o);
 }
 
 /* ---------------------------------------------------------------- single-op entry points (full-size stage checks) */

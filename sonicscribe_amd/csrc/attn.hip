@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
             for (int ks = 0; ks < 8; ++ks)
                 if (ks < a.ksplit) { x1 += v1[ks]; x2 += v2[ks]; }
         }
-        n = a.kv_len[b];
+        n = min(max(a.kv_len[b], 1), a.ctx_max);      // (clamped: the cache / RoPE table rows of this block end at ctx_max)
         if (act) {
             const int pos = n - 1;
             x1 = rbf(x1); x2 = rbf(x2);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         }
         __syncthreads();
     } else {
-        n = a.kv_len[b];
+        n = min(max(a.kv_len[b], 1), a.ctx_max);
     }
     // q as the MFMA B operand: column r = head (zero beyond the group), k = head-dim
     bf16x8 qf[4];

@@ -12,6 +12,30 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define WAVE 64
 
+// Opt-in to > 64 KiB of dynamic LDS for a kernel.  The attribute is per DEVICE, so the "done" set is keyed by (device, kernel):
+// a second engine on another GPU of the same process gets its own opt-in (a process-wide flag once left device 1 without it).
+#include <mutex>
+#include <set>
+#include <utility>
+inline void ensure_dyn_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({dev, fn}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// Experiment knobs.  They belong to an ENGINE (sonic_set_option stores them there); the launchers read this thread-local copy,
+// which every locked C-ABI entry point refreshes from its engine before it launches anything.
+struct LaunchOpts {
+    int skinny_variant = 0;    // 0: shared-X kernel where the shape allows, else one-shot; 2: one-shot nt; 3: one-shot plain loads; 9: read floor (bench only)
+    int gemm_force128 = 0;     // route every GEMM to the 128x128 kernel
+    int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
+    int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
+};
+extern thread_local LaunchOpts g_opts;
+
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }          // v_cvt_pk_bf16_f32: RNE, NaN-safe
 __device__ __forceinline__ float rbf(float x) { return (float)((bf16_t)x); }  // round-trip through bf16
@@ -74,14 +98,10 @@ struct SkinnyArgs {
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
-void set_skinny_variant(int v);
-void set_skinny_no_fused_gu(int v);
 bool skinny_gu_eligible(int M, int N, int K);
 void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s);
 void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, int nblk, const float* w, float eps, hipStream_t s);
 bool skinny_o_eligible(int M, int N, int K);
 void launch_skinny_o(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s);
-void set_gemm_force128(int v);
-void set_gemm256_stagger(int v);
 void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);
 void launch_tile_weights_gu8(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s);   // gate/up: 16-row interleaved source -> 8-row interleaved tiles

@@ -295,17 +295,24 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
         for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
         int tok = bi;
         const int fin = a.finished[b];
+        bool running = false;
         if (fin) tok = a.pad_id;                 // finished rows emit the pad token (:2928-2929)
         else {
+            if (a.force_ids) tok = a.force_ids[(long)b * a.force_ld + a.n_new[b]];   // teacher forcing (parity tests): feed this id instead
             a.out_ids[(long)b * a.out_ld + a.n_new[b]] = tok;
             const int nn = a.n_new[b] + 1;
             a.n_new[b] = nn;
             bool stop = nn >= a.max_new[b];
             for (int e = 0; e < a.n_eos; ++e) stop |= (tok == a.eos[e]);
-            if (stop) { a.finished[b] = 1; atomicSub(a.n_active, 1); }
+            if (stop) { a.finished[b] = 1; atomicSub(a.n_active, 1); } else running = true;
         }
-        a.tok_pos[b] = a.kv_len[b];              // the new token sits right after the current context
-        a.kv_len[b] += 1;
+        // Only a row that keeps running advances its context.  A finished row stays where it is (its later steps rewrite the same
+        // cache slot and are discarded), so kv_len never exceeds prompt + max_new - 1 < max_ctx whatever the other rows' budgets are:
+        // before, a [long prompt, small budget] row riding a [short prompt, large budget] batch walked past its cache region.
+        if (running) {
+            a.tok_pos[b] = a.kv_len[b];          // the new token sits right after the current context
+            a.kv_len[b] += 1;
+        }
         s_tok = tok;
         if (a.step_counter) a.step_counter[b] += 1;
     }

@@ -75,8 +75,13 @@ struct sonic_engine {
     bf16_t* taps = nullptr; int taps_on = 0; int last_ntok = 0;   // debug: prefill hidden states after embedding + each layer
     int* n_active_h = nullptr;  // pinned
     int R = 0, max_steps = 0, greedy_calls = 0;
+    int* force_d = nullptr; int force_ld = 0, force_R = 0;   // teacher forcing for the next runs (sonic_set_forced_ids)
     std::vector<int> last_qlen, last_maxnew;
     std::map<int, hipGraphExec_t> graphs;
+
+    // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
+    LaunchOpts opts;
+    int opt_no_graph = 0, opt_gemm_timing = 0;
 
     // timing
     hipEvent_t ev[5]{};
@@ -136,6 +141,8 @@ template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, b
 }
 template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) { return dalloc_uc(e, p, n, true); }
 #define TRY(x) do { int _s = (x); if (_s != SONIC_OK) return _s; } while (0)
+// every locked C-ABI entry: serialise on the engine, select its device, and hand its experiment knobs to the launchers
+#define ENTER(e) std::lock_guard<std::mutex> lk((e)->mu); HIPC(e, hipSetDevice((e)->device)); g_opts = (e)->opts
 
 static inline float bf16_round_host(float x) {
     uint32_t u; memcpy(&u, &x, 4);
@@ -287,6 +294,15 @@ static int check_dims(const sonic_dims& d, int max_batch, int max_ctx) {
     if (max_batch < 1 || max_batch > 64) return fail(nullptr, SONIC_ERR_INVALID, "max_batch must be in 1..64");
     if (max_ctx < 64 || max_ctx % 64 || max_ctx > 8192) return fail(nullptr, SONIC_ERR_INVALID, "max_ctx must be a multiple of 64 in 64..8192");
     if (d.n_eos < 0 || d.n_eos > 8) return fail(nullptr, SONIC_ERR_INVALID, "n_eos must be 0..8");
+    {   // every decode-step GEMM needs a weight-streaming tiling with 1..8 K slabs (a shape without one would silently produce zeros)
+        const int QD = d.dec_heads * d.dec_head_dim, KD = d.dec_kv_heads * d.dec_head_dim;
+        const int shapes[5][2] = {{QD + 2 * KD, d.dec_d}, {d.dec_d, QD}, {2 * d.dec_ff, d.dec_d}, {d.dec_d, d.dec_ff}, {d.vocab, d.dec_d}};
+        const char* names[5] = {"qkv_proj", "o_proj", "gate/up_proj", "down_proj", "lm_head"};
+        for (int i = 0; i < 5; ++i) {
+            const int ks = skinny_pick_ksplit(shapes[i][0], shapes[i][1]);
+            if (ks < 1 || ks > 8) return fail(nullptr, SONIC_ERR_INVALID, "decoder %s shape [%d x %d] has no decode-step tiling (K slabs = %d, need 1..8)", names[i], shapes[i][0], shapes[i][1], ks);
+        }
+    }
     return SONIC_OK;
 }
 
@@ -295,6 +311,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     *out = nullptr;
     if (mode == SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_UNSUPPORTED, "INT8 mode is not built yet (SURVEY.md §8a row a14, parity unpinned)");
     if (mode != SONIC_MODE_NATIVE) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
+    g_opts = LaunchOpts{};
     TRY(check_dims(*dims, max_batch, max_ctx));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SONIC_ERR_HIP, "no HIP device available");
@@ -307,7 +324,10 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     const sonic_dims& d = e->d;
     e->T = d.enc_T; e->Tp = (d.enc_T + T_PAD_ALIGN - 1) / T_PAD_ALIGN * T_PAD_ALIGN; e->Ta = d.enc_T / d.merge; e->hd_e = d.enc_d / d.enc_heads;
     e->QD = d.dec_heads * d.dec_head_dim; e->KD = d.dec_kv_heads * d.dec_head_dim; e->qkvN = e->QD + 2 * e->KD;
-    e->tok_cap = max_batch * max_ctx; e->out_cap = max_ctx;
+    // prompt tokens of one batch: at most Ta audio rows per window plus text; a long max_ctx (multi-window requests) must not
+    // multiply every prefill buffer by it
+    { const int per = max_ctx < e->Ta + 256 ? max_ctx : e->Ta + 256; e->tok_cap = max_batch * per; }
+    e->out_cap = max_ctx;
     const int Bm = max_batch, T = e->T, C = d.enc_d;
     const size_t Mp = (size_t)Bm * T + 128;
     int s;
@@ -358,6 +378,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->dump) (void)hipFree(e->dump);
+    if (e->force_d) (void)hipFree(e->force_d);
     if (e->taps) (void)hipFree(e->taps);
     if (e->feats_f32) (void)hipFree(e->feats_f32);
     if (e->n_active_h) (void)hipHostFree(e->n_active_h);
@@ -371,8 +392,7 @@ extern "C" const char* sonic_last_error(sonic_engine* e) { return e ? e->err.c_s
 extern "C" int64_t sonic_weight_bytes(sonic_engine* e) { return e ? e->weight_bytes : 0; }
 extern "C" int sonic_synchronize(sonic_engine* e) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     HIPC(e, hipStreamSynchronize(e->st));
     return SONIC_OK;
 }
@@ -392,8 +412,7 @@ static int raw_alloc(sonic_engine* e, const std::string& name, const std::vector
 
 extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
     if (!e || !name || !data || !shape) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (e->finalized) return fail(e, SONIC_ERR_INVALID, "weights already finalized");
     std::vector<int64_t> shp(shape, shape + ndim);
     bool known = false;
@@ -416,8 +435,7 @@ extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* 
 
 extern "C" int sonic_load_synthetic(sonic_engine* e, uint64_t seed) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (e->finalized) return fail(e, SONIC_ERR_INVALID, "weights already finalized");
     for (auto& it : inventory(e->d)) {
         DevTensor* t;
@@ -465,8 +483,7 @@ static int keep_raw(sonic_engine* e, const std::string& name, bf16_t** out) {
 
 extern "C" int sonic_finalize_weights(sonic_engine* e) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (e->finalized) return SONIC_OK;
     const sonic_dims& d = e->d;
     const std::string at = "model.audio_tower.", pj = "model.multi_modal_projector.", lm = "model.language_model.";
@@ -579,7 +596,7 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
     for (int l = 0; l < d.enc_layers; ++l) {
         const EncLayerW& L = e->enc[l];
         launch_layernorm(e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, e->st);
-        const bool tev = (size_t)(8 * l + 7) < e->gemm_ev.size();
+        const bool tev = e->opt_gemm_timing && (size_t)(8 * l + 7) < e->gemm_ev.size();
         auto mark = [&](int i) { if (tev) (void)hipEventRecord(e->gemm_ev[8 * l + i], e->st); };
         {
             GemmArgs a{};
@@ -657,6 +674,7 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     for (int i = 0; i < d.n_eos; ++i) g.eos[i] = d.eos[i];
     g.logits_dump = dump ? e->dump : nullptr; g.dump_stride_step = (long)R * d.vocab; g.step_counter = dump ? e->step_ctr : nullptr;
     g.norm_w = e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
+    g.force_ids = e->force_d; g.force_ld = e->force_ld;
     return g;
 }
 
@@ -811,6 +829,8 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     if (e->W < 1) return fail(e, SONIC_ERR_INVALID, "no PCM staged");
     HostPlan hp;
     TRY(plan_requests(e, req_win, R, prompt_ids, prompt_off, max_new, hp));
+    if (e->force_d && (e->force_R != R || e->force_ld < hp.max_steps))
+        return fail(e, SONIC_ERR_INVALID, "forced ids are [%d][%d] but the run has %d requests / %d steps", e->force_R, e->force_ld, R, hp.max_steps);
     e->R = R; e->max_steps = hp.max_steps; e->last_qlen = hp.q_len; e->last_maxnew = hp.max_new;
     if (want_logits) {
         const size_t need_n = (size_t)hp.max_steps * R * d.vocab;
@@ -833,7 +853,7 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     (void)hipEventRecord(e->ev[3], e->st);
 
     // ---- decode loop: hipGraph replay of one captured step
-    const bool use_graph = !want_logits && getenv("SONIC_NO_GRAPH") == nullptr;
+    const bool use_graph = !want_logits && !e->opt_no_graph && !e->force_d;
     hipGraphExec_t gx = nullptr;
     if (use_graph && hp.max_steps > 1) {
         auto it = e->graphs.find(R);
@@ -900,33 +920,34 @@ static int stage_pcm_locked(sonic_engine* e, const int16_t* pcm, const int64_t* 
 
 extern "C" int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     return stage_pcm_locked(e, pcm, offsets, W);
 }
 
 extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                                 const int32_t* max_new, int want_step_logits) {
     if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     return run_all(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0);
 }
 
 static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
     const int R = e->R;
     if (R < 1) return fail(e, SONIC_ERR_INVALID, "nothing to fetch");
-    std::vector<int> nn(64), kvl(64), tps(64);
+    std::vector<int> nn(64), kvl(64), tps(64), fin(64);
     HIPC(e, hipMemcpy(nn.data(), e->n_new, 64 * 4, hipMemcpyDeviceToHost));
     HIPC(e, hipMemcpy(kvl.data(), e->kv_len, 64 * 4, hipMemcpyDeviceToHost));
     HIPC(e, hipMemcpy(tps.data(), e->tok_pos, 64 * 4, hipMemcpyDeviceToHost));
-    // invariants of the greedy controller: every launch advances each row's context by exactly one token
+    HIPC(e, hipMemcpy(fin.data(), e->finished, 64 * 4, hipMemcpyDeviceToHost));
+    // invariants of the greedy controller: a running row's context grows by one per launch; a finished row stopped growing with the
+    // launch that finished it (kv_len = prompt + tokens - 1), so no row ever leaves its [max_ctx] cache region
     for (int r = 0; r < R && r < (int)e->last_qlen.size(); ++r) {
-        const int want_kv = e->last_qlen[r] + e->greedy_calls;
+        const int want_kv = e->last_qlen[r] + nn[r] - (fin[r] ? 1 : 0);
         const int want_new = e->greedy_calls < e->last_maxnew[r] ? e->greedy_calls : e->last_maxnew[r];
-        if (kvl[r] != want_kv || tps[r] != want_kv - 1 || nn[r] > e->last_maxnew[r] || (e->d.n_eos == 0 && nn[r] != want_new))
-            return fail(e, SONIC_ERR_HIP, "decoder state check failed for request %d: kv_len %d (expected %d), tok_pos %d, n_new %d (budget %d, greedy launches %d)",
-                        r, kvl[r], want_kv, tps[r], nn[r], e->last_maxnew[r], e->greedy_calls);
+        const bool pos_ok = nn[r] >= 1 && kvl[r] == want_kv && kvl[r] <= e->max_ctx && (tps[r] == kvl[r] - 1 || (fin[r] && nn[r] == 1));
+        if (!pos_ok || nn[r] > e->last_maxnew[r] || (!fin[r] && nn[r] != e->greedy_calls) || (e->d.n_eos == 0 && nn[r] != want_new))
+            return fail(e, SONIC_ERR_HIP, "decoder state check failed for request %d: kv_len %d (expected %d), tok_pos %d, n_new %d, finished %d (budget %d, greedy launches %d)",
+                        r, kvl[r], want_kv, tps[r], nn[r], fin[r], e->last_maxnew[r], e->greedy_calls);
     }
     for (int r = 0; r < R; ++r) {
         if (out_len) out_len[r] = nn[r];
@@ -944,8 +965,7 @@ static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* 
 
 extern "C" int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     return fetch_locked(e, out_ids, out_ld, out_len, step_logits);
 }
 
@@ -953,11 +973,27 @@ extern "C" int sonic_transcribe_batch(sonic_engine* e, const int16_t* pcm, const
                                       const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new,
                                       int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
     if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     TRY(stage_pcm_locked(e, pcm, offsets, W));
     TRY(run_all(e, req_win, R, prompt_ids, prompt_off, max_new, step_logits != nullptr));
     return fetch_locked(e, out_ids, out_ld, out_len, step_logits);
+}
+
+// Teacher forcing for parity tests (oracle_outputs.force_ids, sonic_oracle.c): while set, every run feeds ids[r][n] as token n of
+// request r instead of the argmax (logits are still computed and dumped; EOS / budget rules apply to the forced token).  NULL clears.
+extern "C" int sonic_set_forced_ids(sonic_engine* e, const int32_t* ids, int R, int ld) {
+    if (!e) return SONIC_ERR_INVALID;
+    ENTER(e);
+    HIPC(e, hipStreamSynchronize(e->st));
+    if (e->force_d) { (void)hipFree(e->force_d); e->force_d = nullptr; e->force_ld = e->force_R = 0; }
+    if (!ids) return SONIC_OK;
+    if (R < 1 || R > e->Bm || ld < 1) return fail(e, SONIC_ERR_INVALID, "forced ids: bad shape [%d][%d]", R, ld);
+    for (long i = 0; i < (long)R * ld; ++i)
+        if (ids[i] < 0 || ids[i] >= e->d.vocab) return fail(e, SONIC_ERR_INVALID, "forced id %d out of vocabulary", ids[i]);
+    HIPC(e, hipMalloc((void**)&e->force_d, (size_t)R * ld * 4));
+    HIPC(e, h2d(e, e->force_d, ids, (size_t)R * ld * 4));
+    e->force_R = R; e->force_ld = ld;
+    return SONIC_OK;
 }
 
 extern "C" int sonic_get_timings(sonic_engine* e, sonic_timings* out) {
@@ -970,8 +1006,7 @@ extern "C" int sonic_get_timings(sonic_engine* e, sonic_timings* out) {
 // ------------------------------------------------------------------------------------------ C ABI: stage entry points
 extern "C" int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int B, float* feats_out, int32_t* mask_out) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     TRY(stage_pcm_locked(e, pcm, offsets, B));
     TRY(run_mel(e, B, feats_out != nullptr));
     HIPC(e, hipStreamSynchronize(e->st));
@@ -989,8 +1024,7 @@ extern "C" int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* 
 extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* n_valid_frames, int B,
                             float* embeds_out, int32_t* n_audio_out, float* enc_layers_out, float* enc_out) {
     if (!e || !feats || !n_valid_frames) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
     if (B < 1 || B > e->Bm) return fail(e, SONIC_ERR_INVALID, "batch out of range");
     const sonic_dims& d = e->d;
@@ -1060,8 +1094,7 @@ static int down_bf16(sonic_engine* e, TmpBuf& tb, const bf16_t* d, float* h, siz
 extern "C" int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float* bias, const float* resid, float* C,
                                int M, int N, int K, int epi) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (K % 64 || N % 4) return fail(e, SONIC_ERR_INVALID, "K must be a multiple of 64 and N of 4");
     TmpBuf tb(e->st);
     const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
@@ -1076,8 +1109,7 @@ extern "C" int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, 
 
 extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (M < 1 || M > 64 || N % 16 || K % 256 || skinny_pick_ksplit(N, K) < 1) return fail(e, SONIC_ERR_INVALID, "skinny: M<=64, N%%16==0, K%%256==0");
     TmpBuf tb(e->st);
     bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
@@ -1112,8 +1144,7 @@ __global__ void transpose_v_kernel(const bf16_t* v, bf16_t* vt, int B, int Tk, i
 extern "C" int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
                                     int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (hd != 64 && hd != 128) return fail(e, SONIC_ERR_INVALID, "hd must be 64 or 128");
     TmpBuf tb(e->st);
     const int Tkp = (Tk + 63) / 64 * 64;
@@ -1142,8 +1173,7 @@ extern "C" int sonic_test_attention(sonic_engine* e, const float* q, const float
 
 extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out, int B, int Tk, int Hq, int Hkv) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     const int hd = 128, ctx = (Tk + 63) / 64 * 64;
     if (Hq % Hkv || Hq / Hkv > 4) return fail(e, SONIC_ERR_INVALID, "bad GQA group");
     TmpBuf tb(e->st);
@@ -1164,8 +1194,7 @@ extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, cons
 
 extern "C" int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, int rms) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (d % 8 || d > 2048) return fail(e, SONIC_ERR_INVALID, "d must be a multiple of 8 and <= 2048");
     TmpBuf tb(e->st);
     bf16_t* dx = up_bf16(e, tb, x, (size_t)rows * d); float* dw = up_f32(e, tb, w, d); float* db = b ? up_f32(e, tb, b, d) : nullptr;
@@ -1178,8 +1207,7 @@ extern "C" int sonic_test_layernorm(sonic_engine* e, const float* x, const float
 
 extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch) {
     if (!e || !ms_per_launch) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (K % 64 || N % 4 || iters < 1) return fail(e, SONIC_ERR_INVALID, "bad gemm bench shape");
     TmpBuf tb(e->st);
     const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
@@ -1212,12 +1240,10 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
 
 extern "C" int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int iters, float* us_per_launch) {
     if (!e || !us_per_launch) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (M < 1 || M > 64 || N % 16 || K % 256 || skinny_pick_ksplit(N, K) < 1 || iters < 1) return fail(e, SONIC_ERR_INVALID, "bad skinny bench shape");
-    struct Restore { ~Restore() { set_skinny_variant(0); } } restore_variant;
     TmpBuf tb(e->st);
-    set_skinny_variant(variant);   // before the ksplit pick: the slab count depends on the kernel family
+    g_opts.skinny_variant = variant;   // this call only (ENTER() reloads the engine's own knobs on the next entry); before the ksplit pick: the slab count depends on the kernel family
     // 8 distinct weight copies so consecutive launches do not re-read an Infinity-Cache-resident matrix
     const int copies = 8;
     bf16_t* dW = tb.get<bf16_t>((size_t)copies * N * K); bf16_t* dX = tb.get<bf16_t>((size_t)64 * K);
@@ -1235,27 +1261,31 @@ extern "C" int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int vari
     hipError_t r = hipStreamSynchronize(e->st);
     float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
-    set_skinny_variant(0);
+    g_opts = e->opts;
     HIPC(e, r); HIPC(e, hipGetLastError());
     *us_per_launch = ms * 1e3f / iters;
     return SONIC_OK;
 }
+static void drop_graphs(sonic_engine* e) { for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); }
 extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!e || !key) return SONIC_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
-    if (!strcmp(key, "skinny_variant")) { set_skinny_variant(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
-    if (!strcmp(key, "gemm_force128")) { set_gemm_force128(value); return SONIC_OK; }
-    if (!strcmp(key, "no_fused_gu")) { set_skinny_no_fused_gu(value); for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); return SONIC_OK; }
+    // knobs live in the engine: two engines in one process do not see each other's settings; captured decode graphs of THIS engine
+    // are dropped whenever a knob that changes the captured kernels moves
+    if (!strcmp(key, "skinny_variant")) { e->opts.skinny_variant = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
+    if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
-    if (!strcmp(key, "gemm256_stagger")) { set_gemm256_stagger(value); return SONIC_OK; }
+    if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
+    if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
 }
 
 // Debug read-back of an internal activation buffer as fp32 (tests / diagnostics only).
 extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n) {
     if (!e || !name || !out) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     const sonic_dims& d = e->d;
     const bf16_t* src = nullptr; size_t cap = 0;
     if (!strcmp(name, "prefill_tap")) { if (!e->taps) return fail(e, SONIC_ERR_INVALID, "no taps recorded"); src = e->taps + (size_t)index * e->tok_cap * d.dec_d; cap = (size_t)e->tok_cap * d.dec_d; }
@@ -1272,10 +1302,40 @@ extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, fl
     return down_bf16(e, tb, src, out, (size_t)n);
 }
 
+// greedy_kernel on caller-provided lm_head partial slabs [ksplit][mpad][V] (fp32): returns the token each row picks (first maximum of
+// the bf16-rounded slab sum, HF:generation/utils.py:2925 / torch.argmax semantics) and, optionally, the bf16 logits it compared.
+extern "C" int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit, int mpad, int V, int B, int32_t* tok_out, float* logits_out) {
+    if (!e || !slabs || !tok_out) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (ksplit < 1 || ksplit > 8 || B < 1 || B > 64 || mpad < B || V < 4 || V % 4) return fail(e, SONIC_ERR_INVALID, "bad greedy test shape");
+    TmpBuf tb(e->st);
+    const size_t n = (size_t)ksplit * mpad * V;
+    float* dl = up_f32(e, tb, slabs, n);
+    bf16_t* table = tb.get<bf16_t>((size_t)V * 8); bf16_t* x = tb.get<bf16_t>((size_t)64 * 8);
+    int* st = tb.get<int>(64 * 8 + 4); int* ids = tb.get<int>(64);
+    float* dump = logits_out ? tb.get<float>((size_t)B * V) : nullptr;
+    if (!dl || !table || !x || !st || !ids || (logits_out && !dump)) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    std::vector<int> h(64 * 8 + 4, 0);
+    for (int b = 0; b < 64; ++b) { h[64 * 2 + b] = 1; h[64 * 4 + b] = 4; }       // kv_len = 1, max_new = 4
+    h[64 * 8] = B;
+    HIPC(e, h2d(e, st, h.data(), h.size() * 4));
+    GreedyArgs g{};
+    g.logits = dl; g.ksplit = ksplit; g.mpad = mpad; g.V = V; g.B = B; g.table = table; g.x = x; g.d = 8;
+    g.out_ids = ids; g.out_ld = 1; g.n_new = st; g.finished = st + 64; g.kv_len = st + 128; g.tok_pos = st + 192; g.max_new = st + 256;
+    g.n_active = st + 512; g.n_eos = 0; g.pad_id = 0; g.logits_dump = dump; g.dump_stride_step = (long)B * V; g.step_counter = dump ? st + 320 : nullptr;
+    launch_greedy(g, e->st);
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    std::vector<int> out(64);
+    HIPC(e, hipMemcpy(out.data(), ids, 64 * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) tok_out[b] = out[b];
+    if (logits_out) HIPC(e, hipMemcpy(logits_out, dump, (size_t)B * V * 4, hipMemcpyDeviceToHost));
+    return SONIC_OK;
+}
+
 extern "C" int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K) {
     if (!e) return SONIC_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPC(e, hipSetDevice(e->device));
+    ENTER(e);
     if (!skinny_gu_eligible(M, N, K)) return fail(e, SONIC_ERR_INVALID, "shape not handled by the fused gate/up kernel");
     TmpBuf tb(e->st);
     bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, Wgu_interleaved, (size_t)N * K);

@@ -189,8 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 
 bool gemm256_eligible(const GemmArgs& a, int epi);
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
-int g_gemm_force128 = 0;
-void set_gemm_force128(int v) { g_gemm_force128 = v; }
+thread_local LaunchOpts g_opts;
 
 static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s);
 static int device_cus() {
@@ -199,7 +198,7 @@ static int device_cus() {
     return n;
 }
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if (!g_gemm_force128 && gemm256_eligible(a, epi)) {
+    if (!g_opts.gemm_force128 && gemm256_eligible(a, epi)) {
         // Wave quantisation: a 256x256 tile occupies a whole CU, so (tiles mod CUs) small means a nearly empty extra round (prefill at
         // M = 8320: 33 x 8 = 264 tiles on 256 CUs, two rounds for 1.03).  If cutting the ragged last <= 128 rows off saves a round, those
         // rows go to the 128x128 kernel instead (same math per row; rows are independent in every epilogue but QKV+V^T).
@@ -366,8 +365,6 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     }
 }
 
-int g_skinny_no_fused_gu = 0;
-void set_skinny_no_fused_gu(int v) { g_skinny_no_fused_gu = v; }
 
 // skinny_gu_kernel: decode-step gate/up projection with SwiGLU fused (modeling_llama.py:163-176).
 // Weights are fragment-tiled with gate and up rows interleaved in groups of 8 (launch_tile_weights_gu8): one 16-row MFMA tile holds
@@ -585,13 +582,12 @@ template <int MB, int KS8, int TPB, bool NORM> static void launch_gu_v(const Ski
     const size_t lds = (size_t)(KS8 * 4) * MB * 2048;               // X image
     const size_t redb = (size_t)8 * TPB * MB * 1024;
     const size_t need = lds > redb ? lds : redb;
-    static bool attr = false;
-    if (!attr && need > 65536) { (void)hipFuncSetAttribute((const void*)skinny_gu_kernel<MB, KS8, TPB, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); attr = true; }
+    if (need > 65536) ensure_dyn_lds((const void*)skinny_gu_kernel<MB, KS8, TPB, NORM>, (int)need);
     hipLaunchKernelGGL((skinny_gu_kernel<MB, KS8, TPB, NORM>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, act, a.N / 2, nm);
 }
 // true if the fused kernel handles this shape (else: skinny GEMM + swiglu_slab_kernel)
 bool skinny_gu_eligible(int M, int N, int K) {
-    if (g_skinny_no_fused_gu) return false;
+    if (g_opts.no_fused_gu) return false;
     const int mb = (M + 15) / 16;
     if (mb > 2 || N % 32 || N / 32 < 128) return false;
     return K == 256 || K == 512 || K == 1024 || K == 2048;
@@ -613,12 +609,11 @@ void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, in
 template <int KS8> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
     const size_t lds = (size_t)(KS8 * 4) * 2048;
     const size_t need = lds > (size_t)(8 * 1024 + 1024) ? lds : (size_t)(8 * 1024 + 1024);
-    static bool attr = false;
-    if (!attr && need > 65536) { (void)hipFuncSetAttribute((const void*)skinny_o_kernel<KS8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); attr = true; }
+    if (need > 65536) ensure_dyn_lds((const void*)skinny_o_kernel<KS8>, (int)need);
     hipLaunchKernelGGL((skinny_o_kernel<KS8>), dim3(a.N / 16, (a.M + 15) / 16), dim3(512), need, s, a, x, ldxres, SS);
 }
 bool skinny_o_eligible(int M, int N, int K) {
-    if (g_skinny_no_fused_gu) return false;
+    if (g_opts.no_fused_gu) return false;
     if (M > 32 || N % 16) return false;
     return K == 256 || K == 512 || K == 1024 || K == 2048;
 }
@@ -627,8 +622,6 @@ void launch_skinny_o(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipS
                    case 1024: launch_o_v<4>(a, x, ldxres, SS, s); break; default: launch_o_v<8>(a, x, ldxres, SS, s); break; }
 }
 
-int g_skinny_variant = 0;   // 0: shared-X kernel where the shape allows, else one-shot; 2: one-shot nt; 3: one-shot plain loads; 9: read floor (bench only)
-void set_skinny_variant(int v) { g_skinny_variant = v; }
 
 static int skinny_pick_kw(int K) {
     for (int kw = 8; kw >= 1; kw >>= 1)
@@ -637,7 +630,7 @@ static int skinny_pick_kw(int K) {
 }
 // config: 1 = BIG (64 rows x 1024 k per block), 2 = SMALL (32 rows x 512 k), 0 = one-shot register kernel (small K)
 static int skinny_pick_cfg(int N, int K) {
-    if (g_skinny_variant >= 2) return 0;
+    if (g_opts.skinny_variant >= 2) return 0;
     if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8 && (long)(N / 64) * (K / 1024) >= 192) return 1;
     if (K % 512 == 0 && N % 32 == 0 && K / 512 <= 8) return 2;
     if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8) return 1;
@@ -653,7 +646,7 @@ int skinny_pick_ksplit(int N, int K) {
 
 template <int MB, int KW> static void launch_skinny_v(const SkinnyArgs& a, hipStream_t s) {
     dim3 grid(a.N / 16, a.ksplit), block(512);
-    const int v = g_skinny_variant;
+    const int v = g_opts.skinny_variant;
     if (v == 9) hipLaunchKernelGGL((skinny_readfloor_kernel<KW>), grid, block, 0, s, a);
     else if (v == 3) hipLaunchKernelGGL((skinny_kernel<MB, KW, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((skinny_kernel<MB, KW, true>), grid, block, 0, s, a);
@@ -669,8 +662,7 @@ template <int MB> static void launch_skinny_mb(const SkinnyArgs& a, int kw, hipS
 template <int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
     if (cfg == 1) {
         const size_t lds = (size_t)16 * MB * 2048;
-        static bool attr_done = false;
-        if (!attr_done && lds > 65536) { (void)hipFuncSetAttribute((const void*)skinny_xs_kernel<MB, 4, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<MB, 4, 2, 16>, (int)lds);
         hipLaunchKernelGGL((skinny_xs_kernel<MB, 4, 2, 16>), dim3(a.N / 64, a.K / 1024), dim3(512), lds, s, a);
     } else {
         const size_t lds = (size_t)8 * MB * 2048;

@@ -333,17 +333,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     }
 }
 
-int g_gemm256_stagger = 1;
-void set_gemm256_stagger(int v) { g_gemm256_stagger = v; }
 
 template <int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES); attr = true; }
+    ensure_dyn_lds((const void*)gemm256_kernel<EPI, STG>, LDS256_BYTES);
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
     hipLaunchKernelGGL((gemm256_kernel<EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS256_BYTES, s, a);
 }
 template <int EPI> static void launch256(const GemmArgs& a, hipStream_t s) {
-    if (g_gemm256_stagger) launch256v<EPI, true>(a, s); else launch256v<EPI, false>(a, s);
+    if (g_opts.gemm256_stagger) launch256v<EPI, true>(a, s); else launch256v<EPI, false>(a, s);
 }
 
 bool gemm256_eligible(const GemmArgs& a, int epi) {

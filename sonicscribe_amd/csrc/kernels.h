@@ -56,6 +56,7 @@ struct GreedyArgs {
     int eos[8]; int n_eos; int pad_id;
     float* logits_dump; long dump_stride_step; int* step_counter;  // optional: bf16-rounded logits per step [step][B][V]; counter per row [B]
     const float* norm_w; float norm_eps; bf16_t* y;   // optional: y[B][d] = RMSNorm(x) with the first decoder layer's input norm
+    const int* force_ids; int force_ld;                // optional teacher forcing: token n of row b is force_ids[b * force_ld + n] (oracle force_ids)
 };
 void launch_greedy(const GreedyArgs& a, hipStream_t s);
 

@@ -179,8 +179,7 @@ void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev
     const int n = max_samples < n_pad ? max_samples : n_pad;
     int t_live = (n + LM_NFFT / 2 + LM_HOP - 1) / LM_HOP; if (t_live > n_frames) t_live = n_frames;
     const int tiles = (t_live + LM_FT - 1) / LM_FT;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)logmel_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LM_DYN_LDS); attr_done = true; }
+    ensure_dyn_lds((const void*)logmel_power_kernel, LM_DYN_LDS);
     if (tiles > 0) hipLaunchKernelGGL(logmel_power_kernel, dim3(tiles, B), dim3(256), LM_DYN_LDS, s, pcm, pcm_stride, n_samples_dev, lc, logspec, segmax, n_frames, n_mels);
     const long tot = (long)n_frames * n_mels;
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3((tot + 255) / 256, B), dim3(256), 0, s, logspec, segmax, n_samples_dev, n_frames, n_mels, feats_fm, feats_f32);

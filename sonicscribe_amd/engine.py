@@ -26,6 +26,7 @@ EXPORTS = [
     "sonic_finalize_weights", "sonic_weight_bytes", "sonic_logmel", "sonic_encode", "sonic_transcribe_batch", "sonic_stage_pcm",
     "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
     "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_test_skinny_gu",
+    "sonic_set_forced_ids", "sonic_test_greedy",
 ]
 
 
@@ -107,6 +108,8 @@ def load_library():
     lib.sonic_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.sonic_debug_read.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int64]
     lib.sonic_test_skinny_gu.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -340,6 +343,28 @@ def _test_skinny_gu(self, X, Wi):
     return out
 
 
+def _set_forced_ids(self, ids):
+    """ids: [R][ld] int array (token n of request r) or None to clear; see sonic_set_forced_ids."""
+    if ids is None:
+        self._check(self.lib.sonic_set_forced_ids(self.h, None, 0, 0))
+        return
+    a = np.ascontiguousarray(ids, dtype=np.int32)
+    assert a.ndim == 2
+    self._check(self.lib.sonic_set_forced_ids(self.h, _p(a), a.shape[0], a.shape[1]))
+
+
+def _test_greedy(self, slabs, B: int, want_logits: bool = False):
+    """slabs: [ksplit][mpad][V] fp32 -> (token per row [B], bf16 logits [B][V] or None)"""
+    s = np.ascontiguousarray(slabs, np.float32)
+    ks, mpad, V = s.shape
+    tok = np.zeros(B, np.int32)
+    lg = np.zeros((B, V), np.float32) if want_logits else None
+    self._check(self.lib.sonic_test_greedy(self.h, _p(s), ks, mpad, V, B, _p(tok), _p(lg)))
+    return tok, lg
+
+
+Engine.set_forced_ids = _set_forced_ids
+Engine.test_greedy = _test_greedy
 Engine.test_skinny_gu = _test_skinny_gu
 Engine.debug_read = _debug_read
 Engine.bench_skinny = _bench_skinny

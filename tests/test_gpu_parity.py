@@ -512,7 +512,7 @@ def test_checkpoint_loader_equals_synthetic(tmp_path):
     from sonicscribe_amd.asr import ASRModel
     seed = 11
     weights.save_synthetic_checkpoint(str(tmp_path), spec.TINY, seed)
-    m1 = ASRModel(str(tmp_path), device="cuda", mode="native", max_batch=2, max_ctx=512)
+    m1 = ASRModel(str(tmp_path), device="cuda", mode="native", max_batch=2, max_ctx=512, _allow_synthetic_prompt=True)
     m2 = ASRModel.from_synthetic(spec.TINY, seed=seed, max_batch=2, max_ctx=512)
     assert m1.dims == spec.TINY
     wav = synth.synth_pcm(70, 80000).astype(np.float32) / 32768.0

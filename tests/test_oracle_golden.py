@@ -130,3 +130,100 @@ def test_mismatched_placeholders_raise(golden_dir):
     feats = np.zeros((128, 3000), np.float32)
     with pytest.raises(ValueError):
         m.transcribe(feats, 500, [1, d.audio_token_id, 2], 2)   # 1 placeholder vs 62 audio rows
+
+
+# ------------------------------------------------------------------------------------------ teacher-forced trajectories
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_tiny_forced_matches_reference(golden_dir, tag):
+    """The free-running trajectories of the random-weight model repeat one id; these fixtures decode under teacher forcing through
+    generate() itself (a LogitsProcessor pins each step to a seeded VARYING id), so every step feeds a different embedding row at
+    a new position.  fp32 within north_star's 1e-3; bf16 within 3 ulp at |logit| < 4 (accumulation-order flips compound a little more
+    over a varying history than over the repeated-id one: 3 of 24576 logits sit between 2 and 2.5 ulp)."""
+    d = spec.TINY
+    g = _load(golden_dir, f"tiny_forced_{tag}.npz")
+    bf16 = tag == "bf16"
+    model = oracle.Model(d, synth.synth_state_dict(d, int(g["seed"]), bf16=bf16), bf16=bf16)
+    tol = 3 * 2.0 ** -6 if bf16 else 1e-3
+    for si in range(2):
+        p = f"s{si}_"
+        pcm = synth.synth_pcm(int(g[p + "seg_index"]), int(g[p + "n_samples"]))
+        feats, mask = oracle.logmel(pcm)
+        force = g[p + "force_ids"]
+        assert len(set(force.tolist())) > len(force) // 2          # the trajectory really varies
+        r = model.transcribe(feats, int(mask.sum()), g[p + "prompt_ids"], len(force), force_ids=force)
+        assert np.array_equal(r["new_ids"], force)
+        np.testing.assert_allclose(r["step_logits"], g[p + "step_logits"], atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_tiny_multi_window_matches_reference(golden_dir, tag):
+    """One 35 s request = a 30 s and a 5 s window behind one prompt (processing_glmasr.py:136-176, modeling_glmasr.py:380-408)."""
+    from sonicscribe_amd import frontend
+    d = spec.TINY
+    g = _load(golden_dir, f"tiny_multi_{tag}.npz")
+    bf16 = tag == "bf16"
+    model = oracle.Model(d, synth.synth_state_dict(d, SEED_TINY, bf16=bf16), bf16=bf16)
+    pcm = synth.synth_pcm(int(g["seg_index"]), int(g["n_samples"]))
+    wins = frontend.split_windows(len(pcm), d)
+    total, per_win = frontend.request_audio_tokens(len(pcm), d)
+    assert total == sum(per_win) == int(g["n_audio"]) and len(wins) == 2
+    fm = [oracle.logmel(pcm[s:e]) for s, e in wins]
+    assert [int(m.sum()) for _, m in fm] == g["frames"].tolist()
+    force = g["force_ids"]
+    r = model.transcribe(np.stack([f for f, _ in fm]), [int(m.sum()) for _, m in fm], g["prompt_ids"], len(force), force_ids=force)
+    np.testing.assert_allclose(r["step_logits"], g["step_logits"], atol=(3 * 2.0 ** -6 if bf16 else 1e-3), rtol=0)
+
+
+SEED_TINY = 20260128
+
+
+# ------------------------------------------------------------------------------------------ F-full: full-width layers (SURVEY.md 8c)
+def _full_dims():
+    from dataclasses import replace
+    return replace(spec.FULL, enc_layers=1, dec_layers=1)
+
+
+def full_state(d, seed, bf16):
+    """Weights of a full-width model straight from the C generator (the numpy statement needs several 8-byte temporaries per element)."""
+    from sonicscribe_amd.spec import tensor_inventory
+    out = {}
+    for name, shape, kind in tensor_inventory(d):
+        scale, offset = synth.kind_params(kind, shape)
+        out[name] = oracle.synth_fill(seed, name, int(np.prod(shape)), scale, offset, bf16).reshape(shape)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_full_width_layers_match_reference(golden_dir, tag):
+    """Full-width GLM-ASR-Nano layers (encoder d=1280 / ff 5120 / 20 heads, T=1500; decoder 2048 / 6144, GQA 16:4; vocab 59264) at depth
+    1 + 1 on one 20 s segment, weights from the portable generator: conv stem, encoder layer, projector, decoder layer at prefill
+    (P = 260) and 4 teacher-forced decode steps, full-vocabulary lm_head -- sampled slices and checksums recorded from the reference."""
+    d = _full_dims()
+    g = _load(golden_dir, f"full_{tag}.npz")
+    bf16 = tag == "bf16"
+    model = oracle.Model(d, full_state(d, int(g["seed"]), bf16), bf16=bf16)
+    pcm = synth.synth_pcm(int(g["seg_index"]), int(g["n_samples"]))
+    feats, mask = oracle.logmel(pcm)
+    force = g["force_ids"]
+    r = model.transcribe(feats, int(mask.sum()), g["prompt_ids"], len(force), want=("conv2", "enc_layers", "enc_out", "dec_layers"), force_ids=force)
+    n_audio = int(g["n_audio"])
+    lg = r["step_logits"]
+    if not bf16:
+        np.testing.assert_allclose(r["conv2"][::40, ::53], g["conv2_sub"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(r["enc_layers"][0][::97], g["enc_layer0_sub"], atol=5e-4, rtol=1e-4)
+        np.testing.assert_allclose(r["enc_out"][::97], g["enc_out_sub"], atol=5e-4, rtol=1e-4)
+        np.testing.assert_allclose(r["audio_embeds"][:n_audio][::25], g["audio_embeds_sub"], atol=5e-4, rtol=1e-4)
+        np.testing.assert_allclose(r["dec_layers"][0][::37], g["dec_layer0_sub"], atol=1e-3, rtol=1e-4)
+        np.testing.assert_allclose(lg[:, ::16], g["step_logits_sub"], atol=1e-3, rtol=0)          # north_star: 1e-3 on logits
+        for s in range(len(force)):
+            st = g["step_logits_stat"][s]
+            assert abs(lg[s].astype(np.float64).sum() - st[0]) < 1e-3 * d.vocab * 0.05 and abs(np.abs(lg[s]).max() - st[2]) < 1e-3
+        assert np.array_equal(lg.argmax(1), g["step_argmax"])
+    else:
+        e = np.abs(r["enc_layers"][0][::97] - g["enc_layer0_sub"]); assert e.max() < 0.13 and e.mean() < 4e-3, (e.max(), e.mean())
+        e = np.abs(r["audio_embeds"][:n_audio][::25] - g["audio_embeds_sub"]); assert e.max() < 0.07 and e.mean() < 4e-3, (e.max(), e.mean())
+        e = np.abs(r["dec_layers"][0][::37] - g["dec_layer0_sub"]); assert e.max() < 0.13 and e.mean() < 8e-3, (e.max(), e.mean())
+        tol = 3 * 2.0 ** -6                                                                           # 3 bf16 ulp at |logit| in [2, 4)
+        np.testing.assert_allclose(lg[:, ::16], g["step_logits_sub"], atol=tol, rtol=0)
+        safe = g["step_top2_margin"] > 2 * tol
+        assert np.array_equal(lg.argmax(1)[safe], g["step_argmax"][safe]) and safe.any()
