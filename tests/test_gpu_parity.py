@@ -107,7 +107,14 @@ def test_gemm256_path(eng, M, N, K, epi):
         idx_g = np.concatenate([np.arange(32 * i, 32 * i + 16) for i in range(ff // 16)]); idx_u = idx_g + 16
         gg, uu = g[:, idx_g], g[:, idx_u]
         got, ref = eng.test_gemm(A, W, epi=3), bf(bf(gg / (1.0 + np.exp(-gg))) * uu)
-    assert np.all(np.abs(got - ref) <= ulp_tol(ref_mag if epi == 2 else ref, 4) + 1e-3), np.abs(got - ref).max()
+    bad = np.abs(got - ref) > ulp_tol(ref_mag if epi == 2 else ref, 4) + 1e-3
+    if bad.any():      # footprint of the failure: which tiles, and what the wrong values look like
+        rows = np.where(bad.any(1))[0]; cols = np.where(bad.any(0))[0]
+        again = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
+        raise AssertionError(f"{int(bad.sum())} bad elements, max err {np.abs(got - ref).max():.3f}; rows {rows.min()}..{rows.max()} ({len(rows)}), cols {cols.min()}..{cols.max()} "
+                             f"({len(cols)}); row tiles {sorted(set((rows // 256).tolist()))[:12]}, col tiles {sorted(set((cols // 256).tolist()))[:12]}; "
+                             f"bad values are zero: {bool(np.all(got[bad] == 0))}; a rerun is clean: {bool(not (np.abs(again - ref) > ulp_tol(ref_mag if epi == 2 else ref, 4) + 1e-3).any())}; "
+                             f"rerun identical to first: {bool(np.array_equal(again, got))}")
     eng.set_option("gemm_force128", 1)
     try:
         old = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
