@@ -41,6 +41,9 @@ typedef enum {
     SONIC_ERR_UNSUPPORTED = 5
 } sonic_status;
 
+/* SONIC_MODE_INT8 = asr.py mode="int8" (:148-210): fp16 activations, every nn.Linear except lm_head / embed_tokens replaced by
+ * LLM.int8() (row-wise int8 weights, per-token int8 activations, outlier columns |x| >= 6.0 in fp16).  bitsandbytes is absent offline,
+ * so this mode is checked against the restatement in oracle/sonic_oracle.c only (parity unpinned). */
 enum { SONIC_MODE_NATIVE = 0 /* bf16, asr.py mode="native" */, SONIC_MODE_INT8 = 1 /* asr.py mode="int8" */ };
 enum { SONIC_DTYPE_F32 = 0, SONIC_DTYPE_BF16 = 1 };
 
@@ -118,6 +121,11 @@ int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C,
 int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K);
 /* the argmax + greedy controller on caller-provided lm_head partial slabs [ksplit][mpad][V] fp32: token picked per row
  * (first maximum of the bf16-rounded slab sum) and optionally the bf16 logits [B][V] it compared */
+/* one Linear8bitLt call (backend/asr.py:182-198: bnb.nn.Linear8bitLt(has_fp16_weights=False, threshold=6.0)) through the engine's int8
+ * kernels: W [N][K] quantised row-wise on the device, X [M][K] in groups of group_rows rows (one group = one reference call), int8 MFMA
+ * GEMM + dequantising epilogue epi.  fp32 buffers holding fp16 values.  Needs an engine created with SONIC_MODE_INT8. */
+int sonic_test_linear_int8(sonic_engine* e, const float* X, const float* W, const float* bias, const float* resid, float* out,
+                           int M, int N, int K, int group_rows, int epi);
 int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit, int mpad, int V, int B, int32_t* tok_out, float* logits_out);
 int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
                          int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal);

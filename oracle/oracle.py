@@ -52,6 +52,9 @@ def lib():
     if _lib is None:
         build()
         _lib = C.CDLL(LIB_PATH)
+        _lib.oracle_set_threads.argtypes = [C.c_int]
+        # cap the OpenMP team: on a 256-thread host the default team makes every small region cost milliseconds
+        _lib.oracle_set_threads(int(os.environ.get("SONIC_ORACLE_THREADS", min(os.cpu_count() or 8, 48))))
         _lib.oracle_model_create.restype = C.c_void_p
         _lib.oracle_model_create.argtypes = [C.POINTER(Dims), C.POINTER(C.c_void_p), C.c_int, C.c_int]
         _lib.oracle_model_destroy.argtypes = [C.c_void_p]
@@ -71,6 +74,10 @@ def lib():
         _lib.oracle_layernorm.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int]
         _lib.oracle_rmsnorm.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int]
         _lib.oracle_encoder_layer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        _lib.oracle_quantize_rows.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+        _lib.oracle_linear_int8.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3
+        _lib.oracle_round.restype = C.c_float
+        _lib.oracle_round.argtypes = [C.c_float, C.c_int]
     return _lib
 
 
@@ -106,23 +113,50 @@ def mel_filters(n_mels: int = 128) -> np.ndarray:
     return out
 
 
-def synth_fill(seed: int, name: str, n: int, scale: float, offset: float, bf16: bool) -> np.ndarray:
+def synth_fill(seed: int, name: str, n: int, scale: float, offset: float, bf16) -> np.ndarray:
+    """bf16: False/0 fp32, True/1 bf16-rounded, 2 = a bf16 checkpoint loaded as fp16 (the int8 mode's weights, asr.py:156)."""
     out = np.empty(n, np.float32)
     lib().oracle_synth_fill(seed, name.encode(), n, scale, offset, int(bf16), _p(out))
     return out
 
 
+MODE_FP32, MODE_BF16, MODE_FP16, MODE_INT8 = 0, 1, 2, 3
+
+
+def quantize_rows(w: np.ndarray):
+    """Int8Params.cuda(): row-wise absmax int8 of a [N][K] fp16-valued matrix -> (CB int8 [N][K], SCB fp32 [N])."""
+    w = np.ascontiguousarray(w, np.float32)
+    cb = np.empty(w.shape, np.int8); scb = np.empty(w.shape[0], np.float32)
+    lib().oracle_quantize_rows(_p(w), w.shape[0], w.shape[1], _p(cb), _p(scb))
+    return cb, scb
+
+
+def linear_int8(x: np.ndarray, cb: np.ndarray, scb: np.ndarray, bias=None) -> np.ndarray:
+    """One Linear8bitLt(threshold=6.0) call on x [T][K] (fp16-valued fp32)."""
+    x = np.ascontiguousarray(x, np.float32); cb = np.ascontiguousarray(cb, np.int8); scb = np.ascontiguousarray(scb, np.float32)
+    b = np.ascontiguousarray(bias, np.float32) if bias is not None else None
+    y = np.empty((x.shape[0], cb.shape[0]), np.float32)
+    lib().oracle_linear_int8(_p(x), _p(cb), _p(scb), _p(b), _p(y), x.shape[0], cb.shape[0], x.shape[1])
+    return y
+
+
+def round_f16(x: np.ndarray) -> np.ndarray:
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
 class Model:
     """Oracle model over a state dict {name: fp32 ndarray} in spec.tensor_inventory order."""
 
-    def __init__(self, dims, state: Dict[str, np.ndarray], bf16: bool):
+    def __init__(self, dims, state: Dict[str, np.ndarray], bf16: bool = False, mode: Optional[int] = None):
+        """mode: MODE_FP32 / MODE_BF16 / MODE_FP16 / MODE_INT8 (fp16 activations + LLM.int8 linears); `bf16` is the old boolean."""
         from sonicscribe_amd.spec import tensor_inventory
         self.dims = dims
-        self.bf16 = bf16
+        self.mode = int(mode) if mode is not None else (MODE_BF16 if bf16 else MODE_FP32)
+        self.bf16 = self.mode == MODE_BF16
         self._keep = [np.ascontiguousarray(state[name], dtype=np.float32) for name, _, _ in tensor_inventory(dims)]
         arr = (C.c_void_p * len(self._keep))(*[a.ctypes.data for a in self._keep])
         self._cd = make_dims(dims)
-        self.h = lib().oracle_model_create(C.byref(self._cd), arr, len(self._keep), int(bf16))
+        self.h = lib().oracle_model_create(C.byref(self._cd), arr, len(self._keep), self.mode)
         if not self.h:
             raise RuntimeError("oracle_model_create failed")
 

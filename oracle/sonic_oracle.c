@@ -22,12 +22,29 @@
  * replays those fixtures through this file.  The reference tree holds no tests or golden vectors of
  * its own, and no real checkpoint exists offline: real-weight transcripts are unpinned.
  *
- * Two numeric modes:
- *   fp32  (bf16 = 0): every value fp32, as HF runs with dtype=float32.
- *   bf16  (bf16 = 1): values rounded to bfloat16 (RNE) at every torch op boundary, reproducing
- *         the reference's `mode="native"` (torch.bfloat16 weights and activations, fp32 accumulation
- *         inside each op) -- asr.py:61,280-301.
+ * Numeric modes (the `bf16` argument of the entry points is this mode number):
+ *   0 fp32:  every value fp32, as HF runs with dtype=float32.
+ *   1 bf16:  values rounded to bfloat16 (RNE) at every torch op boundary, reproducing the reference's
+ *            `mode="native"` (torch.bfloat16 weights and activations, fp32 accumulation inside each op)
+ *            -- asr.py:61,280-301.
+ *   2 fp16:  the same with IEEE half precision: the activation dtype of the reference's `mode="int8"`
+ *            (asr.py:61 `model_dtype = torch.float16`, :296).
+ *   3 int8:  mode 2 plus LLM.int8() linears (a14): backend/asr.py:169-210 swaps every nn.Linear whose name
+ *            has none of 'lm_head' / 'embed_tokens' / 'audio_proj' for bitsandbytes
+ *            Linear8bitLt(has_fp16_weights=False, threshold=6.0) -- i.e. all encoder q/k/v/o/fc1/fc2,
+ *            BOTH projector linears ('audio_proj' does not match 'multi_modal_projector'), all decoder
+ *            q/k/v/o/gate/up/down; conv stem, norms, embedding and lm_head stay fp16.
+ *            PARITY UNPINNED: bitsandbytes is a third-party dependency of the reference (unpinned in
+ *            backend/requirements.txt, optional import at asr.py:16-22) and is absent here (CUDA-only), so
+ *            linear_int8() restates its published algorithm (bitsandbytes 0.45-0.48: autograd/_functions.py
+ *            MatMul8bitLt.forward, functional.int8_vectorwise_quant, backends int8_mixed_scaled_mm,
+ *            csrc/kernels.cu kInt8VectorQuant / kdequant_mm_int32_fp16) and is anchored only on the
+ *            reference's call site asr.py:182-198.  The CUDA kernels' `__fdividef(127, absmax)` is an
+ *            approximate division; this file (and the HIP engine) use the IEEE quotient.
  */
+#include <float.h>
+#include <immintrin.h>
+#include <omp.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -66,8 +83,11 @@ typedef struct {
 
 typedef struct {
     oracle_dims d;
-    int bf16;
+    int bf16;  /* numeric mode: 0 fp32, 1 bf16, 2 fp16 */
+    int int8;  /* LLM.int8 linears (mode 3 = fp16 + int8) */
+    int n_w;
     float **w; /* tensor pointers in spec.tensor_inventory order (borrowed) */
+    int8_t **cb; float **scb; /* per tensor slot: row-wise int8 weights + row absmax (owned; NULL for unquantised slots) */
 } oracle_model;
 
 /* ---------------------------------------------------------------- bf16 + synth */
@@ -76,7 +96,9 @@ static inline float bf16_round(float x) {
     u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
     memcpy(&x, &u, 4); return x;
 }
-#define RB(m, x) ((m)->bf16 ? bf16_round(x) : (x))
+static inline float fp16_round(float x) { return _cvtsh_ss(_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+static inline float round_mode(int mode, float x) { return mode == 1 ? bf16_round(x) : mode == 2 ? fp16_round(x) : x; }
+#define RB(m, x) round_mode((m)->bf16, (x))
 
 static uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -99,7 +121,7 @@ void oracle_synth_fill(uint64_t seed, const char *name, long n, float scale, flo
         volatile float r = (float)bits * 0x1p-23f - 1.0f;
         volatile float p = r * scale;
         volatile float v = offset + p;
-        out[i] = bf16 ? bf16_round(v) : v;
+        out[i] = bf16 == 2 ? fp16_round(bf16_round(v)) : bf16 ? bf16_round(v) : v;   /* 2: a bf16 checkpoint loaded as fp16 (asr.py:156) */
     }
 }
 
@@ -198,7 +220,7 @@ void oracle_logmel(const int16_t *pcm, int n, int n_mels, int n_frames, float *f
 /* y[T][N] = x[T][K] (row stride ldx) @ w[N][K]^T + b ; optional rounding */
 static void linear(const oracle_model *m, const float *x, long ldx, const float *w, const float *b,
                    float *y, long ldy, int T, int N, int K) {
-    #pragma omp parallel for schedule(static)
+    #pragma omp parallel for schedule(static) if ((long)T * N * K > 4000000L)
     for (int t0 = 0; t0 < T; t0 += 4) {
         int tn = T - t0 < 4 ? T - t0 : 4;
         for (int o = 0; o < N; ++o) {
@@ -213,11 +235,86 @@ static void linear(const oracle_model *m, const float *x, long ldx, const float 
         }
     }
 }
+/* ---------------------------------------------------------------- a14: LLM.int8() linear (bitsandbytes Linear8bitLt)
+ * One call = one activation matrix x[T][K] (fp16 values) as the reference's module sees it; the outlier columns are found over
+ * ALL T rows of the call (functional.int8_vectorwise_quant: `outliers = A.abs() >= threshold; outlier_cols = argwhere(outliers.any(dim=0))`).
+ *   row stats  SCA[t] = max |x[t][k]| over the elements below the threshold      (kInt8VectorQuant<SPARSE_DECOMP=1>)
+ *   CA[t][k]   = rn(x * 127 / SCA[t]); 0 for elements >= threshold and for whole outlier columns
+ *   C32        = CA . CB^T                                                      (int8 x int8 -> int32, exact)
+ *   y          = fp16(fma(float(C32), SCA[t] * SCB[n] * (1 / 127^2), bias))      (kdequant_mm_int32_fp16, MM_DEQUANT_CONST)
+ *   outliers:  y = fp16(y + sum_{k in outlier cols} x[t][k] * fp16(CB[n][k] * SCB[n] * (1/127)))   (int8_mixed_scaled_mm: addmm(subA, subB),
+ *              subB = int8_vectorwise_dequant(CB[:, cols], SCB).to(fp16)) */
+#define LLM_INT8_THRESHOLD 6.0f
+#define MM_DEQUANT_CONST 6.200012e-05f
+static void quantize_rows_int8(const float *w, long n_rows, long K, int8_t *cb, float *scb) { /* Int8Params.cuda(): int8_vectorwise_quant(W.half()) */
+    #pragma omp parallel for
+    for (long n = 0; n < n_rows; ++n) {
+        const float *r = w + n * K;
+        float amax = -FLT_MIN;
+        for (long k = 0; k < K; ++k) amax = fmaxf(amax, fabsf(r[k]));
+        scb[n] = amax;
+        const float scale = 127.0f / amax;
+        for (long k = 0; k < K; ++k) cb[n * K + k] = amax > 0.f ? (int8_t)rintf(r[k] * scale) : 0;
+    }
+}
+static void linear_int8(const float *x, long ldx, const int8_t *cb, const float *scb, const float *b, float *y, long ldy, int T, int N, int K) {
+    char *oc = (char *)calloc(K, 1);
+    int n_oc = 0;
+    for (int t = 0; t < T; ++t) for (int k = 0; k < K; ++k) if (fabsf(x[(long)t * ldx + k]) >= LLM_INT8_THRESHOLD) oc[k] = 1;
+    int *ocl = (int *)malloc(sizeof(int) * (K > 0 ? K : 1));
+    for (int k = 0; k < K; ++k) if (oc[k]) ocl[n_oc++] = k;
+    int8_t *ca = (int8_t *)malloc((size_t)T * K);
+    float *sca = (float *)malloc(sizeof(float) * T);
+    #pragma omp parallel for if ((long)T * K > 200000L)
+    for (int t = 0; t < T; ++t) {
+        const float *xr = x + (long)t * ldx;
+        float amax = -FLT_MIN;
+        for (int k = 0; k < K; ++k) { float a = fabsf(xr[k]); if (a < LLM_INT8_THRESHOLD) amax = fmaxf(amax, a); }
+        sca[t] = amax;
+        const float scale = 127.0f / amax;
+        for (int k = 0; k < K; ++k) {
+            const float v = xr[k];
+            ca[(long)t * K + k] = (oc[k] || !(fabsf(v) < LLM_INT8_THRESHOLD) || !(amax > 0.f)) ? 0 : (int8_t)rintf(v * scale);
+        }
+    }
+    #pragma omp parallel for schedule(static) if ((long)T * N * K > 4000000L)
+    for (int t = 0; t < T; ++t) {
+        const int8_t *ar = ca + (long)t * K;
+        const float *xr = x + (long)t * ldx;
+        for (int n = 0; n < N; ++n) {
+            const int8_t *wr = cb + (long)n * K;
+            int32_t acc = 0;
+            for (int k = 0; k < K; ++k) acc += (int32_t)ar[k] * (int32_t)wr[k];
+            const float sc = sca[t] * scb[n] * MM_DEQUANT_CONST;
+            float v = fp16_round(fmaf((float)acc, sc, b ? b[n] : 0.0f));
+            if (n_oc) {
+                float a2 = 0.f;
+                for (int j = 0; j < n_oc; ++j) {
+                    const int k = ocl[j];
+                    const float wdq = fp16_round(((float)wr[k] * scb[n]) * 7.874015718698502e-3f);
+                    a2 += xr[k] * wdq;
+                }
+                v = fp16_round(v + a2);
+            }
+            y[(long)t * ldy + n] = v;
+        }
+    }
+    free(oc); free(ocl); free(ca); free(sca);
+}
+/* a Linear module of the model: quantised (mode 3 and the slot is one of the swapped modules) or plain.  wslot points into m->w. */
+static void lin(const oracle_model *m, const float *x, long ldx, float *const *wslot, const float *b, float *y, long ldy, int T, int N, int K) {
+    const long idx = wslot - m->w;
+    if (m->int8 && m->cb && idx >= 0 && idx < m->n_w && m->cb[idx]) linear_int8(x, ldx, m->cb[idx], m->scb[idx], b, y, ldy, T, N, K);
+    else linear(m, x, ldx, *wslot, b, y, ldy, T, N, K);
+}
 static inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+/* thread count of the parallel regions: a many-core host (256 hardware threads, possibly under a CPU quota) spends seconds per small
+ * region with the default team size; small regions are serial (if clauses) and the team is capped */
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 static inline float silu(float x) { return x / (1.0f + expf(-x)); }
 
 static void layernorm(const oracle_model *m, const float *x, const float *w, const float *b, float *y, int T, int d, float eps) {
-    #pragma omp parallel for
+    #pragma omp parallel for if (T > 256)
     for (int t = 0; t < T; ++t) {
         const float *xr = x + (long)t * d; float *yr = y + (long)t * d;
         double s = 0; for (int i = 0; i < d; ++i) s += xr[i];
@@ -229,7 +326,7 @@ static void layernorm(const oracle_model *m, const float *x, const float *w, con
 }
 /* LlamaRMSNorm (modeling_llama.py:60-65): fp32 normalise, cast to input dtype, then * weight */
 static void rmsnorm(const oracle_model *m, const float *x, const float *w, float *y, int T, int d, float eps) {
-    #pragma omp parallel for
+    #pragma omp parallel for if (T > 256)
     for (int t = 0; t < T; ++t) {
         const float *xr = x + (long)t * d; float *yr = y + (long)t * d;
         float s = 0; for (int i = 0; i < d; ++i) s += xr[i] * xr[i];
@@ -241,7 +338,7 @@ static void rmsnorm(const oracle_model *m, const float *x, const float *w, float
  * cos/sin are computed in fp32 and cast to the activation dtype before use (:104-106). */
 static void rope(const oracle_model *m, float *x, int T, int heads, int hd, int rd, float theta, const int *pos) {
     int half = rd / 2;
-    #pragma omp parallel for
+    #pragma omp parallel for if (T > 256)
     for (int t = 0; t < T; ++t) {
         float c[128], s[128];
         for (int i = 0; i < half; ++i) {
@@ -268,7 +365,7 @@ static void attention(const oracle_model *m, const float *q, long ldq, const flo
                       float *out, long ldo, int Tq, int Tk, int Hq, int Hkv, int hd, int causal, int q_pos0) {
     float scale = 1.0f / sqrtf((float)hd);
     int grp = Hq / Hkv;
-    #pragma omp parallel
+    #pragma omp parallel if ((long)Hq * Tq * Tk > 200000L)
     {
         float *s = (float *)malloc(sizeof(float) * Tk);
         #pragma omp for collapse(2) schedule(dynamic, 8)
@@ -304,16 +401,41 @@ static float **enc_tail_w(const oracle_model *m) { return m->w + 4 + m->d.enc_la
 static float **dec_layer_w(const oracle_model *m, int l) { return enc_tail_w(m) + 7 + l * D_PER_LAYER; }
 static float *dec_final_norm(const oracle_model *m) { return *(enc_tail_w(m) + 7 + m->d.dec_layers * D_PER_LAYER); }
 
-oracle_model *oracle_model_create(const oracle_dims *d, float **tensors, int n_tensors, int bf16) {
+static void quantize_slot(oracle_model *m, long idx, long n_rows, long K) {
+    m->cb[idx] = (int8_t *)malloc((size_t)n_rows * K); m->scb[idx] = (float *)malloc(sizeof(float) * n_rows);
+    quantize_rows_int8(m->w[idx], n_rows, K, m->cb[idx], m->scb[idx]);
+}
+/* mode: 0 fp32, 1 bf16, 2 fp16, 3 fp16 + LLM.int8 linears */
+oracle_model *oracle_model_create(const oracle_dims *d, float **tensors, int n_tensors, int mode) {
     int expect = 4 + d->enc_layers * E_PER_LAYER + 7 + d->dec_layers * D_PER_LAYER + 1;
     if (n_tensors != expect) { fprintf(stderr, "oracle: expected %d tensors, got %d\n", expect, n_tensors); return NULL; }
     oracle_model *m = (oracle_model *)calloc(1, sizeof(*m));
-    m->d = *d; m->bf16 = bf16;
+    m->d = *d; m->bf16 = mode == 3 ? 2 : mode; m->int8 = mode == 3; m->n_w = n_tensors;
     m->w = (float **)malloc(sizeof(float *) * n_tensors);
     memcpy(m->w, tensors, sizeof(float *) * n_tensors);
+    if (m->int8) {   /* asr.py:169-210: every nn.Linear except lm_head / embed_tokens (the 'audio_proj' pattern matches nothing) */
+        m->cb = (int8_t **)calloc(n_tensors, sizeof(int8_t *)); m->scb = (float **)calloc(n_tensors, sizeof(float *));
+        const long C = d->enc_d, F = d->enc_ff, D = d->dec_d, QD = (long)d->dec_heads * d->dec_head_dim, KD = (long)d->dec_kv_heads * d->dec_head_dim, FF = d->dec_ff;
+        for (int l = 0; l < d->enc_layers; ++l) {
+            const long b = enc_layer_w(m, l) - m->w;
+            quantize_slot(m, b + 2, C, C); quantize_slot(m, b + 4, C, C); quantize_slot(m, b + 5, C, C); quantize_slot(m, b + 7, C, C);
+            quantize_slot(m, b + 11, F, C); quantize_slot(m, b + 13, C, F);
+        }
+        const long tb = enc_tail_w(m) - m->w;
+        quantize_slot(m, tb + 2, 2 * D, C * d->merge); quantize_slot(m, tb + 4, D, 2 * D);
+        for (int l = 0; l < d->dec_layers; ++l) {
+            const long b = dec_layer_w(m, l) - m->w;
+            quantize_slot(m, b + 1, QD, D); quantize_slot(m, b + 2, KD, D); quantize_slot(m, b + 3, KD, D); quantize_slot(m, b + 4, D, QD);
+            quantize_slot(m, b + 6, FF, D); quantize_slot(m, b + 7, FF, D); quantize_slot(m, b + 8, D, FF);
+        }
+    }
     return m;
 }
-void oracle_model_destroy(oracle_model *m) { if (m) { free(m->w); free(m); } }
+void oracle_model_destroy(oracle_model *m) {
+    if (!m) return;
+    if (m->cb) { for (int i = 0; i < m->n_w; ++i) { free(m->cb[i]); free(m->scb[i]); } free(m->cb); free(m->scb); }
+    free(m->w); free(m);
+}
 
 /* a7: conv stem.  feats [n_mels][n_frames] -> x [enc_T][enc_d] */
 static void conv_stem(const oracle_model *m, const float *feats, float *x, oracle_outputs *o) {
@@ -345,57 +467,76 @@ static void conv_stem(const oracle_model *m, const float *feats, float *x, oracl
     free(h1);
 }
 
-/* a8: one encoder layer in place on x [T][d] */
-static void encoder_layer(const oracle_model *m, int l, float *x, int T) {
+/* a8: one encoder layer in place on x [W*T][d]: W windows of one request side by side.  Row-wise ops see all W*T rows in one call
+ * (as HF does with input_features [W, 128, 3000]: that is the granularity of LLM.int8's outlier columns); attention is per window. */
+static void encoder_layer(const oracle_model *m, int l, float *x, int T, int W) {
     const oracle_dims *d = &m->d; int D = d->enc_d, H = d->enc_heads, hd = D / H, FF = d->enc_ff;
+    const int R = W * T;
     float **w = enc_layer_w(m, l);
-    float *ln = (float *)malloc(sizeof(float) * (long)T * D), *q = (float *)malloc(sizeof(float) * (long)T * D);
-    float *k = (float *)malloc(sizeof(float) * (long)T * D), *v = (float *)malloc(sizeof(float) * (long)T * D);
-    float *a = (float *)malloc(sizeof(float) * (long)T * D), *ff = (float *)malloc(sizeof(float) * (long)T * FF);
-    int *pos = (int *)malloc(sizeof(int) * T); for (int t = 0; t < T; ++t) pos[t] = t;
-    layernorm(m, x, w[0], w[1], ln, T, D, d->enc_ln_eps);
-    linear(m, ln, D, w[2], w[3], q, D, T, D, D);
-    linear(m, ln, D, w[4], NULL, k, D, T, D, D);
-    linear(m, ln, D, w[5], w[6], v, D, T, D, D);
-    rope(m, q, T, H, hd, d->enc_rotary_dim, d->enc_theta, pos);
-    rope(m, k, T, H, hd, d->enc_rotary_dim, d->enc_theta, pos);
-    attention(m, q, D, k, v, D, a, D, T, T, H, H, hd, 0, 0);
-    linear(m, a, D, w[7], w[8], q, D, T, D, D);
-    for (long i = 0; i < (long)T * D; ++i) x[i] = RB(m, x[i] + q[i]);
-    layernorm(m, x, w[9], w[10], ln, T, D, d->enc_ln_eps);
-    linear(m, ln, D, w[11], w[12], ff, FF, T, FF, D);
-    for (long i = 0; i < (long)T * FF; ++i) ff[i] = RB(m, gelu_erf(ff[i]));
-    linear(m, ff, FF, w[13], w[14], q, D, T, D, FF);
-    for (long i = 0; i < (long)T * D; ++i) x[i] = RB(m, x[i] + q[i]);
+    float *ln = (float *)malloc(sizeof(float) * (long)R * D), *q = (float *)malloc(sizeof(float) * (long)R * D);
+    float *k = (float *)malloc(sizeof(float) * (long)R * D), *v = (float *)malloc(sizeof(float) * (long)R * D);
+    float *a = (float *)malloc(sizeof(float) * (long)R * D), *ff = (float *)malloc(sizeof(float) * (long)R * FF);
+    int *pos = (int *)malloc(sizeof(int) * R); for (int t = 0; t < R; ++t) pos[t] = t % T;
+    layernorm(m, x, w[0], w[1], ln, R, D, d->enc_ln_eps);
+    lin(m, ln, D, &w[2], w[3], q, D, R, D, D);
+    lin(m, ln, D, &w[4], NULL, k, D, R, D, D);
+    lin(m, ln, D, &w[5], w[6], v, D, R, D, D);
+    rope(m, q, R, H, hd, d->enc_rotary_dim, d->enc_theta, pos);
+    rope(m, k, R, H, hd, d->enc_rotary_dim, d->enc_theta, pos);
+    for (int wi = 0; wi < W; ++wi) {
+        const long o = (long)wi * T * D;
+        attention(m, q + o, D, k + o, v + o, D, a + o, D, T, T, H, H, hd, 0, 0);
+    }
+    lin(m, a, D, &w[7], w[8], q, D, R, D, D);
+    for (long i = 0; i < (long)R * D; ++i) x[i] = RB(m, x[i] + q[i]);
+    layernorm(m, x, w[9], w[10], ln, R, D, d->enc_ln_eps);
+    lin(m, ln, D, &w[11], w[12], ff, FF, R, FF, D);
+    for (long i = 0; i < (long)R * FF; ++i) ff[i] = RB(m, gelu_erf(ff[i]));
+    lin(m, ff, FF, &w[13], w[14], q, D, R, D, FF);
+    for (long i = 0; i < (long)R * D; ++i) x[i] = RB(m, x[i] + q[i]);
     free(ln); free(q); free(k); free(v); free(a); free(ff); free(pos);
 }
 
 static int floordiv_i(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
-/* a7-a9: feats -> audio embeds [n_keep][dec_d]; returns rows kept */
-int oracle_audio_features(const oracle_model *m, const float *feats, int n_valid_frames, float *embeds, oracle_outputs *o) {
-    const oracle_dims *d = &m->d; int T = d->enc_T, D = d->enc_d;
-    float *x = (float *)malloc(sizeof(float) * (long)T * D);
-    conv_stem(m, feats, x, o);
-    for (int l = 0; l < d->enc_layers; ++l) {
-        encoder_layer(m, l, x, T);
-        if (o && o->enc_layers) memcpy(o->enc_layers + (long)l * T * D, x, sizeof(float) * (long)T * D);
-    }
-    float **tw = enc_tail_w(m);
-    float *y = (float *)malloc(sizeof(float) * (long)T * D);
-    layernorm(m, x, tw[0], tw[1], y, T, D, d->enc_ln_eps);
-    if (o && o->enc_out) memcpy(o->enc_out, y, sizeof(float) * (long)T * D);
-    int Tm = T / d->merge, PI = D * d->merge, PM = d->dec_d * 2;
-    float *h = (float *)malloc(sizeof(float) * (long)Tm * PM);
-    linear(m, y, PI, tw[2], tw[3], h, PM, Tm, PM, PI); /* reshape [T][D] -> [T/4][4D] is a view */
-    for (long i = 0; i < (long)Tm * PM; ++i) h[i] = RB(m, gelu_erf(h[i]));
-    float *e = (float *)malloc(sizeof(float) * (long)Tm * d->dec_d);
-    linear(m, h, PM, tw[4], tw[5], e, d->dec_d, Tm, d->dec_d, PM);
-    int L = n_valid_frames; /* modeling_glmasr.py:399-403, python floor division */
+static int keep_rows_of(const oracle_dims *d, int n_valid_frames) { /* modeling_glmasr.py:399-403, python floor division */
+    int L = n_valid_frames, Tm = d->enc_T / d->merge;
     L = floordiv_i(L + 2 - 2 - 1, 1) + 1; L = floordiv_i(L + 2 - 2 - 1, 2) + 1;
     int keep = floordiv_i(L - d->merge, d->merge) + 1; if (keep < 0) keep = 0; if (keep > Tm) keep = Tm;
-    memcpy(embeds, e, sizeof(float) * (long)keep * d->dec_d);
-    free(x); free(y); free(h); free(e);
     return keep;
+}
+/* a7-a9 for the W windows of one request: feats [W][n_mels][n_frames] -> audio embeds [sum keep][dec_d]; returns rows kept.
+ * Taps (conv*, enc_layers, enc_out) record the last window. */
+int oracle_audio_features_multi(const oracle_model *m, const float *feats, const int *n_valid_frames, int W, float *embeds, oracle_outputs *o) {
+    const oracle_dims *d = &m->d; int T = d->enc_T, D = d->enc_d;
+    const long R = (long)W * T;
+    float *x = (float *)malloc(sizeof(float) * R * D);
+    for (int w = 0; w < W; ++w) conv_stem(m, feats + (long)w * d->n_mels * d->n_frames, x + (long)w * T * D, o);
+    for (int l = 0; l < d->enc_layers; ++l) {
+        encoder_layer(m, l, x, T, W);
+        if (o && o->enc_layers) memcpy(o->enc_layers + (long)l * T * D, x + (long)(W - 1) * T * D, sizeof(float) * (long)T * D);
+    }
+    float **tw = enc_tail_w(m);
+    float *y = (float *)malloc(sizeof(float) * R * D);
+    layernorm(m, x, tw[0], tw[1], y, (int)R, D, d->enc_ln_eps);
+    if (o && o->enc_out) memcpy(o->enc_out, y + (long)(W - 1) * T * D, sizeof(float) * (long)T * D);
+    int Tm = T / d->merge, PI = D * d->merge, PM = d->dec_d * 2;
+    const int Rm = W * Tm;
+    float *h = (float *)malloc(sizeof(float) * (long)Rm * PM);
+    lin(m, y, PI, &tw[2], tw[3], h, PM, Rm, PM, PI); /* reshape [T][D] -> [T/4][4D] is a view */
+    for (long i = 0; i < (long)Rm * PM; ++i) h[i] = RB(m, gelu_erf(h[i]));
+    float *e = (float *)malloc(sizeof(float) * (long)Rm * d->dec_d);
+    lin(m, h, PM, &tw[4], tw[5], e, d->dec_d, Rm, d->dec_d, PM);
+    int total = 0;
+    for (int w = 0; w < W; ++w) {
+        const int keep = keep_rows_of(d, n_valid_frames[w]);
+        memcpy(embeds + (long)total * d->dec_d, e + (long)w * Tm * d->dec_d, sizeof(float) * (long)keep * d->dec_d);
+        total += keep;
+    }
+    free(x); free(y); free(h); free(e);
+    return total;
+}
+int oracle_audio_features(const oracle_model *m, const float *feats, int n_valid_frames, float *embeds, oracle_outputs *o) {
+    return oracle_audio_features_multi(m, feats, &n_valid_frames, 1, embeds, o);
 }
 
 typedef struct { float *k, *v; int cap; } kv_cache; /* per layer [cap][kv_dim] */
@@ -411,21 +552,21 @@ static void decoder_forward(const oracle_model *m, float *x, int n, int past, kv
     for (int l = 0; l < d->dec_layers; ++l) {
         float **w = dec_layer_w(m, l);
         rmsnorm(m, x, w[0], hn, n, D, d->dec_rms_eps);
-        linear(m, hn, D, w[1], NULL, q, QD, n, QD, D);
+        lin(m, hn, D, &w[1], NULL, q, QD, n, QD, D);
         float *kn = kv[l].k + (long)past * KD, *vn = kv[l].v + (long)past * KD;
-        linear(m, hn, D, w[2], NULL, kn, KD, n, KD, D);
-        linear(m, hn, D, w[3], NULL, vn, KD, n, KD, D);
+        lin(m, hn, D, &w[2], NULL, kn, KD, n, KD, D);
+        lin(m, hn, D, &w[3], NULL, vn, KD, n, KD, D);
         rope(m, q, n, Hq, hd, hd, d->dec_theta, pos);
         rope(m, kn, n, Hkv, hd, hd, d->dec_theta, pos);
         /* sdpa_attention_forward: is_causal only when q_len > 1 (sdpa_attention.py) */
         attention(m, q, QD, kv[l].k, kv[l].v, KD, a, QD, n, past + n, Hq, Hkv, hd, n > 1, past);
-        linear(m, a, QD, w[4], NULL, o, D, n, D, QD);
+        lin(m, a, QD, &w[4], NULL, o, D, n, D, QD);
         for (long i = 0; i < (long)n * D; ++i) x[i] = RB(m, x[i] + o[i]);
         rmsnorm(m, x, w[5], hn, n, D, d->dec_rms_eps);
-        linear(m, hn, D, w[6], NULL, g, FF, n, FF, D);
-        linear(m, hn, D, w[7], NULL, u, FF, n, FF, D);
+        lin(m, hn, D, &w[6], NULL, g, FF, n, FF, D);
+        lin(m, hn, D, &w[7], NULL, u, FF, n, FF, D);
         for (long i = 0; i < (long)n * FF; ++i) g[i] = RB(m, RB(m, silu(g[i])) * u[i]);
-        linear(m, g, FF, w[8], NULL, o, D, n, D, FF);
+        lin(m, g, FF, &w[8], NULL, o, D, n, D, FF);
         for (long i = 0; i < (long)n * D; ++i) x[i] = RB(m, x[i] + o[i]);
         if (layer_out) memcpy(layer_out + (long)l * n * D, x, sizeof(float) * (long)n * D);
     }
@@ -449,9 +590,7 @@ int oracle_transcribe_multi(const oracle_model *m, const float *feats, const int
     const oracle_dims *d = &m->d; int D = d->dec_d, KD = d->dec_kv_heads * d->dec_head_dim;
     int Tm = d->enc_T / d->merge;
     float *emb = (float *)malloc(sizeof(float) * (long)W * Tm * D);
-    int n_audio = 0;
-    for (int w = 0; w < W; ++w)
-        n_audio += oracle_audio_features(m, feats + (long)w * d->n_mels * d->n_frames, n_valid_frames[w], emb + (long)n_audio * D, o);
+    int n_audio = oracle_audio_features_multi(m, feats, n_valid_frames, W, emb, o);
     if (o && o->audio_embeds) memcpy(o->audio_embeds, emb, sizeof(float) * (long)n_audio * D);
     int n_ph = 0; for (int i = 0; i < P; ++i) n_ph += (prompt[i] == d->audio_token_id);
     if (n_ph != n_audio) { free(emb); return -1; }
@@ -510,4 +649,11 @@ void oracle_layernorm(const float *x, const float *w, const float *b, float *y, 
 void oracle_rmsnorm(const float *x, const float *w, float *y, int T, int d, float eps, int bf16) {
     oracle_model m; memset(&m, 0, sizeof(m)); m.bf16 = bf16; rmsnorm(&m, x, w, y, T, d, eps);
 }
-void oracle_encoder_layer(const oracle_model *m, int l, float *x, int T) { encoder_layer(m, l, x, T); }
+void oracle_encoder_layer(const oracle_model *m, int l, float *x, int T) { encoder_layer(m, l, x, T, 1); }
+
+/* LLM.int8 pieces for single-kernel tests: row-wise weight quantisation and one Linear8bitLt call on x[T][K] (fp16 values) */
+void oracle_quantize_rows(const float *w, long n_rows, long K, int8_t *cb, float *scb) { quantize_rows_int8(w, n_rows, K, cb, scb); }
+void oracle_linear_int8(const float *x, const int8_t *cb, const float *scb, const float *b, float *y, int T, int N, int K) {
+    linear_int8(x, K, cb, scb, b, y, N, T, N, K);
+}
+float oracle_round(float x, int mode) { return round_mode(mode, x); }

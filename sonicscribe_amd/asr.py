@@ -161,8 +161,6 @@ class ASRModel:
                  _allow_synthetic_prompt: bool = False):
         if mode not in ["native", "int8"]:
             raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
-        if mode == "int8":
-            raise ImportError("INT8 mode is not available in this build of the HIP engine")  # asr.py:49-50 analogue
         dev = str(device)
         if dev.startswith("cpu"):
             raise RuntimeError("sonicscribe_amd runs on MI355X only: DEVICE=cpu has no HIP path (no CPU fallback by design)")
@@ -171,20 +169,21 @@ class ASRModel:
             raise RuntimeError(f"HIP device {self.device_index} not available")
         self.device = f"cuda:{self.device_index}"
         self.mode = mode
-        self.model_dtype = "bfloat16"
+        self.model_dtype = "bfloat16" if mode == "native" else "float16"                     # asr.py:61
+        emode = MODE_NATIVE if mode == "native" else MODE_INT8
         self.checkpoint_dir = Path(checkpoint_dir)
         self.target_sr = 16000
         self.is_glm_asr = True
         self.processor = None
         if _synthetic_seed is not None:
             self.dims = _dims or FULL
-            self.model = Engine(self.dims, self.device_index, MODE_NATIVE, max_batch, max_ctx)
+            self.model = Engine(self.dims, self.device_index, emode, max_batch, max_ctx)
             self.model.load_synthetic(_synthetic_seed)
             self.prompt = SyntheticPrompt(self.dims)
         else:
             from . import weights
             self.dims = weights.load_dims(str(self.checkpoint_dir))
-            self.model = Engine(self.dims, self.device_index, MODE_NATIVE, max_batch, max_ctx)
+            self.model = Engine(self.dims, self.device_index, emode, max_batch, max_ctx)
             weights.load_checkpoint(self.model, str(self.checkpoint_dir))
             try:
                 from transformers import AutoProcessor
@@ -203,8 +202,8 @@ class ASRModel:
               f"{self.model.weight_bytes() / 2**20:.0f} MiB weights)")
 
     @classmethod
-    def from_synthetic(cls, dims: ModelDims = FULL, seed: int = 20260128, device: str = "cuda", **kw) -> "ASRModel":
-        return cls("<synthetic>", device=device, mode="native", _dims=dims, _synthetic_seed=seed, **kw)
+    def from_synthetic(cls, dims: ModelDims = FULL, seed: int = 20260128, device: str = "cuda", mode: str = "native", **kw) -> "ASRModel":
+        return cls("<synthetic>", device=device, mode=mode, _dims=dims, _synthetic_seed=seed, **kw)
 
     # -- reference helpers kept under their reference names
     def _format_hotwords_prompt(self, hotwords: List[str], max_hotwords: int = 10) -> str:
@@ -265,7 +264,7 @@ class ASRModel:
         return [self.prompt.decode(i).strip() for i in ids]
 
     def get_model_info(self) -> Dict[str, Any]:
-        return {"mode": self.mode, "device": str(self.device), "model_dtype": "torch.bfloat16", "target_sampling_rate": self.target_sr,
+        return {"mode": self.mode, "device": str(self.device), "model_dtype": "torch." + self.model_dtype, "target_sampling_rate": self.target_sr,
                 "checkpoint_dir": str(self.checkpoint_dir), "is_glm_asr": self.is_glm_asr, "engine": "sonicscribe_amd/gfx950",
                 "gpu_name": "AMD Instinct MI355X", "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0}
 

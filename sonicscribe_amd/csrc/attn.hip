@@ -18,6 +18,7 @@
 // rows, fp32 scores in LDS, one block per (sequence, kv head) serving its 4 query heads together.
 #include "common.h"
 #include "kernels.h"
+#include "int8_util.h"
 #include <type_traits>
 
 
@@ -43,8 +44,10 @@ template <int HD> __device__ __forceinline__ int kswz(int row) {  // swizzle ter
     return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
 }
 
-template <int HD, bool CAUSAL>
+template <typename T, int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
+    typedef typename ET<T>::v8 V8;
+    typedef typename ET<T>::v4 V4;
     constexpr int HS = HD / 32;        // hd k-steps for S^T
     constexpr int HB = HD / 16;        // hd blocks of O^T
     constexpr int KCH = HD / 8;        // 16-B chunks per K row
@@ -65,20 +68,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     if (q0 >= q_len) return;
     const long qbase = a.q_off ? (long)a.q_off[b] * a.q_ld : (long)b * a.q_seq_stride;
     const long obase = a.q_off ? (long)a.q_off[b] * a.o_ld : (long)b * (a.q_seq_stride / a.q_ld) * a.o_ld;
-    const bf16_t* Q = a.Q + qbase + (long)h * HD;
-    const bf16_t* K = a.K + (long)b * a.k_seq_stride + (long)kh * a.k_head_stride;
-    const bf16_t* Vt = a.Vt + (long)b * a.vt_seq_stride + (long)kh * a.vt_head_stride;
+    const T* Q = (const T*)a.Q + qbase + (long)h * HD;
+    const T* K = (const T*)a.K + (long)b * a.k_seq_stride + (long)kh * a.k_head_stride;
+    const T* Vt = (const T*)a.Vt + (long)b * a.vt_seq_stride + (long)kh * a.vt_head_stride;
     const int qpos_off = kv_len - q_len;  // absolute position of query 0 (causal)
 
     // Q fragments (B-operand): lane holds Q[query = qb*16 + fr][hd = hs*32 + fg*8 .. +7]
-    bf16x8 qf[2][HS];
+    V8 qf[2][HS];
     int qrow[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         qrow[qb] = q0 + wid * 32 + qb * 16 + fr;
         const int qr = qrow[qb] < q_len ? qrow[qb] : q_len - 1;
 #pragma unroll
-        for (int hs = 0; hs < HS; ++hs) qf[qb][hs] = *(const bf16x8*)(Q + (long)qr * a.q_ld + hs * 32 + fg * 8);
+        for (int hs = 0; hs < HS; ++hs) qf[qb][hs] = *(const V8*)(Q + (long)qr * a.q_ld + hs * 32 + fg * 8);
     }
 
     // Make the compiler retire the Q loads HERE: otherwise its waitcnt bookkeeping carries them into the tile loop as "possibly
@@ -101,16 +104,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     }
 
     // register-staged prefetch (issue-early / write-late)
-    bf16x8 kreg[KV_PASSES], vreg[KV_PASSES];
+    V8 kreg[KV_PASSES], vreg[KV_PASSES];
     auto issue = [&](int kt) {
         const int key0 = kt * 64;
 #pragma unroll
         for (int p = 0; p < KV_PASSES; ++p) {
             const int idx = p * 256 + tid;
             const int kr = idx / KCH, kc = idx % KCH;        // K tile: row = key, chunk of 8 hd
-            kreg[p] = *(const bf16x8*)(K + (long)(key0 + kr) * a.k_ld + kc * 8);
+            kreg[p] = *(const V8*)(K + (long)(key0 + kr) * a.k_ld + kc * 8);
             const int vr = idx >> 3, vc = idx & 7;           // V^T tile: row = hd, chunk of 8 keys
-            vreg[p] = *(const bf16x8*)(Vt + (long)vr * a.vt_ld + key0 + vc * 8);
+            vreg[p] = *(const V8*)(Vt + (long)vr * a.vt_ld + key0 + vc * 8);
         }
     };
     auto commit = [&]() {
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
         for (int p = 0; p < KV_PASSES; ++p) {
             const int idx = p * 256 + tid;
             const int kr = idx / KCH, kc = idx % KCH;
-            *(bf16x8*)(sK + kr * KROW + ((kc ^ kswz<HD>(kr)) << 4)) = kreg[p];
+            *(V8*)(sK + kr * KROW + ((kc ^ kswz<HD>(kr)) << 4)) = kreg[p];
             const int vr = idx >> 3, vc = idx & 7;
-            *(bf16x8*)(sV + vr * 128 + ((vc ^ (vr & 7)) << 4)) = vreg[p];
+            *(V8*)(sV + vr * 128 + ((vc ^ (vr & 7)) << 4)) = vreg[p];
         }
     };
 
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
 #pragma unroll
                 for (int hs = 0; hs < HS; ++hs) {
                     const int c = hs * 4 + fg;
-                    const bf16x8 kf = *(const bf16x8*)(sK + krow * KROW + ((c ^ kswz<HD>(krow)) << 4));
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][hs], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][hs], s1, 0, 0, 0);
+                    const V8 kf = *(const V8*)(sK + krow * KROW + ((c ^ kswz<HD>(krow)) << 4));
+                    s0 = ET<T>::mfma(kf, qf[0][hs], s0);
+                    s1 = ET<T>::mfma(kf, qf[1][hs], s1);
                 }
                 st[ks][sb][0] = s0;
                 st[ks][sb][1] = s1;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
         // and one v_exp_f32 per score.  Tiles that need no masking (all but the last key tile / the causal diagonal) take a branch
         // without the per-element compares and selects.
         const bool edge = (key0 + 64 > kv_len) || (CAUSAL && (key0 + 63 > q0 + wid * 32 + qpos_off));
-        bf16x8 pf[2][2];
+        V8 pf[2][2];
         const float cexp = a.scale * 1.44269504088896341f;
         auto softmax = [&](auto masked) {
 #pragma unroll
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
                         for (int j = 0; j < 4; ++j) {
                             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[ks][sb][qb][j], cexp, moff));
                             psum += p;
-                            pf[qb][ks][sb * 4 + j] = f2bf(p);
+                            pf[qb][ks][sb * 4 + j] = (T)p;
                         }
                 lrun[qb] = lrun[qb] * alpha + psum;
 #pragma unroll
@@ -210,24 +213,24 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
                 const int vr = hb * 16 + fr, c = ks * 4 + fg;
-                const bf16x8 vf = *(const bf16x8*)(sV + vr * 128 + ((c ^ (vr & 7)) << 4));
-                oacc[0][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][ks], oacc[0][hb], 0, 0, 0);
-                oacc[1][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ks], oacc[1][hb], 0, 0, 0);
+                const V8 vf = *(const V8*)(sV + vr * 128 + ((c ^ (vr & 7)) << 4));
+                oacc[0][hb] = ET<T>::mfma(vf, pf[0][ks], oacc[0][hb]);
+                oacc[1][hb] = ET<T>::mfma(vf, pf[1][ks], oacc[1][hb]);
             }
     }
 
     // ---- epilogue: O[query][h*HD + hb*16 + fg*4 + j] = O^T / l
-    bf16_t* O = a.O + obase + (long)h * HD;
+    T* O = (T*)a.O + obase + (long)h * HD;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float l = rows_sum(lrun[qb]);
         if (qrow[qb] < q_len) {
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
-                bf16x4 o;
+                V4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(oacc[qb][hb][j] / l);
-                *(bf16x4*)(O + (long)qrow[qb] * a.o_ld + hb * 16 + fg * 4) = o;
+                for (int j = 0; j < 4; ++j) o[j] = (T)(oacc[qb][hb][j] / l);
+                *(V4*)(O + (long)qrow[qb] * a.o_ld + hb * 16 + fg * 4) = o;
             }
         }
     }
@@ -235,10 +238,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
 
 void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s) {
     dim3 grid((max_q + 127) / 128, a.Hq, B), block(256);
-    if (hd == 64 && !causal) hipLaunchKernelGGL((flash_attn_kernel<64, false>), grid, block, 0, s, a);
-    else if (hd == 64 && causal) hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, block, 0, s, a);
-    else if (hd == 128 && causal) hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((flash_attn_kernel<128, false>), grid, block, 0, s, a);
+    DT_SWITCH(a.dt, T, {
+        if (hd == 64 && !causal) hipLaunchKernelGGL((flash_attn_kernel<T, 64, false>), grid, block, 0, s, a);
+        else if (hd == 64 && causal) hipLaunchKernelGGL((flash_attn_kernel<T, 64, true>), grid, block, 0, s, a);
+        else if (hd == 128 && causal) hipLaunchKernelGGL((flash_attn_kernel<T, 128, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((flash_attn_kernel<T, 128, false>), grid, block, 0, s, a);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,28 +260,30 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 //     256-byte per-wave LDS record, P.V on the VALU (V is row-major in the cache);
 //  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
 // Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
+template <typename T>
 __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
+    typedef typename ET<T>::v8 V8;
     constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
     __shared__ float s_acc[NW][GMAX][HD];
     __shared__ float s_m[NW][GMAX], s_l[NW][GMAX];
-    __shared__ __attribute__((aligned(16))) bf16_t s_q[GMAX + 2][HD];   // q heads (unscaled), then k, v of the new token (all bf16 values)
+    __shared__ __attribute__((aligned(16))) T s_q[GMAX + 2][HD];   // q heads (unscaled), then k, v of the new token (all T values)
     __shared__ __attribute__((aligned(16))) float s_p[NW][16][4];  // per wave: probabilities [key in slice][head]
     __shared__ __attribute__((aligned(16))) float s_mn[NW][4];     // per wave: new running max per head
     const int G = a.Hq / a.Hkv;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;                        // MFMA: A row / k-chunk;  V pieces: hd chunk r of key 4u + g
     const int b = blockIdx.x, kvh = blockIdx.y;
-    bf16_t* Kc = a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
-    bf16_t* Vc = a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    T* Kc = (T*)a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    T* Vc = (T*)a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
     const int cm1 = a.ctx_max - 1;
 
-    bf16x8 kf[4], vv[4], kfn[4], vvn[4];
-    auto load = [&](int k0, bf16x8 (&kd)[4], bf16x8 (&vd)[4]) {
+    V8 kf[4], vv[4], kfn[4], vvn[4];
+    auto load = [&](int k0, V8 (&kd)[4], V8 (&vd)[4]) {
         const int kr = min(k0 + r, cm1);
 #pragma unroll
-        for (int hs = 0; hs < 4; ++hs) kd[hs] = *(const bf16x8*)(Kc + (long)kr * HD + hs * 32 + g * 8);
+        for (int hs = 0; hs < 4; ++hs) kd[hs] = *(const V8*)(Kc + (long)kr * HD + hs * 32 + g * 8);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vd[u] = *(const bf16x8*)(Vc + (long)min(k0 + 4 * u + g, cm1) * HD + r * 8);
+        for (int u = 0; u < 4; ++u) vd[u] = *(const V8*)(Vc + (long)min(k0 + 4 * u + g, cm1) * HD + r * 8);
     };
     load(wid * 16, kf, vv);
 
@@ -289,29 +296,36 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         float x1 = 0.f, x2 = 0.f;
         if (act) {
             const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
-            // all slab loads in flight at once (a rolled loop would serialise one L2 round trip per slab); fixed summation order
-            float v1[8], v2[8];
+            if (a.dq.sca) {
+                // int8 mode: int32 slabs of the quantised q/k/v projections -> fp16 module outputs (LLM.int8 dequant + outliers)
+                const int c4 = col & ~3;
+                const f32x4 d1 = deq4(a.dq, a.P, a.ksplit, a.mpad, b, c4, N), d2 = deq4(a.dq, a.P, a.ksplit, a.mpad, b, c4 + HALF, N);
+                x1 = d1[col & 3]; x2 = d2[col & 3];
+            } else {
+                // all slab loads in flight at once (a rolled loop would serialise one L2 round trip per slab); fixed summation order
+                float v1[8], v2[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float* p = a.P + ((long)(ks < a.ksplit ? ks : 0) * a.mpad + b) * N + col;
-                v1[ks] = p[0]; v2[ks] = p[HALF];
+                for (int ks = 0; ks < 8; ++ks) {
+                    const float* p = a.P + ((long)(ks < a.ksplit ? ks : 0) * a.mpad + b) * N + col;
+                    v1[ks] = p[0]; v2[ks] = p[HALF];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    if (ks < a.ksplit) { x1 += v1[ks]; x2 += v2[ks]; }
             }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                if (ks < a.ksplit) { x1 += v1[ks]; x2 += v2[ks]; }
         }
         n = min(max(a.kv_len[b], 1), a.ctx_max);      // (clamped: the cache / RoPE table rows of this block end at ctx_max)
         if (act) {
             const int pos = n - 1;
-            x1 = rbf(x1); x2 = rbf(x2);
+            x1 = rT<T>(x1); x2 = rT<T>(x2);
             float o1 = x1, o2 = x2;
             if (vi <= G) {
                 const float c = a.cs[(long)pos * HD + i], sn = a.cs[(long)pos * HD + HALF + i];
-                o1 = rbf(rbf(x1 * c) + rbf(-x2 * sn));
-                o2 = rbf(rbf(x2 * c) + rbf(x1 * sn));
+                o1 = rT<T>(rT<T>(x1 * c) + rT<T>(-x2 * sn));
+                o2 = rT<T>(rT<T>(x2 * c) + rT<T>(x1 * sn));
             }
             const int row = vi < G ? vi : (vi == G ? GMAX : GMAX + 1);
-            const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
+            const T b1 = (T)o1, b2 = (T)o2;
             s_q[row][i] = b1; s_q[row][HALF + i] = b2;
             if (vi == G) { Kc[(long)pos * HD + i] = b1; Kc[(long)pos * HD + HALF + i] = b2; }
             if (vi == G + 1) { Vc[(long)pos * HD + i] = b1; Vc[(long)pos * HD + HALF + i] = b2; }
@@ -321,13 +335,13 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         n = min(max(a.kv_len[b], 1), a.ctx_max);
     }
     // q as the MFMA B operand: column r = head (zero beyond the group), k = head-dim
-    bf16x8 qf[4];
+    V8 qf[4];
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
-        const bf16x8 t = a.P ? *(const bf16x8*)&s_q[r < G ? r : 0][hs * 32 + g * 8]
-                             : *(const bf16x8*)(a.Q + (long)b * a.Hq * HD + (kvh * G + (r < G ? r : 0)) * HD + hs * 32 + g * 8);
+        const V8 t = a.P ? *(const V8*)&s_q[r < G ? r : 0][hs * 32 + g * 8]
+                         : *(const V8*)((const T*)a.Q + (long)b * a.Hq * HD + (kvh * G + (r < G ? r : 0)) * HD + hs * 32 + g * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[hs][j] = r < G ? t[j] : f2bf(0.f);
+        for (int j = 0; j < 8; ++j) qf[hs][j] = r < G ? t[j] : (T)0.f;
     }
     float m[GMAX], lsum = 0.f, acc[GMAX][8];
 #pragma unroll
@@ -336,10 +350,10 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[h][i] = 0.f;
     }
-    auto step = [&](int k0, const bf16x8 (&kd)[4], const bf16x8 (&vd)[4], int limit) {
+    auto step = [&](int k0, const V8 (&kd)[4], const V8 (&vd)[4], int limit) {
         f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int hs = 0; hs < 4; ++hs) st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kd[hs], qf[hs], st, 0, 0, 0);
+        for (int hs = 0; hs < 4; ++hs) st = ET<T>::mfma(kd[hs], qf[hs], st);
         float sc[4], mx = -1e30f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { sc[j] = (k0 + g * 4 + j) < limit ? st[j] * a.scale : -1e30f; mx = fmaxf(mx, sc[j]); }
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         const float mn = fmaxf(m_r, mx);
         float ps = 0.f, pr[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float pv = (k0 + g * 4 + j) < limit ? __expf(sc[j] - mn) : 0.f; ps += pv; pr[j] = rbf(pv); }
+        for (int j = 0; j < 4; ++j) { const float pv = (k0 + g * 4 + j) < limit ? __expf(sc[j] - mn) : 0.f; ps += pv; pr[j] = rT<T>(pv); }
         lsum = lsum * __expf(m_r - mn) + ps;
         if (r < 4) {
 #pragma unroll
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
             for (int i = 0; i < 8; ++i) {
                 float t = acc[h][i] * alpha;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) t += pk[u][h] * bf2f(vd[u][i]);
+                for (int u = 0; u < 4; ++u) t += pk[u][h] * (float)vd[u][i];
                 acc[h][i] = t;
             }
         }
@@ -387,9 +401,9 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     if (a.P && wid == NW - 1) {              // the token being decoded: its k / v are still in LDS (slice key 0 only); the last wave has
                                              // the fewest cached slices (slices go round-robin from wave 0), so it takes the extra step
 #pragma unroll
-        for (int hs = 0; hs < 4; ++hs) kf[hs] = *(const bf16x8*)&s_q[GMAX][hs * 32 + g * 8];
+        for (int hs = 0; hs < 4; ++hs) kf[hs] = *(const V8*)&s_q[GMAX][hs * 32 + g * 8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vv[u] = *(const bf16x8*)&s_q[GMAX + 1][r * 8];
+        for (int u = 0; u < 4; ++u) vv[u] = *(const V8*)&s_q[GMAX + 1][r * 8];
         step(0, kf, vv, 1);
     }
     // merge: per wave the row sums over the 4 key quarters, the outputs over the 4 V-owner groups; then the 8 waves
@@ -412,10 +426,10 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][h] - M); num += f * s_acc[w][h][e]; den += f * s_l[w][h]; }
-        a.O[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = f2bf(num / den);
+        ((T*)a.O)[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = (T)(num / den);
     }
 }
 
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {
-    hipLaunchKernelGGL(decode_attn_kernel, dim3(B, a.Hkv), dim3(512), 0, s, a);
+    DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a));
 }

@@ -9,6 +9,32 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// Activation / weight element type of an engine: bf16 (mode "native", asr.py:61) or IEEE half (mode "int8": the reference runs its
+// non-quantised ops in torch.float16, asr.py:61,296).  Buffers are typed bf16_t* throughout the host code (2-byte storage); kernels
+// are templated on T and reinterpret.  DT_* is the runtime tag the launchers switch on.
+enum { DT_BF16 = 0, DT_F16 = 1 };
+template <typename T> struct ET;
+template <> struct ET<bf16_t> {
+    typedef bf16x8 v8; typedef bf16x4 v4; typedef bf16x2 v2;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct ET<f16_t> {
+    typedef f16x8 v8; typedef f16x4 v4; typedef f16x2 v2;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <typename T> __device__ __forceinline__ float rT(float x) { return (float)((T)x); }   // round-trip through the element type (RNE)
+// fp16: the fp32 value must exist before it is rounded to half.  Without the barrier hipcc folds `fma -> f16` into one
+// v_fma_mixlo_f16 (a single rounding of the exact result); torch / CUDA round the op's fp32 result and then convert (two roundings),
+// and the two disagree on exact ties (measured: 4e-5 of the dequantised outputs of an int8 GEMM).
+template <> __device__ __forceinline__ float rT<f16_t>(float x) { asm volatile("" : "+v"(x)); return (float)((f16_t)x); }
+// host-side dispatch on the runtime tag: DT_SWITCH(dt, T, launch<T>(...))
+#define DT_SWITCH(dt, T, ...) do { if ((dt) == DT_F16) { typedef f16_t T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)
 
 #define WAVE 64
 
@@ -76,9 +102,18 @@ enum GemmEpi {
     EPI_QKV_VT = 4,     // encoder QKV: columns < n_split -> C (row-major, ldc); columns >= n_split -> V^T [seg][col][t]
 };
 
+// int8 GEMM (Linear8bitLt): A and W are int8, the epilogue dequantises with the row statistics and adds the outlier columns
+struct GemmI8 {
+    const float* sca;                 // [M] row absmax of the quantised activations (NULL: not an int8 GEMM)
+    const float* scb;                 // [N] row absmax of the weights
+    const bf16_t* x16; long ldx16;    // unquantised activations (fp16 storage) for the outlier columns
+    const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group
+    const int* row_group; int group_div;                 // group of row m = row_group ? row_group[m / group_div] : m / group_div
+};
+
 struct GemmArgs {
-    const bf16_t* A; long lda;       // [M][K] row stride lda (elements); lda < K allowed (overlapping im2col rows)
-    const bf16_t* W;                 // [N][K] contiguous rows (torch Linear layout)
+    const bf16_t* A; long lda;       // [M][K] row stride lda (elements); lda < K allowed (overlapping im2col rows).  int8 GEMM: int8_t data
+    const bf16_t* W;                 // [N][K] contiguous rows (torch Linear layout).  int8 GEMM: int8_t data
     bf16_t* C; long ldc;
     const float* bias;               // [N] or null
     const bf16_t* R; long ldr;       // residual (EPI_BIAS_RESID)
@@ -86,18 +121,40 @@ struct GemmArgs {
     int batch; long strideA, strideC, strideR;   // blockIdx.z batches (conv stem: one per segment)
     // EPI_QKV_VT
     bf16_t* Vt; int n_split; int seg_T; int vt_ld; long vt_seg_stride;  // Vt[seg][n - n_split][t], row stride vt_ld
+    int dt;                          // DT_BF16 / DT_F16: element type of A, W (16-bit GEMM) and of C, R, Vt
+    GemmI8 q;                        // q.sca != NULL: int8 GEMM, outputs fp16
 };
 
+// Operand kinds of the MFMA GEMM kernels: element, 16-byte fragment, accumulator, output element type
+struct KBF16 {
+    typedef bf16_t elem; typedef bf16_t out; typedef bf16x8 frag; typedef f32x4 acc; static constexpr bool I8 = false;
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+struct KF16 {
+    typedef f16_t elem; typedef f16_t out; typedef f16x8 frag; typedef f32x4 acc; static constexpr bool I8 = false;
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+struct KI8 {   // v_mfma_i32_16x16x64_i8: 16 int8 of k per lane and step, lane l: row l & 15, k = 16 * (l >> 4) + j
+    typedef int8_t elem; typedef f16_t out; typedef i32x4 frag; typedef i32x4 acc; static constexpr bool I8 = true;
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+};
+// host-side dispatch: KD_SWITCH(args, KD, launch<KD>(...))
+#define KD_SWITCH(a, KD, ...) do { if ((a).q.sca) { typedef KI8 KD; __VA_ARGS__; } else if ((a).dt == DT_F16) { typedef KF16 KD; __VA_ARGS__; } \
+                                   else { typedef KBF16 KD; __VA_ARGS__; } } while (0)
+
 struct SkinnyArgs {
-    const bf16_t* X; long ldx;       // [M<=64][K]
-    const bf16_t* W;                 // [N][K] in fragment-tiled order (launch_tile_weights)
-    float* P;                        // partial slabs [ksplit][Mpad][N] fp32
+    const bf16_t* X; long ldx;       // [M<=64][K]   (i8: int8_t data)
+    const bf16_t* W;                 // [N][K] in fragment-tiled order (launch_tile_weights / launch_tile_weights_i8)
+    float* P;                        // partial slabs [ksplit][Mpad][N] fp32 (i8: int32 bit patterns)
     int M, N, K, ksplit;
+    int dt;                          // DT_BF16 / DT_F16
+    int i8;                          // int8 operands (Linear8bitLt decode step): int32 slabs, dequantised by the consumer
 };
 
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
+int skinny_pick_ksplit_i8(int N, int K);
 bool skinny_gu_eligible(int M, int N, int K);
 void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s);
 void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, int nblk, const float* w, float eps, hipStream_t s);

@@ -1,20 +1,62 @@
 // Memory-bound glue kernels: LayerNorm / RMSNorm with wavefront
 // reductions, rotate-half RoPE (partial-32 encoder, full-128 decoder) fused with the KV-cache append,
 // the decode-step consumers of the skinny-GEMM partial slabs, embedding gather, fused argmax + greedy
-// controller, synthetic weight generator.  All bf16 traffic is 16 B per lane (8 elements).
+// controller, synthetic weight generator.  All 16-bit traffic is 16 B per lane (8 elements).
 //
-// Rounding boundaries reproduce torch's bf16 op sequence of the reference path (`mode="native"`):
-// every torch op output is rounded to bf16 once, arithmetic inside an op is fp32.
+// Rounding boundaries reproduce torch's op sequence of the reference path: every torch op output is rounded to the
+// activation dtype once, arithmetic inside an op is fp32.  Kernels are templated on that dtype T: bf16 (`mode="native"`) or
+// IEEE half (`mode="int8"`, asr.py:61,296).  In int8 mode the decode-step consumers read int32 slabs of a quantised skinny
+// GEMM (deq4) and producers that own whole rows also emit them quantised for the next Linear8bitLt (quant_emit_row).
 #include "common.h"
 #include "kernels.h"
 
+#include "int8_util.h"
+
+// A block that owns one whole row (thread c holds its elements [8c, 8c+8) as fp16 values in y, threads with !active hold nothing)
+// emits the row quantised: absmax without the elements >= 6.0, int8 = rn(y * 127 / absmax) (0 for outliers), and the ascending
+// list of the outlier positions.  Every thread of the block must call it.  s_f: >= 16 floats, s_i: >= 17 ints of LDS scratch.
+__device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active, int c, int row, const QuantOut& qo, float* s_f, int* s_i) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    float amax = -1.17549435e-38f;
+    int cnt = 0;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float a = fabsf(y[j]); if (a < LLM_INT8_THRESHOLD) amax = fmaxf(amax, a); else ++cnt; }
+    }
+    amax = wave_max(amax);
+    int incl = cnt;                                   // inclusive scan of the outlier counts inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    __syncthreads();                                  // scratch may still be in use by the caller
+    if (lane == 63) s_i[wid] = incl;
+    if (lane == 0) s_f[wid] = amax;
+    __syncthreads();
+    float bm = s_f[0]; int base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { bm = fmaxf(bm, s_f[w]); if (w < wid) base += s_i[w]; total += s_i[w]; }
+    const float scale = 127.0f / bm;
+    if (tid == 0) { qo.sca[row] = bm; qo.oc_cnt[row] = total; }
+    if (active) {
+        int pos = base + incl - cnt;
+        int pk[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool out = !(fabsf(y[j]) < LLM_INT8_THRESHOLD);
+            int qv = (out || !(bm > 0.f)) ? 0 : (int)rintf(y[j] * scale);
+            pk[j >> 2] |= (qv & 0xFF) << ((j & 3) * 8);
+            if (out) qo.oc_list[(long)row * qo.oc_ld + pos++] = c * 8 + j;
+        }
+        *(int2*)(qo.q + (long)row * qo.ldq + c * 8) = make_int2(pk[0], pk[1]);
+    }
+}
+
 // ---------------------------------------------------------------- LayerNorm (modeling_glmasr.py:246-247,305)
 // one wave per row, d % 8 == 0, d <= 2048; two-pass in registers (mean, then centred variance).
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const float* w, const float* b, bf16_t* y,
-                                                        int rows, int d, float eps) {
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float* w, const float* b, T* y, int rows, int d, float eps) {
+    typedef typename ET<T>::v8 V8;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + (long)row * d;
+    const T* xr = x + (long)row * d;
     const int nv = d >> 3;
     float v[4][8];
     float s = 0.f;
@@ -22,9 +64,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const f
     for (int i = 0; i < 4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const bf16x8 t = *(const bf16x8*)(xr + c * 8);
+            const V8 t = *(const V8*)(xr + c * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); s += v[i][j]; }
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
         }
     }
     const float mean = wave_sum(s) / d;
@@ -40,33 +82,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const f
     for (int i = 0; i < 4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            bf16x8 o;
+            V8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(((v[i][j] - mean) * rstd) * w[c * 8 + j] + b[c * 8 + j]);
-            *(bf16x8*)(y + (long)row * d + c * 8) = o;
+            for (int j = 0; j < 8; ++j) o[j] = (T)(((v[i][j] - mean) * rstd) * w[c * 8 + j] + b[c * 8 + j]);
+            *(V8*)(y + (long)row * d + c * 8) = o;
         }
     }
 }
 
 // ---------------------------------------------------------------- RMSNorm (modeling_llama.py:60-65)
-__device__ __forceinline__ void rms_row(const float (&v)[4][8], float ssq, const float* w, bf16_t* yr, int lane, int nv, int d, float eps) {
-    const float r = 1.0f / sqrtf(wave_sum(ssq) / d + eps);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(w[c * 8 + j] * rbf(v[i][j] * r));
-            *(bf16x8*)(yr + c * 8) = o;
-        }
-    }
-}
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps,
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const float* w, T* y, int rows, int d, float eps,
                                                       const int* row_map /* optional gather: y[r] = norm(x[row_map[r]]) */) {
+    typedef typename ET<T>::v8 V8;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + (long)(row_map ? row_map[row] : row) * d;
+    const T* xr = x + (long)(row_map ? row_map[row] : row) * d;
     const int nv = d >> 3;
     float v[4][8];
     float s = 0.f;
@@ -74,51 +105,72 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* x, const flo
     for (int i = 0; i < 4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const bf16x8 t = *(const bf16x8*)(xr + c * 8);
+            const V8 t = *(const V8*)(xr + c * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); s += v[i][j] * v[i][j]; }
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j] * v[i][j]; }
         }
     }
-    rms_row(v, s, w, y + (long)row * d, lane, nv, d, eps);
+    const float r = 1.0f / sqrtf(wave_sum(s) / d + eps);
+    T* yr = y + (long)row * d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            V8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)(w[c * 8 + j] * rT<T>(v[i][j] * r));
+            *(V8*)(yr + c * 8) = o;
+        }
+    }
 }
 
-// decode: x[r] = bf16(x[r] + bf16(sum_ks P[ks][r][:])); y[r] = rmsnorm(x[r]) (o_proj / down_proj consumer).
+// decode: x[r] = T(x[r] + T(sum_ks P[ks][r][:])); y[r] = rmsnorm(x[r]) (o_proj / down_proj consumer).
 // one block of d/8 threads per row (the step has only <= 64 rows: parallelism comes from the row width).
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y,
-                                                          int rows, int d, float eps) {
-    __shared__ float part[4];
+// int8 mode (dq.sca != null): P holds the int32 slabs of the quantised projection; the normalised row is also emitted quantised (qo.q).
+template <typename T>
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, int ksplit, int mpad, const float* w, T* y,
+                                                          int rows, int d, float eps, DeqInfo dq, QuantOut qo) {
+    typedef typename ET<T>::v8 V8;
+    __shared__ float part[16];
+    __shared__ int parti[17];
     const int row = blockIdx.x, c = threadIdx.x, lane = c & 63, wid = c >> 6;
     const int nv = d >> 3;
     float v[8];
     float s = 0.f;
     if (c < nv) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        bf16_t* xr = x + (long)row * d + c * 8;
-        const bf16x8 t = *(const bf16x8*)xr;
-        // every slab load is issued before the first add (a rolled ksplit loop costs one L2 round trip per slab); the sum keeps its
-        // fixed order ks = 0, 1, ...
-        f32x4 a0[8], a1[8];
+        T* xr = x + (long)row * d + c * 8;
+        const V8 t = *(const V8*)xr;
+        if (dq.sca) {
+            const f32x4 a0 = deq4(dq, P, ksplit, mpad, row, c * 8, d), a1 = deq4(dq, P, ksplit, mpad, row, c * 8 + 4, d);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const float* p = P + ((long)(ks < ksplit ? ks : 0) * mpad + row) * d + c * 8;
-            a0[ks] = *(const f32x4*)p; a1[ks] = *(const f32x4*)(p + 4);
-        }
+            for (int j = 0; j < 4; ++j) { acc[j] = a0[j]; acc[4 + j] = a1[j]; }
+        } else {
+            // every slab load is issued before the first add (a rolled ksplit loop costs one L2 round trip per slab); the sum keeps its
+            // fixed order ks = 0, 1, ...
+            f32x4 a0[8], a1[8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (ks < ksplit) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[j] += a0[ks][j]; acc[4 + j] += a1[ks][j]; }
+            for (int ks = 0; ks < 8; ++ks) {
+                const float* p = P + ((long)(ks < ksplit ? ks : 0) * mpad + row) * d + c * 8;
+                a0[ks] = *(const f32x4*)p; a1[ks] = *(const f32x4*)(p + 4);
             }
-        for (int ks = 8; ks < ksplit; ++ks) {                         // (not reached by the current tilings: ksplit <= 8)
-            const float* p = P + ((long)ks * mpad + row) * d + c * 8;
-            const f32x4 b0 = *(const f32x4*)p, b1 = *(const f32x4*)(p + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] += b0[j]; acc[4 + j] += b1[j]; }
+            for (int ks = 0; ks < 8; ++ks)
+                if (ks < ksplit) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { acc[j] += a0[ks][j]; acc[4 + j] += a1[ks][j]; }
+                }
+            for (int ks = 8; ks < ksplit; ++ks) {                         // (not reached by the current tilings: ksplit <= 8)
+                const float* p = P + ((long)ks * mpad + row) * d + c * 8;
+                const f32x4 b0 = *(const f32x4*)p, b1 = *(const f32x4*)(p + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += b0[j]; acc[4 + j] += b1[j]; }
+            }
         }
-        bf16x8 o;
+        V8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] = f2bf(bf2f(t[j]) + rbf(acc[j])); v[j] = bf2f(o[j]); s += v[j] * v[j]; }
-        *(bf16x8*)xr = o;
+        for (int j = 0; j < 8; ++j) { o[j] = (T)((float)t[j] + rT<T>(acc[j])); v[j] = (float)o[j]; s += v[j] * v[j]; }
+        *(V8*)xr = o;
     }
     s = wave_sum(s);
     if (lane == 0) part[wid] = s;
@@ -127,16 +179,20 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(bf16_t* x, const float
     float tot = 0.f;
     for (int i = 0; i < nw; ++i) tot += part[i];
     const float r = 1.0f / sqrtf(tot / d + eps);
+    float yo[8];
     if (c < nv) {
-        bf16x8 o;
+        V8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(w[c * 8 + j] * rbf(v[j] * r));
-        *(bf16x8*)(y + (long)row * d + c * 8) = o;
+        for (int j = 0; j < 8; ++j) { o[j] = (T)(w[c * 8 + j] * rT<T>(v[j] * r)); yo[j] = (float)o[j]; }
+        *(V8*)(y + (long)row * d + c * 8) = o;
     }
+    if (qo.q) quant_emit_row(yo, c < nv, c, row, qo, part, parti);
 }
 
-// decode: act[r][c] = bf16(bf16(silu(bf16 g)) * bf16 u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)
-__global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 /* 2*ff */, bf16_t* act, int rows) {
+// decode: act[r][c] = T(T(silu(T g)) * T u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)
+template <typename T>
+__global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 /* 2*ff */, T* act, int rows) {
+    typedef typename ET<T>::v4 V4;
     const int ff = n2 >> 1;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 outputs
     if (idx >= (long)rows * (ff >> 2)) return;
@@ -149,41 +205,82 @@ __global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 
         g += *(const f32x4*)(p + ng);
         u += *(const f32x4*)(p + nu);
     }
-    bf16x4 o;
+    V4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(rbf(silu_f(rbf(g[j]))) * rbf(u[j]));
-    *(bf16x4*)(act + (long)row * ff + c4) = o;
+    for (int j = 0; j < 4; ++j) o[j] = (T)(rT<T>(silu_f(rT<T>(g[j]))) * rT<T>(u[j]));
+    *(V4*)(act + (long)row * ff + c4) = o;
+}
+
+// int8 decode: one block (1024 threads) per row; slabs hold the int32 products of the quantised gate and up projections, weight rows
+// interleaved in 16-row groups like the prefill GEMM's SwiGLU layout (one int8 copy serves both).  act = fp16(fp16(silu(g)) * u) and,
+// in the same pass, the row quantised for down_proj's Linear8bitLt.  ff <= 8192.
+__global__ __launch_bounds__(1024) void swiglu_quant_kernel(const float* P, int ksplit, int mpad, int ff, f16_t* act, DeqInfo dq, QuantOut qo) {
+    __shared__ float part[16];
+    __shared__ int parti[17];
+    const int row = blockIdx.x, c = threadIdx.x;
+    const bool active = c * 8 < ff;
+    float y[8];
+    if (active) {
+        f16x8 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c4 = c * 8 + h * 4, ng = (c4 >> 4) * 32 + (c4 & 15);
+            const f32x4 g = deq4(dq, P, ksplit, mpad, row, ng, 2 * ff), u = deq4(dq, P, ksplit, mpad, row, ng + 16, 2 * ff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[h * 4 + j] = (f16_t)(rT<f16_t>(silu_f(g[j])) * u[j]); y[h * 4 + j] = (float)o[h * 4 + j]; }
+        }
+        *(f16x8*)(act + (long)row * ff + c * 8) = o;
+    }
+    quant_emit_row(y, active, c, row, qo, part, parti);
+}
+
+// decode flavour of the activation quantiser: one block per row of an fp16 matrix (K <= 8192)
+__global__ __launch_bounds__(1024) void quant_rows_kernel(const f16_t* X, long ld, int K, QuantOut qo) {
+    __shared__ float part[16];
+    __shared__ int parti[17];
+    const int row = blockIdx.x, c = threadIdx.x;
+    const bool active = c * 8 < K;
+    float y[8];
+    if (active) {
+        const f16x8 t = *(const f16x8*)(X + (long)row * ld + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (float)t[j];
+    }
+    quant_emit_row(y, active, c, row, qo, part, parti);
 }
 
 // ---------------------------------------------------------------- encoder RoPE (modeling_glmasr.py:153-168)
 // in place on the fused q|k buffer [M][ld]; first `rd` dims of each 64-dim head, pairs (i, i + rd/2);
-// cs table [T][rd] = cos[0..rd/2) | sin[0..rd/2) (bf16-rounded fp32).  one thread = 8 pairs.
-__global__ void rope_enc_kernel(bf16_t* qk, long ld, int M, int T, int heads2 /* q heads + k heads */, int hd, int rd, const float* cs) {
+// cs table [T][rd] = cos[0..rd/2) | sin[0..rd/2) (T-rounded fp32).  one thread = 8 pairs.
+template <typename T>
+__global__ void rope_enc_kernel(T* qk, long ld, int M, int Tn, int heads2 /* q heads + k heads */, int hd, int rd, const float* cs) {
+    typedef typename ET<T>::v8 V8;
     const int half = rd >> 1, per_head = half >> 3;  // threads per head
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)M * heads2 * per_head) return;
     const int u = idx % per_head, hh = (idx / per_head) % heads2;
-    const int m = idx / ((long)per_head * heads2), t = m % T;
-    bf16_t* p = qk + (long)m * ld + hh * hd + u * 8;
-    const bf16x8 a = *(const bf16x8*)p, bb = *(const bf16x8*)(p + half);
+    const int m = idx / ((long)per_head * heads2), t = m % Tn;
+    T* p = qk + (long)m * ld + hh * hd + u * 8;
+    const V8 a = *(const V8*)p, bb = *(const V8*)(p + half);
     const float* c = cs + (long)t * rd + u * 8;
     const float* s = c + half;
-    bf16x8 o1, o2;
+    V8 o1, o2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float x1 = bf2f(a[j]), x2 = bf2f(bb[j]);
-        o1[j] = f2bf(rbf(x1 * c[j]) + rbf(-x2 * s[j]));
-        o2[j] = f2bf(rbf(x2 * c[j]) + rbf(x1 * s[j]));
+        const float x1 = (float)a[j], x2 = (float)bb[j];
+        o1[j] = (T)(rT<T>(x1 * c[j]) + rT<T>(-x2 * s[j]));
+        o2[j] = (T)(rT<T>(x2 * c[j]) + rT<T>(x1 * s[j]));
     }
-    *(bf16x8*)p = o1;
-    *(bf16x8*)(p + half) = o2;
+    *(V8*)p = o1;
+    *(V8*)(p + half) = o2;
 }
 
 // ---------------------------------------------------------------- decoder RoPE + KV append (modeling_llama.py:121-143,261-262)
-// Source is either the bf16 QKV matrix of the prefill GEMM or the fp32 slabs of the decode skinny GEMM.
-// Writes roped q (bf16 [tok][Hq*128]), roped k -> K cache, v -> V cache, and (prefill) v^T -> Vt scratch.
-template <bool SLAB>
+// Source is either the 16-bit QKV matrix of the prefill GEMM or the fp32 slabs of the decode skinny GEMM.
+// Writes roped q ([tok][Hq*128]), roped k -> K cache, v -> V cache, and (prefill) v^T -> Vt scratch.
+template <typename T, bool SLAB>
 __global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
+    typedef typename ET<T>::v8 V8;
     constexpr int HD = 128, HALF = 64;
     const int tok = blockIdx.x;
     const int heads = a.Hq + 2 * a.Hkv;
@@ -201,38 +298,38 @@ __global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
                 for (int j = 0; j < 8; ++j) { x1[j] += p[j]; x2[j] += p[HALF + j]; }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { x1[j] = rbf(x1[j]); x2[j] = rbf(x2[j]); }
+            for (int j = 0; j < 8; ++j) { x1[j] = rT<T>(x1[j]); x2[j] = rT<T>(x2[j]); }
         } else {
-            const bf16_t* p = a.qkv + (long)tok * a.ld + hh * HD + u * 8;
-            const bf16x8 t1 = *(const bf16x8*)p, t2 = *(const bf16x8*)(p + HALF);
+            const T* p = (const T*)a.qkv + (long)tok * a.ld + hh * HD + u * 8;
+            const V8 t1 = *(const V8*)p, t2 = *(const V8*)(p + HALF);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { x1[j] = bf2f(t1[j]); x2[j] = bf2f(t2[j]); }
+            for (int j = 0; j < 8; ++j) { x1[j] = (float)t1[j]; x2[j] = (float)t2[j]; }
         }
-        bf16x8 o1, o2;
+        V8 o1, o2;
         if (hh < a.Hq + a.Hkv) {
             const float* c = a.cs + (long)pos * HD + u * 8;
             const float* s = c + HALF;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                o1[j] = f2bf(rbf(x1[j] * c[j]) + rbf(-x2[j] * s[j]));
-                o2[j] = f2bf(rbf(x2[j] * c[j]) + rbf(x1[j] * s[j]));
+                o1[j] = (T)(rT<T>(x1[j] * c[j]) + rT<T>(-x2[j] * s[j]));
+                o2[j] = (T)(rT<T>(x2[j] * c[j]) + rT<T>(x1[j] * s[j]));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { o1[j] = f2bf(x1[j]); o2[j] = f2bf(x2[j]); }
+            for (int j = 0; j < 8; ++j) { o1[j] = (T)x1[j]; o2[j] = (T)x2[j]; }
         }
         if (hh < a.Hq) {
-            bf16_t* q = a.q_out + (long)tok * a.Hq * HD + hh * HD + u * 8;
-            *(bf16x8*)q = o1; *(bf16x8*)(q + HALF) = o2;
+            T* q = (T*)a.q_out + (long)tok * a.Hq * HD + hh * HD + u * 8;
+            *(V8*)q = o1; *(V8*)(q + HALF) = o2;
         } else if (hh < a.Hq + a.Hkv) {
-            bf16_t* k = a.Kc + (((long)b * a.Hkv + (hh - a.Hq)) * a.ctx_max + pos) * HD + u * 8;
-            *(bf16x8*)k = o1; *(bf16x8*)(k + HALF) = o2;
+            T* k = (T*)a.Kc + (((long)b * a.Hkv + (hh - a.Hq)) * a.ctx_max + pos) * HD + u * 8;
+            *(V8*)k = o1; *(V8*)(k + HALF) = o2;
         } else {
             const int kvh = hh - a.Hq - a.Hkv;
-            bf16_t* v = a.Vc + (((long)b * a.Hkv + kvh) * a.ctx_max + pos) * HD + u * 8;
-            *(bf16x8*)v = o1; *(bf16x8*)(v + HALF) = o2;
+            T* v = (T*)a.Vc + (((long)b * a.Hkv + kvh) * a.ctx_max + pos) * HD + u * 8;
+            *(V8*)v = o1; *(V8*)(v + HALF) = o2;
             if (a.Vt) {
-                bf16_t* vt = a.Vt + ((long)b * a.Hkv + kvh) * HD * a.vt_ld + pos;
+                T* vt = (T*)a.Vt + ((long)b * a.Hkv + kvh) * HD * a.vt_ld + pos;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { vt[(long)(u * 8 + j) * a.vt_ld] = o1[j]; vt[(long)(HALF + u * 8 + j) * a.vt_ld] = o2[j]; }
             }
@@ -241,7 +338,7 @@ __global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
 }
 
 // ---------------------------------------------------------------- embedding gather / audio scatter (modeling_glmasr.py:452-465)
-// src[tok] >= 0: row of the embedding table; src[tok] < 0: audio row -(src+1) of `audio`.
+// src[tok] >= 0: row of the embedding table; src[tok] < 0: audio row -(src+1) of `audio`.  (2-byte copies: dtype-agnostic)
 __global__ void assemble_embeds_kernel(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d) {
     const int tok = blockIdx.x;
     const int s = src[tok];
@@ -250,9 +347,11 @@ __global__ void assemble_embeds_kernel(const int* src, const bf16_t* table, cons
 }
 
 // ---------------------------------------------------------------- argmax + greedy controller (generation/utils.py:2894-2936)
+template <typename T>
 __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
+    typedef typename ET<T>::v8 V8;
     __shared__ float sv[16];
-    __shared__ int si[16];
+    __shared__ int si[17];
     __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lg = a.logits + (long)b * a.V;
@@ -278,7 +377,7 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
             for (int ks = 2; ks < a.ksplit; ++ks) t += *(const f32x4*)(lg + ks * ks_stride + i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float r = rbf(t[j]);          // logits are bf16 in the reference, compared as fp32
+                const float r = rT<T>(t[j]);        // logits are T in the reference, compared as fp32
                 if (dump) dump[i + j] = r;
                 if (r > best) { best = r; bi = i + j; }   // strict > keeps the first maximum within a thread
             }
@@ -317,21 +416,22 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
         if (a.step_counter) a.step_counter[b] += 1;
     }
     __syncthreads();
-    const bf16_t* row = a.table + (long)s_tok * a.d;
+    const T* row = (const T*)a.table + (long)s_tok * a.d;
+    T* xo = (T*)a.x;
     if (!a.y || (a.d >> 3) > 1024) {
-        for (int c = tid; c < (a.d >> 3); c += 1024) *(bf16x8*)(a.x + (long)b * a.d + c * 8) = *(const bf16x8*)(row + c * 8);
+        for (int c = tid; c < (a.d >> 3); c += 1024) *(V8*)(xo + (long)b * a.d + c * 8) = *(const V8*)(row + c * 8);
         return;
     }
     // next step's input row and, in the same pass, the first decoder layer's input RMSNorm of it (modeling_llama.py:60-65, :306):
     // one launch less per token step
     const int c = tid, nv = a.d >> 3;
-    bf16x8 xv;
+    V8 xv;
     float ss = 0.f;
     if (c < nv) {
-        xv = *(const bf16x8*)(row + c * 8);
-        *(bf16x8*)(a.x + (long)b * a.d + c * 8) = xv;
+        xv = *(const V8*)(row + c * 8);
+        *(V8*)(xo + (long)b * a.d + c * 8) = xv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = bf2f(xv[j]); ss += f * f; }
+        for (int j = 0; j < 8; ++j) { const float f = (float)xv[j]; ss += f * f; }
     }
     ss = wave_sum(ss);
     __syncthreads();                         // sv is reused below
@@ -341,12 +441,14 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
 #pragma unroll
     for (int w = 0; w < 16; ++w) tot += sv[w];
     const float r = 1.0f / sqrtf(tot / a.d + a.norm_eps);
+    float yo[8];
     if (c < nv) {
-        bf16x8 o;
+        V8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(a.norm_w[c * 8 + j] * rbf(bf2f(xv[j]) * r));
-        *(bf16x8*)(a.y + (long)b * a.d + c * 8) = o;
+        for (int j = 0; j < 8; ++j) { o[j] = (T)(a.norm_w[c * 8 + j] * rT<T>((float)xv[j] * r)); yo[j] = (float)o[j]; }
+        *(V8*)((T*)a.y + (long)b * a.d + c * 8) = o;
     }
+    if (a.qo.q) quant_emit_row(yo, c < nv, c, b, a.qo, sv, si);
 }
 
 // ---------------------------------------------------------------- misc
@@ -360,13 +462,17 @@ __global__ void fill_i32_kernel(int* p, int value, int n) {
 void launch_fill_i32(int* p, int value, int n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, value, n);
 }
-__global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, long n) {
+template <typename T> __global__ void f32_to_t_kernel(const float* in, T* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f2bf(in[i]);
+    if (i < n) out[i] = (T)in[i];
 }
-__global__ void bf16_to_f32_kernel(const bf16_t* in, float* out, long n) {
+template <typename T> __global__ void t_to_f32_kernel(const T* in, float* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = bf2f(in[i]);
+    if (i < n) out[i] = (float)in[i];
+}
+__global__ void bf16_to_f16_kernel(const bf16_t* in, f16_t* out, long n) {   // a bf16 checkpoint loaded with torch_dtype=float16 (asr.py:156)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (f16_t)(float)in[i];
 }
 
 // sonicscribe_amd/synth.py restated for the device: writes bf16 and/or fp32
@@ -387,38 +493,54 @@ __global__ void synth_fill_kernel(unsigned long long key, long n, float scale, f
 }
 
 // ---------------------------------------------------------------- launchers
-void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, d, eps);
+void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt) {
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps));
 }
-void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s) {
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, rows, d, eps, row_map);
+void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt) {
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map));
 }
-void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s) {
+void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
+                        int dt, const DeqInfo* dq, const QuantOut* qo) {
     const int threads = ((d >> 3) + 63) / 64 * 64;   // d <= 2048 -> <= 256 threads
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(rows), dim3(threads), 0, s, x, P, ksplit, mpad, w, y, rows, d, eps);
+    const DeqInfo q = dq ? *dq : DeqInfo{};
+    const QuantOut o = qo ? *qo : QuantOut{};
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(add_rmsnorm_kernel<T>, dim3(rows), dim3(threads), 0, s, (T*)x, P, ksplit, mpad, w, (T*)y, rows, d, eps, q, o));
 }
-void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s) {
+void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt) {
     const long n = (long)rows * (n2 >> 3);
-    hipLaunchKernelGGL(swiglu_slab_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, ksplit, mpad, n2, act, rows);
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(swiglu_slab_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, P, ksplit, mpad, n2, (T*)act, rows));
 }
-void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s) {
+void launch_swiglu_quant(const float* P, int ksplit, int mpad, int ff, bf16_t* act, int rows, const DeqInfo& dq, const QuantOut& qo, hipStream_t s) {
+    hipLaunchKernelGGL(swiglu_quant_kernel, dim3(rows), dim3(1024), 0, s, P, ksplit, mpad, ff, (f16_t*)act, dq, qo);
+}
+void launch_quant_rows(const bf16_t* X, long ld, int M, int K, const QuantOut& qo, hipStream_t s) {
+    hipLaunchKernelGGL(quant_rows_kernel, dim3(M), dim3(1024), 0, s, (const f16_t*)X, ld, K, qo);
+}
+void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s, int dt) {
     const long n = (long)M * heads2 * (rd >> 4);
-    hipLaunchKernelGGL(rope_enc_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qk, ld, M, T, heads2, hd, rd, cs);
+    DT_SWITCH(dt, E, hipLaunchKernelGGL(rope_enc_kernel<E>, dim3((n + 255) / 256), dim3(256), 0, s, (E*)qk, ld, M, T, heads2, hd, rd, cs));
 }
 void launch_rope_append(const RopeAppendArgs& a, bool slab, hipStream_t s) {
     if (a.n_tok <= 0) return;
-    if (slab) hipLaunchKernelGGL(rope_append_kernel<true>, dim3(a.n_tok), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(rope_append_kernel<false>, dim3(a.n_tok), dim3(256), 0, s, a);
+    DT_SWITCH(a.dt, T, {
+        if (slab) hipLaunchKernelGGL((rope_append_kernel<T, true>), dim3(a.n_tok), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((rope_append_kernel<T, false>), dim3(a.n_tok), dim3(256), 0, s, a);
+    });
 }
 void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d, hipStream_t s) {
     if (n_tok > 0) hipLaunchKernelGGL(assemble_embeds_kernel, dim3(n_tok), dim3(256), 0, s, src, table, audio, x, n_tok, d);
 }
-void launch_greedy(const GreedyArgs& a, hipStream_t s) { hipLaunchKernelGGL(greedy_kernel, dim3(a.B), dim3(1024), 0, s, a); }
-void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+void launch_greedy(const GreedyArgs& a, hipStream_t s) {
+    DT_SWITCH(a.dt, T, hipLaunchKernelGGL(greedy_kernel<T>, dim3(a.B), dim3(1024), 0, s, a));
 }
-void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s, int dt) {
+    if (n > 0) DT_SWITCH(dt, T, hipLaunchKernelGGL(f32_to_t_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, in, (T*)out, n));
+}
+void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s, int dt) {
+    if (n > 0) DT_SWITCH(dt, T, hipLaunchKernelGGL(t_to_f32_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, (const T*)in, out, n));
+}
+void launch_bf16_to_f16(const bf16_t* in, bf16_t* out, long n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(bf16_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, (f16_t*)out, n);
 }
 void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(synth_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, key, n, scale, offset, out_bf, out_f32);

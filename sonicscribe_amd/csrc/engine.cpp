@@ -27,13 +27,18 @@ struct DevTensor {
     size_t n = 0;
 };
 
-struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; };
+// int8 mode (asr.py:169-210): a quantised Linear keeps row-wise int8 weights + row absmax instead of its 16-bit matrix
+struct QW { int8_t* cb = nullptr; float* scb = nullptr; int8_t* cbt = nullptr; };   // cbt: fragment-tiled copy for the decode step
+struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; QW qqkv, qo, q1, q2; };
 struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          // row-major (prefill GEMM)
-                   bf16_t *wqkv_t, *wo_t, *wgu_t, *wgu_t8, *wdown_t; };                 // fragment-tiled copies (decode skinny GEMM)
+                   bf16_t *wqkv_t, *wo_t, *wgu_t, *wgu_t8, *wdown_t;                    // fragment-tiled copies (decode skinny GEMM)
+                   QW qqkv, qo, qgu, qdown; };
 
 struct sonic_engine {
     sonic_dims d;
     int device = 0, mode = 0, Bm = 0, max_ctx = 0;
+    int dt = DT_BF16;          // activation / 16-bit weight element type: bf16 (native) or fp16 (int8 mode, asr.py:61)
+    bool i8 = false;           // LLM.int8 linears
     hipStream_t st = nullptr;
     std::mutex mu;
     std::string err;
@@ -46,7 +51,14 @@ struct sonic_engine {
     bf16_t *conv1w = nullptr, *conv2w = nullptr; float *conv1b = nullptr, *conv2b = nullptr;
     std::vector<EncLayerW> enc;
     float *enc_nw = nullptr, *enc_nb = nullptr;
-    bf16_t *pj1w = nullptr, *pj2w = nullptr; float *pj1b = nullptr, *pj2b = nullptr;
+    bf16_t *pj1w = nullptr, *pj2w = nullptr; float *pj1b = nullptr, *pj2b = nullptr; QW qpj1, qpj2;
+    // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
+    int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
+    int q_kmax = 0; bf16_t* qkv_rm = nullptr;
+    // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
+    int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
+    int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
+    std::map<std::string, bool> raw_f16;   // int8 mode: tensors already converted to fp16 at load
     bf16_t* embed = nullptr; bf16_t* embed_t = nullptr;
     std::vector<DecLayerW> dec;
     float* dec_nw = nullptr;
@@ -156,12 +168,12 @@ static uint64_t fnv1a64h(const char* s) { uint64_t h = 0xCBF29CE484222325ULL; fo
 
 // small in-file kernels ---------------------------------------------------------------------------
 // [B][n_mels][n_frames] fp32 (HF layout) -> frame-major bf16 with one zero row each side
-__global__ void feats_to_fm_kernel(const float* in, bf16_t* out, int n_mels, int n_frames) {
+template <typename T> __global__ void feats_to_fm_kernel(const float* in, T* out, int n_mels, int n_frames) {
     const int b = blockIdx.y;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)n_mels * n_frames) return;
     const int t = e / n_mels, m = e % n_mels;
-    out[((long)b * (n_frames + 2) + 1 + t) * n_mels + m] = f2bf(in[((long)b * n_mels + m) * n_frames + t]);
+    out[((long)b * (n_frames + 2) + 1 + t) * n_mels + m] = (T)in[((long)b * n_mels + m) * n_frames + t];   // asr.py:280-301: cast to the model dtype
 }
 // conv weight [C][Ci][3] -> [C][3][Ci]
 __global__ void conv_permute_kernel(const bf16_t* in, bf16_t* out, int C, int Ci) {
@@ -281,7 +293,7 @@ static int build_constants(sonic_engine* e) {
 // ------------------------------------------------------------------------------------------ create / destroy
 extern "C" int sonic_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
-static int check_dims(const sonic_dims& d, int max_batch, int max_ctx) {
+static int check_dims(const sonic_dims& d, int max_batch, int max_ctx, int mode) {
     if (d.n_mels <= 0 || d.n_mels % 64 != 0) return fail(nullptr, SONIC_ERR_INVALID, "n_mels must be a positive multiple of 64");
     if (d.enc_d % 64 || d.enc_ff % 64 || d.dec_d % 256 || d.dec_ff % 256) return fail(nullptr, SONIC_ERR_INVALID, "hidden sizes must be multiples of 64 (encoder) / 256 (decoder)");
     if (d.enc_d / d.enc_heads != 64 || d.enc_d % d.enc_heads) return fail(nullptr, SONIC_ERR_INVALID, "encoder head_dim must be 64");
@@ -299,7 +311,7 @@ static int check_dims(const sonic_dims& d, int max_batch, int max_ctx) {
         const int shapes[5][2] = {{QD + 2 * KD, d.dec_d}, {d.dec_d, QD}, {2 * d.dec_ff, d.dec_d}, {d.dec_d, d.dec_ff}, {d.vocab, d.dec_d}};
         const char* names[5] = {"qkv_proj", "o_proj", "gate/up_proj", "down_proj", "lm_head"};
         for (int i = 0; i < 5; ++i) {
-            const int ks = skinny_pick_ksplit(shapes[i][0], shapes[i][1]);
+            const int ks = (mode == SONIC_MODE_INT8 && i < 4) ? skinny_pick_ksplit_i8(shapes[i][0], shapes[i][1]) : skinny_pick_ksplit(shapes[i][0], shapes[i][1]);
             if (ks < 1 || ks > 8) return fail(nullptr, SONIC_ERR_INVALID, "decoder %s shape [%d x %d] has no decode-step tiling (K slabs = %d, need 1..8)", names[i], shapes[i][0], shapes[i][1], ks);
         }
     }
@@ -309,15 +321,17 @@ static int check_dims(const sonic_dims& d, int max_batch, int max_ctx) {
 extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out) {
     if (!dims || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (mode == SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_UNSUPPORTED, "INT8 mode is not built yet (SURVEY.md §8a row a14, parity unpinned)");
-    if (mode != SONIC_MODE_NATIVE) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
+    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
     g_opts = LaunchOpts{};
-    TRY(check_dims(*dims, max_batch, max_ctx));
+    TRY(check_dims(*dims, max_batch, max_ctx, mode));
+    if (mode == SONIC_MODE_INT8 && (dims->dec_ff > 8192 || dims->enc_d % 128 || dims->enc_ff % 128 || (dims->dec_heads * dims->dec_head_dim) % 128))
+        return fail(nullptr, SONIC_ERR_INVALID, "int8 mode: dec_ff must be <= 8192 and every quantised K a multiple of 128");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SONIC_ERR_HIP, "no HIP device available");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
     sonic_engine* e = new sonic_engine();
     e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
+    e->i8 = mode == SONIC_MODE_INT8; e->dt = e->i8 ? DT_F16 : DT_BF16;
     auto bail = [&](int code) { g_create_err = e->err; sonic_destroy(e); return code; };
     if (hipSetDevice(device_id) != hipSuccess) { e->err = "hipSetDevice failed"; return bail(SONIC_ERR_HIP); }
     if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(SONIC_ERR_HIP); }
@@ -353,6 +367,23 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->kv_len, 64)); A(dalloc(e, &e->tok_pos, 64)); A(dalloc(e, &e->n_new, 64)); A(dalloc(e, &e->finished, 64));
     A(dalloc(e, &e->max_new_d, 64)); A(dalloc(e, &e->n_active, 4)); A(dalloc(e, &e->out_ids, (size_t)64 * e->out_cap));
     A(dalloc(e, &e->step_ctr, 64)); A(dalloc(e, &e->seq_iota, 64));
+    if (e->i8) {
+        // widest Linear8bitLt input: encoder MLP (enc_ff), projector (enc_d * merge), decoder MLP (dec_ff)
+        int kmax = d.enc_ff; if (C * d.merge > kmax) kmax = C * d.merge; if (d.dec_ff > kmax) kmax = d.dec_ff; if (2 * d.dec_d > kmax) kmax = 2 * d.dec_d;
+        if (e->QD > kmax) kmax = e->QD;
+        e->q_kmax = kmax;
+        size_t rows = Mp > tc ? Mp : tc;
+        size_t qa_bytes = Mp * (size_t)(d.enc_ff > C * d.merge ? d.enc_ff : C * d.merge);
+        if (tc * (size_t)d.dec_ff > qa_bytes) qa_bytes = tc * (size_t)d.dec_ff;
+        if (((size_t)Bm * e->Ta + 128) * 2 * d.dec_d > qa_bytes) qa_bytes = ((size_t)Bm * e->Ta + 128) * 2 * d.dec_d;
+        A(dalloc(e, &e->qa, qa_bytes + 4096)); A(dalloc(e, &e->q_sca, rows)); A(dalloc(e, &e->q_flags, (size_t)64 * kmax + 64));
+        A(dalloc(e, &e->q_oc_cnt, 64)); A(dalloc(e, &e->q_oc_list, (size_t)64 * kmax)); A(dalloc(e, &e->win_req, 64));
+        A(dalloc(e, &e->qkv_rm, Mp * 3 * C));
+        A(dalloc_act(e, &e->hn_q, (size_t)64 * d.dec_d)); A(dalloc_act(e, &e->att_q, (size_t)64 * e->QD)); A(dalloc_act(e, &e->act_q, (size_t)64 * d.dec_ff));
+        A(dalloc(e, &e->sca_hn, 64)); A(dalloc(e, &e->sca_att, 64)); A(dalloc(e, &e->sca_act, 64));
+        A(dalloc(e, &e->oc_hn, 64)); A(dalloc(e, &e->oc_att, 64)); A(dalloc(e, &e->oc_act, 64));
+        A(dalloc(e, &e->ol_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ol_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ol_act, (size_t)64 * d.dec_ff));
+    }
     A(dalloc(e, &e->src, tc)); A(dalloc(e, &e->tok_seq, tc)); A(dalloc(e, &e->tok_pos_pf, tc));
     A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
     {
@@ -426,7 +457,8 @@ extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* 
         float* tmp = nullptr;
         HIPC(e, hipMalloc((void**)&tmp, t->n * 4));
         hipError_t r = h2d(e, tmp, data, t->n * 4);
-        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st); r = hipStreamSynchronize(e->st); }
+        // int8 mode loads the checkpoint with torch_dtype=float16 (asr.py:156): an fp32 source goes straight to fp16
+        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st, e->dt); r = hipStreamSynchronize(e->st); if (e->i8) e->raw_f16[name] = true; }
         (void)hipFree(tmp);
         HIPC(e, r);
     } else return fail(e, SONIC_ERR_INVALID, "dtype must be f32 or bf16");
@@ -460,8 +492,23 @@ static int need(sonic_engine* e, const std::string& name, DevTensor** t) {
 static int to_f32(sonic_engine* e, const std::string& name, float** out) {
     DevTensor* t; TRY(need(e, name, &t));
     TRY(dalloc(e, out, t->n, false));
-    launch_bf16_to_f32(t->p, *out, (long)t->n, e->st);
+    launch_bf16_to_f32(t->p, *out, (long)t->n, e->st, e->dt);
     e->weight_bytes += (int64_t)t->n * 4;
+    return SONIC_OK;
+}
+// int8 mode: row-wise int8 of a packed [N][K] fp16 matrix (Int8Params.cuda()); the 16-bit matrix is released afterwards
+static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool tiled) {
+    TRY(dalloc(e, &q->cb, (size_t)N * K, false)); TRY(dalloc(e, &q->scb, (size_t)N, false));
+    launch_quant_weights(*w16, q->cb, q->scb, N, K, e->st);
+    e->weight_bytes += (int64_t)N * K + (int64_t)N * 4 - (int64_t)N * K * 2;
+    if (tiled) {
+        TRY(dalloc_uc(e, &q->cbt, (size_t)N * K, false));
+        launch_tile_weights_i8(q->cb, q->cbt, N, K, e->st);
+        e->weight_bytes += (int64_t)N * K;
+    }
+    HIPC(e, hipStreamSynchronize(e->st));
+    for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w16) { e->allocs.erase(it); break; }
+    (void)hipFree(*w16); *w16 = nullptr;
     return SONIC_OK;
 }
 // concatenate row blocks of [rows_i][K] tensors
@@ -488,6 +535,8 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
     const sonic_dims& d = e->d;
     const std::string at = "model.audio_tower.", pj = "model.multi_modal_projector.", lm = "model.language_model.";
     e->weight_bytes = 0;
+    if (e->i8)   // a bf16 checkpoint (or the synthetic generator's bf16 values) loaded as fp16, in place (asr.py:156 torch_dtype=float16)
+        for (auto& kv : e->raw) if (kv.second.p && !e->raw_f16.count(kv.first)) launch_bf16_to_f16(kv.second.p, kv.second.p, (long)kv.second.n, e->st);
     {   // conv stem in im2col order [C][3][Ci]
         DevTensor *w1, *w2; TRY(need(e, at + "conv1.weight", &w1)); TRY(need(e, at + "conv2.weight", &w2));
         TRY(dalloc(e, &e->conv1w, w1->n, false)); TRY(dalloc(e, &e->conv2w, w2->n, false));
@@ -504,16 +553,23 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         TRY(concat_rows(e, {p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, &L.wqkv));
         TRY(dalloc(e, &L.bqkv, (size_t)3 * d.enc_d, true));   // k_proj has no bias (modeling_glmasr.py:184)
         DevTensor *bq, *bv; TRY(need(e, p + "self_attn.q_proj.bias", &bq)); TRY(need(e, p + "self_attn.v_proj.bias", &bv));
-        launch_bf16_to_f32(bq->p, L.bqkv, d.enc_d, e->st);
-        launch_bf16_to_f32(bv->p, L.bqkv + 2 * d.enc_d, d.enc_d, e->st);
+        launch_bf16_to_f32(bq->p, L.bqkv, d.enc_d, e->st, e->dt);
+        launch_bf16_to_f32(bv->p, L.bqkv + 2 * d.enc_d, d.enc_d, e->st, e->dt);
         TRY(keep_raw(e, p + "self_attn.o_proj.weight", &L.wo)); TRY(to_f32(e, p + "self_attn.o_proj.bias", &L.bo));
         TRY(to_f32(e, p + "post_attention_layernorm.weight", &L.ln2w)); TRY(to_f32(e, p + "post_attention_layernorm.bias", &L.ln2b));
         TRY(keep_raw(e, p + "mlp.fc1.weight", &L.w1)); TRY(to_f32(e, p + "mlp.fc1.bias", &L.b1));
         TRY(keep_raw(e, p + "mlp.fc2.weight", &L.w2)); TRY(to_f32(e, p + "mlp.fc2.bias", &L.b2));
+        if (e->i8) {
+            TRY(quantize(e, &L.wqkv, 3 * d.enc_d, d.enc_d, &L.qqkv, false)); TRY(quantize(e, &L.wo, d.enc_d, d.enc_d, &L.qo, false));
+            TRY(quantize(e, &L.w1, d.enc_ff, d.enc_d, &L.q1, false)); TRY(quantize(e, &L.w2, d.enc_d, d.enc_ff, &L.q2, false));
+        }
     }
     TRY(to_f32(e, at + "norm.weight", &e->enc_nw)); TRY(to_f32(e, at + "norm.bias", &e->enc_nb));
     TRY(keep_raw(e, pj + "linear_1.weight", &e->pj1w)); TRY(to_f32(e, pj + "linear_1.bias", &e->pj1b));
     TRY(keep_raw(e, pj + "linear_2.weight", &e->pj2w)); TRY(to_f32(e, pj + "linear_2.bias", &e->pj2b));
+    if (e->i8) {   // both projector linears are swapped: the reference's skip pattern 'audio_proj' does not match 'multi_modal_projector'
+        TRY(quantize(e, &e->pj1w, 2 * d.dec_d, d.enc_d * d.merge, &e->qpj1, false)); TRY(quantize(e, &e->pj2w, d.dec_d, 2 * d.dec_d, &e->qpj2, false));
+    }
     TRY(keep_raw(e, lm + "embed_tokens.weight", &e->embed));
     e->dec.resize(d.dec_layers);
     for (int i = 0; i < d.dec_layers; ++i) {
@@ -536,9 +592,14 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
             e->weight_bytes += (int64_t)N * K * 2;
             return SONIC_OK;
         };
+        L.wgu_t8 = nullptr; L.wqkv_t = L.wo_t = L.wgu_t = L.wdown_t = nullptr;
+        if (e->i8) {
+            TRY(quantize(e, &L.wqkv, e->qkvN, d.dec_d, &L.qqkv, true)); TRY(quantize(e, &L.wo, d.dec_d, e->QD, &L.qo, true));
+            TRY(quantize(e, &L.wgu, 2 * d.dec_ff, d.dec_d, &L.qgu, true)); TRY(quantize(e, &L.wdown, d.dec_d, d.dec_ff, &L.qdown, true));
+            continue;
+        }
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
         TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
-        L.wgu_t8 = nullptr;
         if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave)
             TRY(dalloc_uc(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
             launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
@@ -560,7 +621,24 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
 static void gemm(sonic_engine* e, int epi, const bf16_t* A, long lda, const bf16_t* W, const float* bias, bf16_t* C, long ldc,
                  int M, int N, int K, const bf16_t* R = nullptr, long ldr = 0) {
     GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1;
+    a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = e->dt;
+    launch_gemm(a, epi, e->st);
+}
+// Rows -> reference-call groups for LLM.int8's outlier columns: group of row r = gmap ? gmap[r / gdiv] : r / gdiv, G groups
+struct QGroup { const int* gmap; int gdiv; int G; };
+// One nn.Linear of the model on X [M][K] (row stride ldx).  Native mode: the 16-bit GEMM.  int8 mode and a swapped module (q.cb):
+// Linear8bitLt = activation quantisation (3 streaming passes) + int8 MFMA GEMM whose epilogue dequantises and adds the outlier columns.
+static void qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
+                    int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp) {
+    if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return; }
+    QuantActArgs qa{};
+    qa.X = X; qa.ld = ldx; qa.M = M; qa.K = K; qa.gmap = grp.gmap; qa.gdiv = grp.gdiv; qa.G = grp.G; qa.flags = e->q_flags;
+    qa.q = e->qa; qa.sca = e->q_sca; qa.oc_cnt = e->q_oc_cnt; qa.oc_list = e->q_oc_list; qa.oc_ld = e->q_kmax;
+    launch_quant_act(qa, e->st);
+    GemmArgs a{};
+    a.A = (const bf16_t*)e->qa; a.lda = K; a.W = (const bf16_t*)q.cb; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = DT_F16;
+    a.q.sca = e->q_sca; a.q.scb = q.scb; a.q.x16 = X; a.q.ldx16 = ldx; a.q.oc_cnt = e->q_oc_cnt; a.q.oc_list = e->q_oc_list; a.q.oc_ld = e->q_kmax;
+    a.q.row_group = grp.gmap; a.q.group_div = grp.gdiv;
     launch_gemm(a, epi, e->st);
 }
 
@@ -571,22 +649,24 @@ static int run_mel(sonic_engine* e, int W, bool want_f32) {
     }
     int mx = 0; for (int i = 0; i < W; ++i) mx = e->n_samples_h[i] > mx ? e->n_samples_h[i] : mx;
     launch_logmel(e->pcm, (long)d.n_frames * 160, e->n_samples_d, mx, e->lc, e->logspec, e->segmax, W, d.n_frames, d.n_mels,
-                  e->feats_fm, want_f32 ? e->feats_f32 : nullptr, e->st);
+                  e->feats_fm, want_f32 ? e->feats_f32 : nullptr, e->st, e->dt);
     return SONIC_OK;
 }
 
-// feats_fm (bf16, frame-major, padded) -> pe [W*Ta][dec_d]
-static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc_out_host) {
+// feats_fm (16-bit, frame-major, padded) -> pe [W*Ta][dec_d].  win_group: request of each window (int8 mode: LLM.int8 finds its outlier
+// columns over all rows of one reference call, i.e. over all windows of a request - HF runs them as one encoder batch)
+static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc_out_host, int n_groups) {
     const sonic_dims& d = e->d;
-    const int C = d.enc_d, T = e->T, M = W * T, H = d.enc_heads;
-    {   // conv stem as two batched im2col-free GEMMs (modeling_glmasr.py:313-316)
+    const int C = d.enc_d, T = e->T, M = W * T, H = d.enc_heads, dt = e->dt;
+    const QGroup grp{e->win_req, T, n_groups}, grp_p{e->win_req, e->Ta, n_groups};
+    {   // conv stem as two batched im2col-free GEMMs (modeling_glmasr.py:313-316); nn.Conv1d is not swapped in int8 mode
         GemmArgs a{};
-        a.A = e->feats_fm; a.lda = d.n_mels; a.W = e->conv1w; a.bias = e->conv1b; a.C = e->h1 + C; a.ldc = C;
+        a.A = e->feats_fm; a.lda = d.n_mels; a.W = e->conv1w; a.bias = e->conv1b; a.C = e->h1 + C; a.ldc = C; a.dt = dt;
         a.M = d.n_frames; a.N = C; a.K = 3 * d.n_mels; a.batch = W;
         a.strideA = (long)(d.n_frames + 2) * d.n_mels; a.strideC = (long)(d.n_frames + 2) * C;
         launch_gemm(a, EPI_BIAS_GELU, e->st);
         GemmArgs b{};
-        b.A = e->h1; b.lda = 2L * C; b.W = e->conv2w; b.bias = e->conv2b; b.C = e->x; b.ldc = C;
+        b.A = e->h1; b.lda = 2L * C; b.W = e->conv2w; b.bias = e->conv2b; b.C = e->x; b.ldc = C; b.dt = dt;
         b.M = T; b.N = C; b.K = 3 * C; b.batch = W; b.strideA = (long)(d.n_frames + 2) * C; b.strideC = (long)T * C;
         launch_gemm(b, EPI_BIAS_GELU, e->st);
     }
@@ -595,55 +675,63 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
     e->gemm_ev_used = 0;
     for (int l = 0; l < d.enc_layers; ++l) {
         const EncLayerW& L = e->enc[l];
-        launch_layernorm(e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, e->st);
+        launch_layernorm(e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, e->st, dt);
         const bool tev = e->opt_gemm_timing && (size_t)(8 * l + 7) < e->gemm_ev.size();
         auto mark = [&](int i) { if (tev) (void)hipEventRecord(e->gemm_ev[8 * l + i], e->st); };
-        {
+        FlashArgs f{};
+        f.dt = dt; f.T = T; f.Hq = H; f.Hkv = H; f.scale = 1.0f / sqrtf((float)e->hd_e); f.Vt = e->vt; f.vt_ld = e->Tp; f.O = e->att; f.o_ld = C;
+        f.k_head_stride = e->hd_e; f.vt_seq_stride = (long)C * e->Tp; f.vt_head_stride = (long)e->hd_e * e->Tp;
+        if (e->i8) {
+            // Linear8bitLt q / k / v share their input, hence one quantisation and one fused int8 GEMM; Q | K | V land row-major
+            // ([M][3C]) and V is transposed by its own pass (the fused V^T epilogue plus the dequantisation spills registers)
+            mark(0);
+            qlinear(e, EPI_BIAS, e->ln, C, nullptr, L.qqkv, L.bqkv, e->qkv_rm, 3L * C, M, 3 * C, C, nullptr, 0, grp);
+            mark(1);
+            launch_rope_enc(e->qkv_rm, 3L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
+            launch_transpose_v(e->qkv_rm, 3L * C, 2 * C, e->vt, W, T, C, e->Tp, (long)C * e->Tp, e->st);
+            f.Q = e->qkv_rm; f.q_ld = 3L * C; f.K = e->qkv_rm + C; f.k_ld = 3L * C;
+            f.q_seq_stride = (long)T * 3 * C; f.k_seq_stride = (long)T * 3 * C;
+        } else {
             GemmArgs a{};
-            a.A = e->ln; a.lda = C; a.W = L.wqkv; a.bias = L.bqkv; a.C = e->qk; a.ldc = 2L * C; a.M = M; a.N = 3 * C; a.K = C; a.batch = 1;
+            a.A = e->ln; a.lda = C; a.W = L.wqkv; a.bias = L.bqkv; a.C = e->qk; a.ldc = 2L * C; a.M = M; a.N = 3 * C; a.K = C; a.batch = 1; a.dt = dt;
             a.Vt = e->vt; a.n_split = 2 * C; a.seg_T = T; a.vt_ld = e->Tp; a.vt_seg_stride = (long)C * e->Tp;
             mark(0);
             launch_gemm(a, EPI_QKV_VT, e->st);
             mark(1);
+            launch_rope_enc(e->qk, 2L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
+            f.Q = e->qk; f.q_ld = 2L * C; f.K = e->qk + C; f.k_ld = 2L * C;
+            f.q_seq_stride = (long)T * 2 * C; f.k_seq_stride = (long)T * 2 * C;
         }
-        launch_rope_enc(e->qk, 2L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st);
-        {
-            FlashArgs f{};
-            f.Q = e->qk; f.q_ld = 2L * C; f.K = e->qk + C; f.k_ld = 2L * C; f.Vt = e->vt; f.vt_ld = e->Tp; f.O = e->att; f.o_ld = C;
-            f.q_seq_stride = (long)T * 2 * C; f.k_seq_stride = (long)T * 2 * C; f.k_head_stride = e->hd_e;
-            f.vt_seq_stride = (long)C * e->Tp; f.vt_head_stride = (long)e->hd_e * e->Tp;
-            f.T = T; f.Hq = H; f.Hkv = H; f.scale = 1.0f / sqrtf((float)e->hd_e);
-            launch_flash(f, 64, false, W, T, e->st);
-        }
+        launch_flash(f, 64, false, W, T, e->st);
         mark(2);
-        gemm(e, EPI_BIAS_RESID, e->att, C, L.wo, L.bo, e->x, C, M, C, C, e->x, C);
+        qlinear(e, EPI_BIAS_RESID, e->att, C, L.wo, L.qo, L.bo, e->x, C, M, C, C, e->x, C, grp);
         mark(3);
-        launch_layernorm(e->x, L.ln2w, L.ln2b, e->ln, M, C, d.enc_ln_eps, e->st);
+        launch_layernorm(e->x, L.ln2w, L.ln2b, e->ln, M, C, d.enc_ln_eps, e->st, dt);
         mark(4);
-        gemm(e, EPI_BIAS_GELU, e->ln, C, L.w1, L.b1, e->ff, d.enc_ff, M, d.enc_ff, C);
+        qlinear(e, EPI_BIAS_GELU, e->ln, C, L.w1, L.q1, L.b1, e->ff, d.enc_ff, M, d.enc_ff, C, nullptr, 0, grp);
         mark(5);
         if (tev) e->gemm_ev_used = l + 1;
         mark(6);
-        gemm(e, EPI_BIAS_RESID, e->ff, d.enc_ff, L.w2, L.b2, e->x, C, M, C, d.enc_ff, e->x, C);
+        qlinear(e, EPI_BIAS_RESID, e->ff, d.enc_ff, L.w2, L.q2, L.b2, e->x, C, M, C, d.enc_ff, e->x, C, grp);
         mark(7);
         if (enc_layers_out) {
-            launch_bf16_to_f32(e->x, tap, (long)M * C, e->st);
+            launch_bf16_to_f32(e->x, tap, (long)M * C, e->st, dt);
             HIPC(e, hipStreamSynchronize(e->st));
             for (int b = 0; b < W; ++b)
                 HIPC(e, hipMemcpy(enc_layers_out + ((size_t)b * d.enc_layers + l) * T * C, tap + (size_t)b * T * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
         }
     }
-    launch_layernorm(e->x, e->enc_nw, e->enc_nb, e->ln, M, C, d.enc_ln_eps, e->st);
+    launch_layernorm(e->x, e->enc_nw, e->enc_nb, e->ln, M, C, d.enc_ln_eps, e->st, dt);
     if (enc_out_host) {
-        launch_bf16_to_f32(e->ln, tap, (long)M * C, e->st);
+        launch_bf16_to_f32(e->ln, tap, (long)M * C, e->st, dt);
         HIPC(e, hipStreamSynchronize(e->st));
         HIPC(e, hipMemcpy(enc_out_host, tap, (size_t)M * C * 4, hipMemcpyDeviceToHost));
     }
     if (tap) (void)hipFree(tap);
     // 4-frame merge is a view: [M][C] == [W*Ta][4C] (modeling_glmasr.py:392-397)
     const int Mp = W * e->Ta, PI = C * d.merge, PM = 2 * d.dec_d;
-    gemm(e, EPI_BIAS_GELU, e->ln, PI, e->pj1w, e->pj1b, e->ph, PM, Mp, PM, PI);
-    gemm(e, EPI_BIAS, e->ph, PM, e->pj2w, e->pj2b, e->pe, d.dec_d, Mp, d.dec_d, PM);
+    qlinear(e, EPI_BIAS_GELU, e->ln, PI, e->pj1w, e->qpj1, e->pj1b, e->ph, PM, Mp, PM, PI, nullptr, 0, grp_p);
+    qlinear(e, EPI_BIAS, e->ph, PM, e->pj2w, e->qpj2, e->pj2b, e->pe, d.dec_d, Mp, d.dec_d, PM, nullptr, 0, grp_p);
     return SONIC_OK;
 }
 
@@ -660,9 +748,16 @@ static int frames_of(int n_samples) { return n_samples > 0 ? (n_samples + 159) /
 
 static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, float* P, int M, int N, int K, int* ks_out) {
     SkinnyArgs a{};
-    a.X = X; a.ldx = ldx; a.W = W; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit(N, K);
+    a.X = X; a.ldx = ldx; a.W = W; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit(N, K); a.dt = e->dt;
     if (ks_out) *ks_out = a.ksplit;
     launch_skinny(a, e->st);
+}
+// int8 decode step: quantised rows Xq [M][K] x fragment-tiled int8 weights -> int32 slabs (dequantised by the consumer)
+static int skinny_i8(sonic_engine* e, const int8_t* Xq, const int8_t* Wt, float* P, int M, int N, int K) {
+    SkinnyArgs a{};
+    a.X = (const bf16_t*)Xq; a.ldx = K; a.W = (const bf16_t*)Wt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit_i8(N, K); a.i8 = 1;
+    launch_skinny(a, e->st);
+    return a.ksplit;
 }
 
 static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
@@ -675,21 +770,25 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     g.logits_dump = dump ? e->dump : nullptr; g.dump_stride_step = (long)R * d.vocab; g.step_counter = dump ? e->step_ctr : nullptr;
     g.norm_w = e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
     g.force_ids = e->force_d; g.force_ld = e->force_ld;
+    g.dt = e->dt;
+    if (e->i8) g.qo = QuantOut{e->hn_q, d.dec_d, e->sca_hn, e->oc_hn, e->ol_hn, d.dec_d};     // layer 0's q/k/v input, quantised
     return g;
 }
 
-// one decode step for R rows: sx (bf16 [R][d]) -> next token (generation/utils.py:2876-2943)
+// one decode step for R rows: sx ([R][d]) -> next token (generation/utils.py:2876-2943)
+static void decode_step_i8(sonic_engine* e, int R, bool dump);
 static void decode_step(sonic_engine* e, int R, bool dump) {
+    if (e->i8) { decode_step_i8(e, R, dump); return; }
     const sonic_dims& d = e->d;
-    const int D = d.dec_d, mpad = ((R + 15) / 16) * 16;
+    const int D = d.dec_d, mpad = ((R + 15) / 16) * 16, dt = e->dt;
     int ks;
-    if (D > 8192) launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st);   // else: done by the greedy kernel of the previous step
+    if (D > 8192) launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st, dt);   // else: done by the greedy kernel of the previous step
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
         skinny(e, e->shn, D, L.wqkv_t, e->slab, R, e->qkvN, D, &ks);
         DecodeAttnArgs da{};
-        da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs;     // RoPE + KV append fused into the attention kernel
+        da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = dt;     // RoPE + KV append fused into the attention kernel
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_decode_attn(da, R, e->st);
@@ -704,20 +803,59 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 16, L.ln2, d.dec_rms_eps, e->st);
         } else {
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
-        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st);
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st, dt);
         if (fuse_gu) {          // gate/up + SwiGLU in one kernel, no slabs
             SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
             launch_skinny_gu(ga, e->sact, e->st);
         } else {
             skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
-            launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st);
+            launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st, dt);
         }
         }
         skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks);
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
-        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st);
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, dt);
     }
     skinny(e, e->shn, D, e->embed_t, e->lslab, R, d.vocab, D, nullptr);   // tied lm_head (modeling_glmasr.py:517)
+    launch_greedy(greedy_args(e, R, dump), e->st);
+}
+
+// int8 mode (asr.py:169-210): every decoder projection is a Linear8bitLt.  In a decode step each row is one reference call, so its
+// outlier "columns" are its own elements >= 6.0.  Producers that own whole rows emit them quantised (greedy / add+RMSNorm / SwiGLU
+// kernels; the attention output by its own one-block-per-row pass), the skinny int8 GEMM streams the fragment-tiled int8 weights
+// (half the bytes of the bf16 step) into exact int32 slabs, and the consumer dequantises them (int8_util.h deq4).
+static void decode_step_i8(sonic_engine* e, int R, bool dump) {
+    const sonic_dims& d = e->d;
+    const int D = d.dec_d, FF = d.dec_ff, mpad = ((R + 15) / 16) * 16;
+    const QuantOut q_hn{e->hn_q, D, e->sca_hn, e->oc_hn, e->ol_hn, D};
+    const QuantOut q_att{e->att_q, e->QD, e->sca_att, e->oc_att, e->ol_att, e->QD};
+    const QuantOut q_act{e->act_q, FF, e->sca_act, e->oc_act, e->ol_act, FF};
+    auto deq = [&](const QuantOut& q, const QW& w, int K, const bf16_t* x16) {
+        DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
+        dq.row_group = nullptr; dq.group_div = 1;
+        return dq;
+    };
+    for (int l = 0; l < d.dec_layers; ++l) {
+        const DecLayerW& L = e->dec[l];
+        const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
+        int ks = skinny_i8(e, e->hn_q, L.qqkv.cbt, e->slab, R, e->qkvN, D);
+        DecodeAttnArgs da{};
+        da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = DT_F16; da.dq = deq(q_hn, L.qqkv, D, e->shn);
+        da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
+        da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
+        launch_decode_attn(da, R, e->st);
+        launch_quant_rows(e->satt, e->QD, R, e->QD, q_att, e->st);
+        ks = skinny_i8(e, e->att_q, L.qo.cbt, e->slab, R, D, e->QD);
+        DeqInfo dq = deq(q_att, L.qo, e->QD, e->satt);
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st, DT_F16, &dq, &q_hn);
+        ks = skinny_i8(e, e->hn_q, L.qgu.cbt, e->slab, R, 2 * FF, D);
+        launch_swiglu_quant(e->slab, ks, mpad, FF, e->sact, R, deq(q_hn, L.qgu, D, e->shn), q_act, e->st);
+        ks = skinny_i8(e, e->act_q, L.qdown.cbt, e->slab, R, D, FF);
+        dq = deq(q_act, L.qdown, FF, e->sact);
+        const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, DT_F16, &dq, &q_hn);
+    }
+    skinny(e, e->shn, D, e->embed_t, e->lslab, R, d.vocab, D, nullptr);   // lm_head is not swapped (asr.py:177): fp16 skinny GEMM
     launch_greedy(greedy_args(e, R, dump), e->st);
 }
 
@@ -774,7 +912,8 @@ static int plan_requests(sonic_engine* e, const int32_t* req_win, int R, const i
 
 static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     const sonic_dims& d = e->d;
-    const int D = d.dec_d, M = hp.n_tok;
+    const int D = d.dec_d, M = hp.n_tok, dt = e->dt;
+    const QGroup grp{e->tok_seq, 1, R};        // one reference call = the prompt rows of one request
     HIPC(e, hipMemcpyAsync(e->src, hp.src.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(e->tok_seq, hp.tok_seq.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(e->tok_pos_pf, hp.tok_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
@@ -797,27 +936,27 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
-        launch_rmsnorm(e->dx, L.ln1, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st);
-        gemm(e, EPI_BIAS, e->dhn, D, L.wqkv, nullptr, e->dqkv, e->qkvN, M, e->qkvN, D);
-        RopeAppendArgs ra{};
+        launch_rmsnorm(e->dx, L.ln1, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st, dt);
+        qlinear(e, EPI_BIAS, e->dhn, D, L.wqkv, L.qqkv, nullptr, e->dqkv, e->qkvN, M, e->qkvN, D, nullptr, 0, grp);
+        RopeAppendArgs ra{}; ra.dt = dt;
         ra.qkv = e->dqkv; ra.ld = e->qkvN; ra.q_out = e->dq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = e->Vts; ra.vt_ld = e->max_ctx;
         ra.tok_seq = e->tok_seq; ra.tok_pos = e->tok_pos_pf; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = M;
         launch_rope_append(ra, false, e->st);
-        FlashArgs f{};
+        FlashArgs f{}; f.dt = dt;
         f.Q = e->dq; f.q_ld = e->QD; f.K = e->Kc + kvoff; f.k_ld = d.dec_head_dim; f.Vt = e->Vts; f.vt_ld = e->max_ctx; f.O = e->datt; f.o_ld = e->QD;
         f.k_seq_stride = (long)d.dec_kv_heads * e->max_ctx * d.dec_head_dim; f.k_head_stride = (long)e->max_ctx * d.dec_head_dim;
         f.vt_seq_stride = (long)d.dec_kv_heads * d.dec_head_dim * e->max_ctx; f.vt_head_stride = (long)d.dec_head_dim * e->max_ctx;
         f.q_off = e->q_off; f.q_len = e->q_len; f.kv_len = e->q_len; f.Hq = d.dec_heads; f.Hkv = d.dec_kv_heads;
         f.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_flash(f, 128, true, R, hp.max_p, e->st);
-        gemm(e, EPI_BIAS_RESID, e->datt, e->QD, L.wo, nullptr, e->dx, D, M, D, e->QD, e->dx, D);
-        launch_rmsnorm(e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st);
-        gemm(e, EPI_SWIGLU, e->dhn, D, L.wgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D);
-        gemm(e, EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, nullptr, e->dx, D, M, D, d.dec_ff, e->dx, D);
+        qlinear(e, EPI_BIAS_RESID, e->datt, e->QD, L.wo, L.qo, nullptr, e->dx, D, M, D, e->QD, e->dx, D, grp);
+        launch_rmsnorm(e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st, dt);
+        qlinear(e, EPI_SWIGLU, e->dhn, D, L.wgu, L.qgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D, nullptr, 0, grp);
+        qlinear(e, EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, L.qdown, nullptr, e->dx, D, M, D, d.dec_ff, e->dx, D, grp);
         if (e->taps_on) HIPC(e, hipMemcpyAsync(e->taps + (size_t)(l + 1) * e->tok_cap * D, e->dx, (size_t)M * D * 2, hipMemcpyDeviceToDevice, e->st));
     }
     // logits only for the last prompt position of each request (logits_to_keep=1, generation/utils.py:2612-2616)
-    launch_rmsnorm(e->dx, e->dec_nw, e->shn, R, D, d.dec_rms_eps, e->last_row, e->st);
+    launch_rmsnorm(e->dx, e->dec_nw, e->shn, R, D, d.dec_rms_eps, e->last_row, e->st, dt);
     skinny(e, e->shn, D, e->embed_t, e->lslab, R, d.vocab, D, nullptr);
     return SONIC_OK;
 }
@@ -846,7 +985,15 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     (void)hipEventRecord(e->ev[0], e->st);
     TRY(run_mel(e, e->W, false));
     (void)hipEventRecord(e->ev[1], e->st);
-    TRY(run_encoder(e, e->W, nullptr, nullptr));
+    {   // window -> request map (int8 mode: outlier columns are found per request)
+        std::vector<int> wr(64, 0);
+        for (int r = 0; r < R; ++r) {
+            const int w0 = req_win ? req_win[r] : r, w1 = req_win ? req_win[r + 1] : r + 1;
+            for (int w = w0; w < w1 && w < 64; ++w) wr[w] = r;
+        }
+        if (e->i8) HIPC(e, h2d(e, e->win_req, wr.data(), 64 * 4));
+    }
+    TRY(run_encoder(e, e->W, nullptr, nullptr, R));
     (void)hipEventRecord(e->ev[2], e->st);
     TRY(run_prefill(e, R, hp));
     launch_greedy(greedy_args(e, R, want_logits), e->st);
@@ -1034,8 +1181,9 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
     hipError_t r = h2d(e, tmp, feats, n * 4);
     if (r != hipSuccess) { (void)hipFree(tmp); HIPC(e, r); }
     const long per = (long)d.n_mels * d.n_frames;
-    hipLaunchKernelGGL(feats_to_fm_kernel, dim3((per + 255) / 256, B), dim3(256), 0, e->st, tmp, e->feats_fm, d.n_mels, d.n_frames);
-    int s = run_encoder(e, B, enc_layers_out, enc_out);
+    DT_SWITCH(e->dt, T, hipLaunchKernelGGL(feats_to_fm_kernel<T>, dim3((per + 255) / 256, B), dim3(256), 0, e->st, tmp, (T*)e->feats_fm, d.n_mels, d.n_frames));
+    if (e->i8) HIPC(e, hipMemcpyAsync(e->win_req, e->seq_iota, (size_t)B * 4, hipMemcpyDeviceToDevice, e->st));   // every window its own request
+    int s = run_encoder(e, B, enc_layers_out, enc_out, B);
     hipError_t r2 = hipStreamSynchronize(e->st);
     (void)hipFree(tmp);
     TRY(s); HIPC(e, r2); HIPC(e, hipGetLastError());
@@ -1043,7 +1191,7 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
         float* t2 = nullptr;
         const size_t m = (size_t)B * e->Ta * d.dec_d;
         HIPC(e, hipMalloc((void**)&t2, m * 4));
-        launch_bf16_to_f32(e->pe, t2, (long)m, e->st);
+        launch_bf16_to_f32(e->pe, t2, (long)m, e->st, e->dt);
         hipError_t r3 = hipStreamSynchronize(e->st);
         if (r3 == hipSuccess) r3 = hipMemcpy(embeds_out, t2, m * 4, hipMemcpyDeviceToHost);
         (void)hipFree(t2);
@@ -1073,7 +1221,7 @@ static bf16_t* up_bf16(sonic_engine* e, TmpBuf& tb, const float* h, size_t n, si
     float* f = tb.get<float>(n); bf16_t* b = tb.get<bf16_t>(n + pad);
     if (!f || !b) return nullptr;
     if (h2d(e, f, h, n * 4) != hipSuccess) return nullptr;
-    launch_f32_to_bf16(f, b, (long)n, e->st);
+    launch_f32_to_bf16(f, b, (long)n, e->st, e->dt);     // the engine's element type: bf16, or fp16 on an int8-mode engine
     return b;
 }
 static float* up_f32(sonic_engine* e, TmpBuf& tb, const float* h, size_t n) {
@@ -1084,7 +1232,7 @@ static float* up_f32(sonic_engine* e, TmpBuf& tb, const float* h, size_t n) {
 static int down_bf16(sonic_engine* e, TmpBuf& tb, const bf16_t* d, float* h, size_t n) {
     float* f = tb.get<float>(n);
     if (!f) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
-    launch_bf16_to_f32(d, f, (long)n, e->st);
+    launch_bf16_to_f32(d, f, (long)n, e->st, e->dt);
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
     HIPC(e, hipMemcpy(h, f, n * 4, hipMemcpyDeviceToHost));
@@ -1118,7 +1266,7 @@ extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W
     float* P = tb.get<float>((size_t)ks * mpad * N);
     if (!dX || !dW || !dWt || !P) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     launch_tile_weights(dW, dWt, N, K, e->st);
-    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks;
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks; a.dt = e->dt;
     launch_skinny(a, e->st);
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
@@ -1133,7 +1281,7 @@ extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W
     return SONIC_OK;
 }
 
-__global__ void transpose_v_kernel(const bf16_t* v, bf16_t* vt, int B, int Tk, int Hkv, int hd, int ld_t) {
+__global__ void test_transpose_v_kernel(const bf16_t* v, bf16_t* vt, int B, int Tk, int Hkv, int hd, int ld_t) {
     // v [B][Tk][Hkv*hd] -> vt [B][Hkv][hd][ld_t]
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)B * Tk * Hkv * hd) return;
@@ -1155,11 +1303,11 @@ extern "C" int sonic_test_attention(sonic_engine* e, const float* q, const float
     bf16_t* dO = tb.get<bf16_t>((size_t)B * Tq * Hq * hd);
     if (!dq || !dk || !dv || !dvt || !dO) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     const long nv = (long)B * Tk * Hkv * hd;
-    hipLaunchKernelGGL(transpose_v_kernel, dim3((nv + 255) / 256), dim3(256), 0, e->st, dv, dvt, B, Tk, Hkv, hd, Tkp);
+    hipLaunchKernelGGL(test_transpose_v_kernel, dim3((nv + 255) / 256), dim3(256), 0, e->st, dv, dvt, B, Tk, Hkv, hd, Tkp);
     FlashArgs f{};
     f.Q = dq; f.q_ld = (long)Hq * hd; f.K = dk; f.k_ld = (long)Hkv * hd; f.Vt = dvt; f.vt_ld = Tkp; f.O = dO; f.o_ld = (long)Hq * hd;
     f.q_seq_stride = (long)Tq * Hq * hd; f.k_seq_stride = (long)Tk * Hkv * hd; f.k_head_stride = hd;
-    f.vt_seq_stride = (long)Hkv * hd * Tkp; f.vt_head_stride = (long)hd * Tkp; f.T = Tq; f.Hq = Hq; f.Hkv = Hkv; f.scale = 1.0f / sqrtf((float)hd);
+    f.vt_seq_stride = (long)Hkv * hd * Tkp; f.vt_head_stride = (long)hd * Tkp; f.T = Tq; f.Hq = Hq; f.Hkv = Hkv; f.scale = 1.0f / sqrtf((float)hd); f.dt = e->dt;
     int *ql = nullptr, *kl = nullptr;
     if (Tq != Tk) {   // per-sequence lengths (decode-style offset: query t sits at position Tk - Tq + t)
         ql = tb.get<int>(B); kl = tb.get<int>(B);
@@ -1187,7 +1335,7 @@ extern "C" int sonic_test_decode_attention(sonic_engine* e, const float* q, cons
     bf16_t* dO = tb.get<bf16_t>((size_t)B * Hq * hd); int* kl = tb.get<int>(B);
     if (!dq || !dk || !dv || !dO || !kl) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     std::vector<int> l(B, Tk); HIPC(e, h2d(e, kl, l.data(), B * 4));
-    DecodeAttnArgs a{}; a.Q = dq; a.P = nullptr; a.Kc = dk; a.Vc = dv; a.O = dO; a.kv_len = kl; a.Hq = Hq; a.Hkv = Hkv; a.ctx_max = ctx; a.scale = 1.0f / sqrtf(128.f);
+    DecodeAttnArgs a{}; a.Q = dq; a.P = nullptr; a.Kc = dk; a.Vc = dv; a.O = dO; a.kv_len = kl; a.Hq = Hq; a.Hkv = Hkv; a.ctx_max = ctx; a.scale = 1.0f / sqrtf(128.f); a.dt = e->dt;
     launch_decode_attn(a, B, e->st);
     return down_bf16(e, tb, dO, out, (size_t)B * Hq * hd);
 }
@@ -1200,8 +1348,8 @@ extern "C" int sonic_test_layernorm(sonic_engine* e, const float* x, const float
     bf16_t* dx = up_bf16(e, tb, x, (size_t)rows * d); float* dw = up_f32(e, tb, w, d); float* db = b ? up_f32(e, tb, b, d) : nullptr;
     bf16_t* dy = tb.get<bf16_t>((size_t)rows * d);
     if (!dx || !dw || !dy) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
-    if (rms) launch_rmsnorm(dx, dw, dy, rows, d, eps, nullptr, e->st);
-    else launch_layernorm(dx, dw, db, dy, rows, d, eps, e->st);
+    if (rms) launch_rmsnorm(dx, dw, dy, rows, d, eps, nullptr, e->st, e->dt);
+    else launch_layernorm(dx, dw, db, dy, rows, d, eps, e->st, e->dt);
     return down_bf16(e, tb, dy, y, (size_t)rows * d);
 }
 
@@ -1224,7 +1372,7 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     // random (not zero) operands: zero data reads high on this chip (cdna_hip_programming.md rule 25)
     launch_synth_fill(0x1234, (long)M * K, 1.0f, 0.f, dA, nullptr, e->st);
     launch_synth_fill(0x5678, (long)N * K, 0.05f, 0.f, dW, nullptr, e->st);
-    a.A = dA; a.lda = K; a.W = dW; a.C = dC; a.ldc = (epi == EPI_QKV_VT) ? 2 * N / 3 : Nout; a.bias = db; a.R = dC; a.ldr = Nout; a.M = M; a.N = N; a.K = K; a.batch = 1;
+    a.A = dA; a.lda = K; a.W = dW; a.C = dC; a.ldc = (epi == EPI_QKV_VT) ? 2 * N / 3 : Nout; a.bias = db; a.R = dC; a.ldr = Nout; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = e->dt;
     for (int i = 0; i < 2; ++i) launch_gemm(a, epi, e->st);
     hipEvent_t ea, eb; HIPC(e, hipEventCreate(&ea)); HIPC(e, hipEventCreate(&eb));
     (void)hipEventRecord(ea, e->st);
@@ -1252,7 +1400,7 @@ extern "C" int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int vari
     if (!dW || !dX || !P) return fail(e, SONIC_ERR_OOM, "HIP out of memory in skinny bench");
     launch_synth_fill(0x77, (long)copies * N * K, 0.05f, 0.f, dW, nullptr, e->st);
     launch_synth_fill(0x78, (long)64 * K, 1.0f, 0.f, dX, nullptr, e->st);
-    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks;
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks; a.dt = e->dt;
     for (int i = 0; i < copies; ++i) { a.W = dW + (size_t)(i % copies) * N * K; launch_skinny(a, e->st); }
     hipEvent_t ea, eb; HIPC(e, hipEventCreate(&ea)); HIPC(e, hipEventCreate(&eb));
     (void)hipEventRecord(ea, e->st);
@@ -1300,6 +1448,37 @@ extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, fl
     if (n < 0 || (size_t)n > cap) return fail(e, SONIC_ERR_INVALID, "read of %lld elements exceeds buffer %s", (long long)n, name);
     TmpBuf tb(e->st);
     return down_bf16(e, tb, src, out, (size_t)n);
+}
+
+// One Linear8bitLt (LLM.int8, threshold 6.0) through the engine's kernels: W [N][K] is quantised row-wise on the device, X [M][K] is
+// cut into groups of `group_rows` rows (one group = one reference call: its outlier columns are found over its rows), then the int8
+// MFMA GEMM with the dequantising epilogue `epi` (EPI_BIAS / _GELU / _RESID / _SWIGLU).  Inputs are fp32 holding fp16 values.
+extern "C" int sonic_test_linear_int8(sonic_engine* e, const float* X, const float* W, const float* bias, const float* resid, float* out,
+                                      int M, int N, int K, int group_rows, int epi) {
+    if (!e || !X || !W || !out) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->i8) return fail(e, SONIC_ERR_INVALID, "sonic_test_linear_int8 needs an engine created with mode int8");
+    if (K % 128 || N % 16 || M < 1 || group_rows < 1 || (M + group_rows - 1) / group_rows > 64)
+        return fail(e, SONIC_ERR_INVALID, "bad int8 linear test shape");
+    TmpBuf tb(e->st);
+    const int Nout = (epi == EPI_SWIGLU) ? N / 2 : N;
+    bf16_t* dX = up_bf16(e, tb, X, (size_t)M * K); bf16_t* dW = up_bf16(e, tb, W, (size_t)N * K);
+    float* db = bias ? up_f32(e, tb, bias, N) : nullptr;
+    bf16_t* dR = resid ? up_bf16(e, tb, resid, (size_t)M * Nout) : nullptr;
+    bf16_t* dC = tb.get<bf16_t>((size_t)M * Nout);
+    int8_t* cb = tb.get<int8_t>((size_t)N * K); float* scb = tb.get<float>(N);
+    int8_t* qa = tb.get<int8_t>((size_t)M * K + 4096); float* sca = tb.get<float>(M);
+    if (!dX || !dW || !dC || !cb || !scb || !qa || !sca) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    launch_quant_weights(dW, cb, scb, N, K, e->st);
+    QW q; q.cb = cb; q.scb = scb;
+    unsigned char* fl = tb.get<unsigned char>((size_t)64 * K + 64); int* occ = tb.get<int>(64); int* ocl = tb.get<int>((size_t)64 * K);
+    if (!fl || !occ || !ocl) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
+    // the engine's own scratch is sized for its model, not for this test: swap in buffers of the test's shape for the call
+    int8_t* s_qa = e->qa; float* s_sca = e->q_sca; unsigned char* s_fl = e->q_flags; int *s_occ = e->q_oc_cnt, *s_ocl = e->q_oc_list; const int s_k = e->q_kmax;
+    e->qa = qa; e->q_sca = sca; e->q_flags = fl; e->q_oc_cnt = occ; e->q_oc_list = ocl; e->q_kmax = K;
+    qlinear(e, epi, dX, K, nullptr, q, db, dC, Nout, M, N, K, dR, Nout, QGroup{nullptr, group_rows, (M + group_rows - 1) / group_rows});
+    e->qa = s_qa; e->q_sca = s_sca; e->q_flags = s_fl; e->q_oc_cnt = s_occ; e->q_oc_list = s_ocl; e->q_kmax = s_k;
+    return down_bf16(e, tb, dC, out, (size_t)M * Nout);
 }
 
 // greedy_kernel on caller-provided lm_head partial slabs [ksplit][mpad][V] (fp32): returns the token each row picks (first maximum of

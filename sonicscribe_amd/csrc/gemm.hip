@@ -13,6 +13,7 @@
 // rows, B-operand = activation rows) so each lane ends up with 4 consecutive output columns of one
 // row and the epilogue stores 8-byte bf16 quads.
 #include "common.h"
+#include "int8_util.h"
 
 #define BM 128
 #define BN 128
@@ -24,8 +25,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int EPI>
+template <typename KD, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
+    typedef typename KD::elem ET_; typedef typename KD::out OT; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
+    typedef typename ET<OT>::v4 O4;
+    constexpr int EB = sizeof(ET_), CE = 16 / EB, BKE = 128 / EB;   // bytes per element, elements per 16-B chunk / per 128-B tile row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -46,21 +50,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         tn = in / gm;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const bf16_t* A = a.A + (long)blockIdx.z * a.strideA;
-    bf16_t* C = a.C + (long)blockIdx.z * a.strideC;
-    const bf16_t* R = (EPI == EPI_BIAS_RESID) ? a.R + (long)blockIdx.z * a.strideR : nullptr;
+    const ET_* A = (const ET_*)a.A + (long)blockIdx.z * a.strideA;
+    OT* C = (OT*)a.C + (long)blockIdx.z * a.strideC;
+    const OT* R = (EPI == EPI_BIAS_RESID) ? (const OT*)a.R + (long)blockIdx.z * a.strideR : nullptr;
 
     // ---- per-lane DMA source pointers (4 row groups of 8 rows per wave, per operand)
     const int lr = lane >> 3, lp = lane & 7, lc = lp ^ lr;  // LDS row-in-group, physical chunk, logical chunk
-    const bf16_t* srcA[4];
-    const bf16_t* srcW[4];
+    const ET_* srcA[4];
+    const ET_* srcW[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int g = wid * 4 + i;
         int ra = m0 + g * 8 + lr; ra = ra < a.M ? ra : a.M - 1;
         int rw = n0 + g * 8 + lr; rw = rw < a.N ? rw : a.N - 1;
-        srcA[i] = A + (long)ra * a.lda + lc * 8;
-        srcW[i] = a.W + (long)rw * a.K + lc * 8;
+        srcA[i] = A + (long)ra * a.lda + lc * CE;
+        srcW[i] = (const ET_*)a.W + (long)rw * a.K + lc * CE;
     }
     auto stage_load = [&](int stage, int k0) {
         char* sA = smem + stage * STAGE_BYTES;
@@ -73,45 +77,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         }
     };
 
-    f32x4 acc[4][4];  // [ni][mi]
+    Acc acc[4][4];  // [ni][mi]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
 
     const bool vtile = (EPI == EPI_QKV_VT) && (n0 >= a.n_split);
     const int fr = lane & 15, fg = lane >> 4;
-    const int nk = a.K / BK;
+    const int nk = a.K / BKE;
     stage_load(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage_load(cur ^ 1, (kt + 1) * BK);
+        if (kt + 1 < nk) stage_load(cur ^ 1, (kt + 1) * BKE);
         const char* sA = smem + cur * STAGE_BYTES;
         const char* sB = sA + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 xf[4], wf[4];
+            Frag xf[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rx = wr * 64 + i * 16 + fr, rw = wc * 64 + i * 16 + fr;
                 const int c = kk * 4 + fg;
-                xf[i] = *(const bf16x8*)(sA + rx * 128 + ((c ^ (rx & 7)) << 4));
-                wf[i] = *(const bf16x8*)(sB + rw * 128 + ((c ^ (rw & 7)) << 4));
+                xf[i] = *(const Frag*)(sA + rx * 128 + ((c ^ (rx & 7)) << 4));
+                wf[i] = *(const Frag*)(sB + rw * 128 + ((c ^ (rw & 7)) << 4));
             }
             if (vtile) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mi], wf[ni], acc[ni][mi], 0, 0, 0);
+                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = KD::mfma(xf[mi], wf[ni], acc[ni][mi]);
             } else {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = KD::mfma(wf[ni], xf[mi], acc[ni][mi]);
             }
         }
     }
@@ -122,16 +126,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wc * 64 + ni * 16 + fr;
-            const float bv = a.bias ? a.bias[n] : 0.f;
+            const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = m0 + wr * 64 + mi * 16 + fg * 4;
                 if (m < a.M && n < a.N) {
                     const int seg = m / a.seg_T, t = m - seg * a.seg_T;
-                    bf16x4 o;
+                    O4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[ni][mi][j] + bv);
-                    *(bf16x4*)(a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv);
+                    *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
                 }
             }
         }
@@ -141,17 +145,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int oc = ((n0 + wc * 64) >> 1) + q * 16 + fg * 4;
+            const int ng = n0 + wc * 64 + q * 32 + fg * 4;           // gate columns ng .. ng+3, up columns ng+16 ..
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = m0 + wr * 64 + mi * 16 + fr;
                 if (m < a.M && (n0 + wc * 64 + q * 32) < a.N) {
-                    bf16x4 o;
+                    O4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float g = rbf(acc[2 * q][mi][j]), u = rbf(acc[2 * q + 1][mi][j]);
-                        o[j] = f2bf(rbf(silu_f(g)) * u);
+                        const float g = gemm_lin<KD>(a, acc[2 * q][mi][j], m, ng + j, 0.f), u = gemm_lin<KD>(a, acc[2 * q + 1][mi][j], m, ng + 16 + j, 0.f);
+                        o[j] = (OT)(rT<OT>(silu_f(g)) * u);
                     }
-                    *(bf16x4*)(C + (long)m * a.ldc + oc) = o;
+                    *(O4*)(C + (long)m * a.ldc + oc) = o;
                 }
             }
         }
@@ -170,19 +175,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wr * 64 + mi * 16 + fr;
             if (m >= a.M) continue;
-            bf16x4 o;
-            if (EPI == EPI_BIAS_RESID) {
-                const bf16x4 rv = *(const bf16x4*)(R + (long)m * a.ldr + n);
+            O4 o;
+            float l[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(rbf(acc[ni][mi][j] + bv[j]) + bf2f(rv[j]));
+            for (int j = 0; j < 4; ++j) l[j] = gemm_lin<KD>(a, acc[ni][mi][j], m, n + j, bv[j]);
+            if (EPI == EPI_BIAS_RESID) {
+                const O4 rv = *(const O4*)(R + (long)m * a.ldr + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (OT)(l[j] + (float)rv[j]);
             } else if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(gelu_erf(rbf(acc[ni][mi][j] + bv[j])));
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(l[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[ni][mi][j] + bv[j]);
+                for (int j = 0; j < 4; ++j) o[j] = (OT)l[j];
             }
-            *(bf16x4*)(C + (long)m * a.ldc + n) = o;
+            *(O4*)(C + (long)m * a.ldc + n) = o;
         }
     }
 }
@@ -223,13 +231,15 @@ static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s) {
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), block(256);
     const size_t lds = 2 * STAGE_BYTES;
-    switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, lds, s, a); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS_GELU>, grid, block, lds, s, a); break;
-        case EPI_BIAS_RESID: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS_RESID>, grid, block, lds, s, a); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL(gemm_kernel<EPI_SWIGLU>, grid, block, lds, s, a); break;
-        case EPI_QKV_VT: hipLaunchKernelGGL(gemm_kernel<EPI_QKV_VT>, grid, block, lds, s, a); break;
-    }
+    KD_SWITCH(a, KD, {
+        switch (epi) {
+            case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<KD, EPI_BIAS>), grid, block, lds, s, a); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<KD, EPI_BIAS_GELU>), grid, block, lds, s, a); break;
+            case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_kernel<KD, EPI_BIAS_RESID>), grid, block, lds, s, a); break;
+            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<KD, EPI_SWIGLU>), grid, block, lds, s, a); break;
+            case EPI_QKV_VT: if constexpr (!KD::I8) hipLaunchKernelGGL((gemm_kernel<KD, EPI_QKV_VT>), grid, block, lds, s, a); break;
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,25 +250,26 @@ static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s) {
 // D[n][m] (A-operand = W rows, B-operand = X rows); the 8 K-slices of a block are summed through LDS in fixed order
 // (deterministic, no float atomics) and stored as fp32.  K = 2048 needs no split at all (one slab); down_proj
 // (K = 6144) leaves 3 slabs for its consumer.
-template <int MB, int KW, bool NT>
+template <typename KD, int MB, int KW, bool NT>
 __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs a) {
+    typedef typename KD::elem ET_; typedef typename KD::frag Frag;
     __shared__ f32x4 red[8][MB][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int kb = (blockIdx.y * 8 + wid) * (KW * 32);
     // fragment-tiled weights (tile_weights_kernel): k-step s of row tile t is the contiguous 1 KiB block (t*K/32 + s)
-    const bf16_t* wp = a.W + ((long)blockIdx.x * (a.K >> 5) + (kb >> 5)) * 512 + lane * 8;
-    bf16x8 wf[KW];
+    const ET_* wp = (const ET_*)a.W + ((long)blockIdx.x * (a.K >> 5) + (kb >> 5)) * 512 + lane * 8;
+    Frag wf[KW];
 #pragma unroll
-    for (int u = 0; u < KW; ++u) wf[u] = NT ? __builtin_nontemporal_load((const bf16x8*)(wp + u * 512)) : *(const bf16x8*)(wp + u * 512);
-    bf16x8 xf[MB][KW];
+    for (int u = 0; u < KW; ++u) wf[u] = NT ? __builtin_nontemporal_load((const Frag*)(wp + u * 512)) : *(const Frag*)(wp + u * 512);
+    Frag xf[MB][KW];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         int row = mb * 16 + r; row = row < a.M ? row : a.M - 1;
-        const bf16_t* xp = a.X + (long)row * a.ldx + kb + g * 8;
+        const ET_* xp = (const ET_*)a.X + (long)row * a.ldx + kb + g * 8;
 #pragma unroll
-        for (int u = 0; u < KW; ++u) xf[mb][u] = *(const bf16x8*)(xp + u * 32);
+        for (int u = 0; u < KW; ++u) xf[mb][u] = *(const Frag*)(xp + u * 32);
     }
     f32x4 acc[MB];
 #pragma unroll
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int u = 0; u < KW; ++u)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[mb][u], acc[mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = KD::mfma(wf[u], xf[mb][u], acc[mb]);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) red[wid][mb][lane] = acc[mb];
     __syncthreads();
@@ -301,10 +312,13 @@ __global__ __launch_bounds__(512) void skinny_readfloor_kernel(SkinnyArgs a) {
 // source address, conflict-free ds_read_b128 fragments) and read by all 8 waves; weights go straight to VGPRs from the
 // fragment-tiled copy (every wave load is one contiguous 1 KiB, each weight byte read once, nontemporal).  The WK
 // K-slices of a block are summed through LDS; K/BKk slabs are left for the consumer (2 for K = 2048 with BKk = 1024).
-template <int MB, int WN, int WK, int KSW>
+template <typename KD, int MB, int WN, int WK, int KSW>
 __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
-    constexpr int BKk = WK * KSW * 32, NKB = BKk / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048;
-    static_assert(WN * WK == 8 && NI % 8 == 0, "8 waves");
+    typedef typename KD::elem ET_; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
+    // element size; elements per 16-B chunk, per MFMA k-step, per 128-B LDS row, per 1-KiB weight tile
+    constexpr int EB = sizeof(ET_), CE = 16 / EB, KS = 64 / EB, ROWE = 128 / EB, TILE_E = 1024 / EB;
+    constexpr int BKk = WK * KSW * KS, NKB = BKk / ROWE, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048, PW = (NI + 7) / 8;
+    static_assert(WN * WK == 8 && (WK * KSW) % 2 == 0, "8 waves, whole 128-byte K blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -315,27 +329,32 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
 #pragma unroll
-        for (int t = 0; t < NI / 8; ++t) {
-            const int ii = wid * (NI / 8) + t, kblock = ii / RG, rg = ii % RG;
-            int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
-            const bf16_t* src = a.X + (long)row * a.ldx + kb + kblock * 64 + lc * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
+        for (int t = 0; t < PW; ++t) {
+            const int ii = NI % 8 == 0 ? wid * PW + t : wid + t * 8;
+            if (NI % 8 == 0 || ii < NI) {
+                const int kblock = ii / RG, rg = ii % RG;
+                int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
+                const ET_* src = (const ET_*)a.X + (long)row * a.ldx + kb + kblock * ROWE + lc * CE;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
+            }
         }
     }
     // then the weights (HBM, nontemporal): asm loads with hand-counted waits, so that k-step u is multiplied as soon as ITS fragment
     // has landed (vmcnt retires in order) instead of after the whole slice - the compiler's own bookkeeping falls back to vmcnt(0)
     // when LDS-DMA and register loads are in flight together
-    const bf16_t* wp = a.W + ((long)(n0 >> 4) * (a.K >> 5) + ((kb + wk * (KSW * 32)) >> 5)) * 512 + lane * 8;
-    bf16x8 wf[KSW];
+    const ET_* wp = (const ET_*)a.W + ((long)(n0 >> 4) * (a.K / KS) + ((kb + wk * (KSW * KS)) / KS)) * TILE_E + lane * CE;
+    Frag wf[KSW];
 #pragma unroll
     for (int u = 0; u < KSW; ++u) {
         if (u < 4) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp), "n"(u * 1024) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp + (u / 4) * 2048), "n"((u % 4) * 1024) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp + (u / 4) * 4 * TILE_E), "n"((u % 4) * 1024) : "memory");
     }
-    f32x4 acc[MB];
+    Acc acc[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mb][e] = 0;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KSW) : "memory");      // this wave's X pieces are in LDS
     __builtin_amdgcn_s_barrier();                                    // (raw barrier: __syncthreads would add a vmcnt(0) fence)
 #pragma unroll
@@ -345,12 +364,12 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int m = mb * 16 + r;
-            const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[mb], 0, 0, 0);
+            const Frag xf = *(const Frag*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+            acc[mb] = KD::mfma(wf[u], xf, acc[mb]);
         }
     }
     __syncthreads();
-    f32x4* red = (f32x4*)smem;   // [WK][WN][MB][64]
+    Acc* red = (Acc*)smem;   // [WK][WN][MB][64]
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) red[((wk * WN + wn) * MB + mb) * 64 + lane] = acc[mb];
     __syncthreads();
@@ -358,13 +377,20 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     const int nb0 = blockIdx.x * BNR;
     for (int o = tid; o < BNR * mpad; o += 512) {
         const int m = o / BNR, nl = o % BNR, wn2 = nl >> 4, nloc = nl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3;
-        float s = 0.f;
+        const long dst = ((long)blockIdx.y * mpad + m) * a.N + nb0 + nl;
+        if constexpr (KD::I8) {
+            int s = 0;
 #pragma unroll
-        for (int k = 0; k < WK; ++k) s += red[((k * WN + wn2) * MB + (m >> 4)) * 64 + ln][j];
-        a.P[((long)blockIdx.y * mpad + m) * a.N + nb0 + nl] = s;
+            for (int k = 0; k < WK; ++k) s += red[((k * WN + wn2) * MB + (m >> 4)) * 64 + ln][j];
+            ((int*)a.P)[dst] = s;                                    // exact int32 partial product; the consumer dequantises (deq4)
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < WK; ++k) s += red[((k * WN + wn2) * MB + (m >> 4)) * 64 + ln][j];
+            a.P[dst] = s;
+        }
     }
 }
-
 
 // skinny_gu_kernel: decode-step gate/up projection with SwiGLU fused (modeling_llama.py:163-176).
 // Weights are fragment-tiled with gate and up rows interleaved in groups of 8 (launch_tile_weights_gu8): one 16-row MFMA tile holds
@@ -644,46 +670,71 @@ int skinny_pick_ksplit(int N, int K) {
     return kw ? K / (256 * kw) : 0;
 }
 
-template <int MB, int KW> static void launch_skinny_v(const SkinnyArgs& a, hipStream_t s) {
+template <typename KD, int MB, int KW> static void launch_skinny_v(const SkinnyArgs& a, hipStream_t s) {
     dim3 grid(a.N / 16, a.ksplit), block(512);
     const int v = g_opts.skinny_variant;
     if (v == 9) hipLaunchKernelGGL((skinny_readfloor_kernel<KW>), grid, block, 0, s, a);
-    else if (v == 3) hipLaunchKernelGGL((skinny_kernel<MB, KW, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<MB, KW, true>), grid, block, 0, s, a);
+    else if (v == 3) hipLaunchKernelGGL((skinny_kernel<KD, MB, KW, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<KD, MB, KW, true>), grid, block, 0, s, a);
 }
-template <int MB> static void launch_skinny_mb(const SkinnyArgs& a, int kw, hipStream_t s) {
+template <typename KD, int MB> static void launch_skinny_mb(const SkinnyArgs& a, int kw, hipStream_t s) {
     switch (kw) {
-        case 8: launch_skinny_v<MB, 8>(a, s); break;
-        case 4: launch_skinny_v<MB, 4>(a, s); break;
-        case 2: launch_skinny_v<MB, 2>(a, s); break;
-        default: launch_skinny_v<MB, 1>(a, s); break;
+        case 8: launch_skinny_v<KD, MB, 8>(a, s); break;
+        case 4: launch_skinny_v<KD, MB, 4>(a, s); break;
+        case 2: launch_skinny_v<KD, MB, 2>(a, s); break;
+        default: launch_skinny_v<KD, MB, 1>(a, s); break;
     }
 }
-template <int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
-    if (cfg == 1) {
-        const size_t lds = (size_t)16 * MB * 2048;
-        if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<MB, 4, 2, 16>, (int)lds);
-        hipLaunchKernelGGL((skinny_xs_kernel<MB, 4, 2, 16>), dim3(a.N / 64, a.K / 1024), dim3(512), lds, s, a);
-    } else {
-        const size_t lds = (size_t)8 * MB * 2048;
-        hipLaunchKernelGGL((skinny_xs_kernel<MB, 2, 4, 4>), dim3(a.N / 32, a.K / 512), dim3(512), lds, s, a);
-    }
+template <typename KD, int MB, int WN, int WK, int KSW> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
+    constexpr int EB = sizeof(typename KD::elem), KS = 64 / EB, ROWE = 128 / EB;
+    constexpr int NI = (WK * KSW * KS / ROWE) * MB * 2;
+    const size_t img = (size_t)NI * 1024, red = (size_t)8 * MB * 1024, lds = img > red ? img : red;
+    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW>, (int)lds);
+    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW>), dim3(a.N / (WN * 16), nkslices), dim3(512), lds, s, a);
 }
-void launch_skinny(const SkinnyArgs& a, hipStream_t s) {
+template <typename KD, int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
+    if (cfg == 1) launch_xs_v<KD, MB, 4, 2, 16>(a, a.K / 1024, s);
+    else launch_xs_v<KD, MB, 2, 4, 4>(a, a.K / 512, s);
+}
+// int8 operands (Linear8bitLt decode step): one kernel family, 32 weight rows x (4 * KSW * 64) of K per block
+//   K % 1024 == 0: K slices of 1024 (full-size model: qkv 96 x 2, o 64 x 2, gate/up 384 x 2, down 64 x 6 blocks)
+//   else K % 256 == 0: K slices of 256 (tiny test configurations)
+int skinny_pick_ksplit_i8(int N, int K) {
+    if (N % 32) return 0;
+    if (K % 1024 == 0) return K / 1024;
+    if (K % 256 == 0) return K / 256;
+    return 0;
+}
+template <int MB> static void launch_skinny_i8(const SkinnyArgs& a, hipStream_t s) {
+    if (a.K % 1024 == 0) launch_xs_v<KI8, MB, 2, 4, 4>(a, a.K / 1024, s);
+    else launch_xs_v<KI8, MB, 2, 4, 1>(a, a.K / 256, s);
+}
+template <typename KD> static void launch_skinny_16(const SkinnyArgs& a, hipStream_t s) {
     const int cfg = skinny_pick_cfg(a.N, a.K);
     const int mb = (a.M + 15) / 16;
     if (cfg) {
-        if (mb <= 1) launch_skinny_xs<1>(a, cfg, s);
-        else if (mb == 2) launch_skinny_xs<2>(a, cfg, s);
-        else if (mb == 3) launch_skinny_xs<3>(a, cfg, s);
-        else launch_skinny_xs<4>(a, cfg, s);
+        if (mb <= 1) launch_skinny_xs<KD, 1>(a, cfg, s);
+        else if (mb == 2) launch_skinny_xs<KD, 2>(a, cfg, s);
+        else if (mb == 3) launch_skinny_xs<KD, 3>(a, cfg, s);
+        else launch_skinny_xs<KD, 4>(a, cfg, s);
         return;
     }
     const int kw = skinny_pick_kw(a.K);
-    if (mb <= 1) launch_skinny_mb<1>(a, kw, s);
-    else if (mb == 2) launch_skinny_mb<2>(a, kw, s);
-    else if (mb == 3) launch_skinny_mb<3>(a, kw, s);
-    else launch_skinny_mb<4>(a, kw, s);
+    if (mb <= 1) launch_skinny_mb<KD, 1>(a, kw, s);
+    else if (mb == 2) launch_skinny_mb<KD, 2>(a, kw, s);
+    else if (mb == 3) launch_skinny_mb<KD, 3>(a, kw, s);
+    else launch_skinny_mb<KD, 4>(a, kw, s);
+}
+void launch_skinny(const SkinnyArgs& a, hipStream_t s) {
+    if (a.i8) {
+        const int mb = (a.M + 15) / 16;
+        if (mb <= 1) launch_skinny_i8<1>(a, s);
+        else if (mb == 2) launch_skinny_i8<2>(a, s);
+        else if (mb == 3) launch_skinny_i8<3>(a, s);
+        else launch_skinny_i8<4>(a, s);
+        return;
+    }
+    if (a.dt == DT_F16) launch_skinny_16<KF16>(a, s); else launch_skinny_16<KBF16>(a, s);
 }
 
 // W[N][K] row-major -> fragment-tiled: element (n, k) goes to ((n/16)*(K/32) + k/32)*512 + (((k%32)/8)*16 + n%16)*8 + k%8,
@@ -713,4 +764,18 @@ void launch_tile_weights_gu8(const bf16_t* w, bf16_t* wt, int N, int K, hipStrea
 void launch_tile_weights(const bf16_t* w, bf16_t* wt, int N, int K, hipStream_t s) {
     const long n = (long)N * (K >> 3);
     hipLaunchKernelGGL(tile_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wt, N, K);
+}
+
+// int8 variant: a (16-row, 64-k) MFMA A-operand tile of v_mfma_i32_16x16x64_i8 is 1 KiB; element (n, k) goes to
+// ((n/16)*(K/64) + k/64)*1024 + (((k%64)/16)*16 + n%16)*16 + k%16
+__global__ void tile_weights_i8_kernel(const int8_t* w, int8_t* wt, int N, int K) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece per thread
+    if (e >= (long)N * (K >> 4)) return;
+    const int n = e / (K >> 4), kc = e % (K >> 4), k = kc * 16;
+    const long dst = ((long)(n >> 4) * (K >> 6) + (k >> 6)) * 1024 + ((((k & 63) >> 4) * 16) + (n & 15)) * 16;
+    *(i32x4*)(wt + dst) = *(const i32x4*)(w + (long)n * K + k);
+}
+void launch_tile_weights_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s) {
+    const long n = (long)N * (K >> 4);
+    hipLaunchKernelGGL(tile_weights_i8_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wt, N, K);
 }

@@ -25,10 +25,11 @@
 #include <type_traits>
 
 #include "common.h"
+#include "int8_util.h"
 
 #define T256 256
-#define TBK 64
-#define HT_BYTES (128 * TBK * 2)            // one half-tile: 128 rows x 128 B
+#define TBKB 128                            // bytes of K per tile row: 64 16-bit or 128 int8 elements
+#define HT_BYTES (128 * TBKB)                // one half-tile: 128 rows x 128 B
 #define TILE_BYTES (4 * HT_BYTES)           // A0 A1 B0 B1
 #define LDS256_BYTES (256 * 528)            // >= 2 * TILE_BYTES; also holds the staged output tile of the epilogue
 #define SLOT_A0 0
@@ -41,8 +42,11 @@
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, bool STAGGER>
+template <typename KD, int EPI, bool STAGGER>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
+    typedef typename KD::elem ET_; typedef typename KD::out OT; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
+    typedef typename ET<OT>::v4 O4; typedef typename ET<OT>::v8 O8;
+    constexpr int EB = sizeof(ET_), CE = 16 / EB, TBK = TBKB / EB;   // bytes per element, elements per 16-B chunk / per K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x TILE_BYTES, the only LDS object of the kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,14 +68,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         tn = in / gm;
     }
     const int m0 = tm * T256, n0 = tn * T256;
-    const bf16_t* A = a.A + (long)blockIdx.z * a.strideA;
-    bf16_t* C = a.C + (long)blockIdx.z * a.strideC;
-    const bf16_t* R = (EPI == EPI_BIAS_RESID) ? a.R + (long)blockIdx.z * a.strideR : nullptr;
+    const ET_* A = (const ET_*)a.A + (long)blockIdx.z * a.strideA;
+    OT* C = (OT*)a.C + (long)blockIdx.z * a.strideC;
+    const OT* R = (EPI == EPI_BIAS_RESID) ? (const OT*)a.R + (long)blockIdx.z * a.strideR : nullptr;
 
     // ---- DMA sources: per half-tile this wave moves rows j*8 .. j*8+7 for j = 2*wid, 2*wid+1 of the 128-row image
     const int lr8 = lane >> 3, lc = (lane & 7) ^ lr8;
-    const bf16_t* srcA[2][2];   // [half][i]
-    const bf16_t* srcB[2][2];
+    const ET_* srcA[2][2];   // [half][i]
+    const ET_* srcB[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int lrow = (wid * 2 + i) * 8 + lr8;                 // row in the half-tile image
@@ -79,11 +83,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         for (int h = 0; h < 2; ++h) {
             int m = m0 + (lrow >> 6) * 128 + h * 64 + (lrow & 63); m = m < a.M ? m : a.M - 1;
             int n = n0 + (lrow >> 5) * 64 + h * 32 + (lrow & 31); n = n < a.N ? n : a.N - 1;
-            srcA[h][i] = A + (long)m * a.lda + lc * 8;
-            srcB[h][i] = a.W + (long)n * a.K + lc * 8;
+            srcA[h][i] = A + (long)m * a.lda + lc * CE;
+            srcB[h][i] = (const ET_*)a.W + (long)n * a.K + lc * CE;
         }
     }
-    auto dma = [&](const bf16_t* const (&src)[2], int k0, int buf, int slot) {
+    auto dma = [&](const ET_* const (&src)[2], int k0, int buf, int slot) {
         char* dst = smem + buf * TILE_BYTES + slot * HT_BYTES + wid * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -91,34 +95,36 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[4][8];   // [n-block][m-block]
+    Acc acc[4][8];   // [n-block][m-block]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
 
     const bool vtile = (EPI == EPI_QKV_VT) && (n0 >= a.n_split);
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    Frag af[4][2], b0[2][2], b1[2][2];
     auto read_a = [&](int buf, int half) {
         const char* s = smem + buf * TILE_BYTES + (half ? SLOT_A1 : SLOT_A0) * HT_BYTES;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int row = wr * 64 + mi * 16 + fr;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const Frag*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
         }
     };
-    auto read_b = [&](int buf, int half, bf16x8 (&b)[2][2]) {
+    auto read_b = [&](int buf, int half, Frag (&b)[2][2]) {
         const char* s = smem + buf * TILE_BYTES + (half ? SLOT_B1 : SLOT_B0) * HT_BYTES;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int row = wc * 32 + ni * 16 + fr;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b[ni][kk] = *(const bf16x8*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            for (int kk = 0; kk < 2; ++kk) b[ni][kk] = *(const Frag*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
         }
     };
     // vt (compile-time): transposed MFMA roles for the V tiles of the fused QKV GEMM; hoisted out of the K loop
-    auto quad = [&](auto vt, int mh, int nh, const bf16x8 (&b)[2][2]) {
+    auto quad = [&](auto vt, int mh, int nh, const Frag (&b)[2][2]) {
         constexpr bool VT = decltype(vt)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    if (VT) acc[nh * 2 + ni][mh * 4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], b[ni][kk], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
-                    else acc[nh * 2 + ni][mh * 4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][kk], af[mi][kk], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
+                    if (VT) acc[nh * 2 + ni][mh * 4 + mi] = KD::mfma(af[mi][kk], b[ni][kk], acc[nh * 2 + ni][mh * 4 + mi]);
+                    else acc[nh * 2 + ni][mh * 4 + mi] = KD::mfma(b[ni][kk], af[mi][kk], acc[nh * 2 + ni][mh * 4 + mi]);
                 }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -191,7 +197,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             ++kt;
             ktile(vt, kt, I4{}, I2{}, I0{}, No{});        // K tile nk-1
         };
-        if (EPI == EPI_QKV_VT && vtile) run0(Yes{}); else run0(No{});
+        if constexpr (EPI == EPI_QKV_VT) { if (vtile) run0(Yes{}); else run0(No{}); }
+        else run0(No{});
     } else {
         auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
         // one K tile of one wave group (G0 = true: waves 0-3).  The two groups run separate straight-line loops (the branch
@@ -233,8 +240,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             stile(grp, vt, kt, I2{}, I0{}, IM1{}, No{}, false);
             if (!decltype(grp)::value) quad(vt, 1, 0, b0);                               // waves 4-7: last K tile's quadrant 3
         };
-        if (EPI == EPI_QKV_VT && vtile) { if (wid < 4) run(Yes{}, Yes{}); else run(No{}, Yes{}); }
-        else { if (wid < 4) run(Yes{}, No{}); else run(No{}, No{}); }
+        if constexpr (EPI == EPI_QKV_VT) {
+            if (vtile) { if (wid < 4) run(Yes{}, Yes{}); else run(No{}, Yes{}); }
+            else { if (wid < 4) run(Yes{}, No{}); else run(No{}, No{}); }
+        } else { if (wid < 4) run(Yes{}, No{}); else run(No{}, No{}); }
     }
 
     // ---- epilogue.  acc[nb][mb][j] = D[n = n0 + wc*64 + nb*16 + fg*4 + j][m = m0 + wr*128 + mb*16 + fr].
@@ -244,18 +253,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     // with the same coalesced pattern in that final pass.
     __syncthreads();
     constexpr int CLD = 528;                     // staged row pitch in bytes (256 bf16 + 16 B skew)
-    if (vtile) {
+    if (EPI == EPI_QKV_VT && vtile) {
         // staged transposed: row = n (256), columns = m; V^T[seg][n - n_split][t .. t+3] leaves in 8-byte pieces (T % 4 == 0)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const int nl = wc * 64 + nb * 16 + fr, n = n0 + nl;
             const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+            const int nc = n < a.N ? n : a.N - 1;
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
-                bf16x4 o;
+                O4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[nb][mb][j] + bv);
-                *(bf16x4*)(smem + nl * CLD + (wr * 128 + mb * 16 + fg * 4) * 2) = o;
+                for (int j = 0; j < 4; ++j) {
+                    int m = m0 + wr * 128 + mb * 16 + fg * 4 + j; m = m < a.M ? m : a.M - 1;
+                    o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc, bv);
+                }
+                *(O4*)(smem + nl * CLD + (wr * 128 + mb * 16 + fg * 4) * 2) = o;
             }
         }
         __syncthreads();
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             const int m = m0 + mc * 4, n = n0 + nl;
             if (m < a.M && n < a.N) {
                 const int seg = m / a.seg_T, t = m - seg * a.seg_T;
-                *(bf16x4*)(a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = *(const bf16x4*)(smem + nl * CLD + mc * 8);
+                *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = *(const O4*)(smem + nl * CLD + mc * 8);
             }
         }
         return;
@@ -274,15 +287,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ol = wc * 32 + q * 16 + fg * 4;           // column in the 128-wide activated tile
+            int ng = n0 + wc * 64 + q * 32 + fg * 4; ng = ng + 19 < a.N ? ng : 0;   // gate columns ng .., up columns ng + 16 .. (clamped: unused beyond N)
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
-                bf16x4 o;
+                O4 o;
+                int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g = rbf(acc[2 * q][mb][j]), u = rbf(acc[2 * q + 1][mb][j]);
-                    o[j] = f2bf(rbf(silu_f(g)) * u);
+                    const float g = gemm_lin<KD>(a, acc[2 * q][mb][j], m, ng + j, 0.f), u = gemm_lin<KD>(a, acc[2 * q + 1][mb][j], m, ng + 16 + j, 0.f);
+                    o[j] = (OT)(rT<OT>(silu_f(g)) * u);
                 }
-                *(bf16x4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + ol * 2) = o;
+                *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + ol * 2) = o;
             }
         }
         __syncthreads();
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         for (int it = 0; it < 8; ++it) {
             const int c = it * 512 + tid, row = c >> 4, ch = c & 15;
             const int m = m0 + row, oc = o0 + ch * 8;
-            if (m < a.M && oc < No) *(bf16x8*)(C + (long)m * a.ldc + oc) = *(const bf16x8*)(smem + row * CLD + ch * 16);
+            if (m < a.M && oc < No) *(O8*)(C + (long)m * a.ldc + oc) = *(const O8*)(smem + row * CLD + ch * 16);
         }
         return;
     }
@@ -303,17 +318,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             const f32x4 b4 = *(const f32x4*)(a.bias + n);
             bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
         }
+        const int nc = n + 3 < a.N ? n : 0;                  // (clamped: columns beyond N are computed and dropped)
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
-            bf16x4 o;
+            O4 o;
+            int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
             if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(gelu_erf(rbf(acc[nb][mb][j] + bv[j])));
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j]));
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[nb][mb][j] + bv[j]);   // RESID: the linear's own bf16 output; R is added below
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j]);   // RESID: the linear's own output; R is added below
             }
-            *(bf16x4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
+            *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
         }
     }
     __syncthreads();
@@ -322,29 +339,33 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int c = it * 512 + tid, row = c >> 5, ch = c & 31;
         const int m = m0 + row, n = n0 + ch * 8;
         if (m < a.M && n < a.N) {
-            bf16x8 v = *(const bf16x8*)(smem + row * CLD + ch * 16);
+            O8 v = *(const O8*)(smem + row * CLD + ch * 16);
             if (EPI == EPI_BIAS_RESID) {
-                const bf16x8 rv = *(const bf16x8*)(R + (long)m * a.ldr + n);
+                const O8 rv = *(const O8*)(R + (long)m * a.ldr + n);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(rv[j]));
+                for (int j = 0; j < 8; ++j) v[j] = (OT)((float)v[j] + (float)rv[j]);
             }
-            *(bf16x8*)(C + (long)m * a.ldc + n) = v;
+            *(O8*)(C + (long)m * a.ldc + n) = v;
         }
     }
 }
 
 
-template <int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
-    ensure_dyn_lds((const void*)gemm256_kernel<EPI, STG>, LDS256_BYTES);
+template <typename KD, int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
+    ensure_dyn_lds((const void*)gemm256_kernel<KD, EPI, STG>, LDS256_BYTES);
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS256_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<KD, EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS256_BYTES, s, a);
 }
 template <int EPI> static void launch256(const GemmArgs& a, hipStream_t s) {
-    if (g_opts.gemm256_stagger) launch256v<EPI, true>(a, s); else launch256v<EPI, false>(a, s);
+    if (a.q.sca) { if constexpr (EPI != EPI_QKV_VT) launch256v<KI8, EPI, true>(a, s); }
+    else if (a.dt == DT_F16) launch256v<KF16, EPI, true>(a, s);
+    else if (g_opts.gemm256_stagger) launch256v<KBF16, EPI, true>(a, s);
+    else launch256v<KBF16, EPI, false>(a, s);                  // the un-staggered schedule is kept for bf16 experiments only
 }
 
 bool gemm256_eligible(const GemmArgs& a, int epi) {
-    if (a.K % TBK || a.K / TBK < 4) return false;
+    const int tbk = a.q.sca ? TBKB : TBKB / 2;                 // K elements per tile
+    if (a.K % tbk || a.K / tbk < 4) return false;
     if (a.M < 512 || a.N < 256) return false;
     if (a.N % 16 || a.ldc % 8 || (epi == EPI_BIAS_RESID && a.ldr % 8)) return false;   // 16-byte row pieces in the staged epilogue
     if (epi == EPI_QKV_VT && (a.n_split % T256)) return false;
@@ -357,6 +378,6 @@ void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_BIAS_GELU: launch256<EPI_BIAS_GELU>(a, s); break;
         case EPI_BIAS_RESID: launch256<EPI_BIAS_RESID>(a, s); break;
         case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, s); break;
-        case EPI_QKV_VT: launch256<EPI_QKV_VT>(a, s); break;
+        case EPI_QKV_VT: launch256<EPI_QKV_VT>(a, s); break;      // (never with int8 operands: the int8 encoder writes V row-major and transposes it)
     }
 }

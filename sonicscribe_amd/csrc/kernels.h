@@ -2,6 +2,26 @@
 #pragma once
 #include "common.h"
 
+// ---- int8 mode (LLM.int8, asr.py:169-210) plumbing shared by the decode-step kernels ---------------------------------------------
+// How a consumer turns the int32 partial slabs of a quantised skinny GEMM into the module's fp16 output:
+//   y = fp16(float(sum_ks C32) * (SCA[row] * SCB[col] * 1/127^2)); outlier columns of the row's group are added from the unquantised
+//   input and the dequantised int8 weights, y = fp16(y + sum_k x[row][k] * fp16(CB[col][k] * SCB[col] / 127))   (sonic_oracle.c linear_int8)
+struct DeqInfo {
+    const float* sca;                 // [M] row absmax of the GEMM's quantised input; NULL = plain mode (slabs hold fp32 partial sums)
+    const float* scb;                 // [N] row absmax of the weights
+    const int8_t* cb; int K;          // [N][K] row-major int8 weights
+    const bf16_t* x16; long ldx16;    // the GEMM's unquantised input (fp16 storage)
+    const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
+    const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div
+};
+// A producer that owns whole rows also emits them quantised for the next Linear8bitLt (decode step: one row = one reference call,
+// so the outlier "columns" are the row's own elements >= 6.0)
+struct QuantOut {
+    int8_t* q; long ldq;              // [M][K] int8; NULL = off
+    float* sca;                       // [M]
+    int* oc_cnt; int* oc_list; int oc_ld;
+};
+
 struct FlashArgs {
     const bf16_t* Q; long q_ld;            // token-major, head h at column h*HD
     const bf16_t* K; long k_ld;            // key-major rows
@@ -13,6 +33,7 @@ struct FlashArgs {
     const int* kv_len;                     // optional [B]; else T
     int T, Hq, Hkv;
     float scale;
+    int dt;                                // DT_BF16 / DT_F16
 };
 void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s);
 
@@ -25,6 +46,8 @@ struct DecodeAttnArgs {
     const int* kv_len;    // [B] keys visible (new token included)
     int Hq, Hkv, ctx_max;
     float scale;
+    int dt;
+    DeqInfo dq;           // int8 mode: P holds int32 slabs of the quantised QKV projection
 };
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s);
 
@@ -37,6 +60,7 @@ struct RopeAppendArgs {
     const int* tok_seq; const int* tok_pos;  // per token: sequence index, absolute position
     const float* cs;                     // [ctx_max][hd]: cos[0..hd/2) | sin[0..hd/2)
     int Hq, Hkv, ctx_max, n_tok;
+    int dt;
 };
 void launch_rope_append(const RopeAppendArgs& a, bool slab, hipStream_t s);
 
@@ -57,6 +81,8 @@ struct GreedyArgs {
     float* logits_dump; long dump_stride_step; int* step_counter;  // optional: bf16-rounded logits per step [step][B][V]; counter per row [B]
     const float* norm_w; float norm_eps; bf16_t* y;   // optional: y[B][d] = RMSNorm(x) with the first decoder layer's input norm
     const int* force_ids; int force_ld;                // optional teacher forcing: token n of row b is force_ids[b * force_ld + n] (oracle force_ids)
+    int dt;
+    QuantOut qo;                                       // int8 mode: y is also emitted quantised (input of layer 0's q/k/v Linear8bitLt)
 };
 void launch_greedy(const GreedyArgs& a, hipStream_t s);
 
@@ -70,15 +96,37 @@ struct LogmelConst {
     const float* mel_w;    // packed taps
 };
 void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev, int max_samples, const LogmelConst& lc,
-                   float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s);
+                   float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s, int dt = DT_BF16);
 
-void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s);
-void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s);
-void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s);
-void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s);
-void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s);
+void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt = DT_BF16);
+void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt = DT_BF16);
+void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
+                        int dt = DT_BF16, const DeqInfo* dq = nullptr, const QuantOut* qo = nullptr);
+void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt = DT_BF16);
+// int8 decode: int32 gate/up slabs (rows interleaved in 16-row groups as for EPI_SWIGLU) -> act (fp16) + its quantised form
+void launch_swiglu_quant(const float* P, int ksplit, int mpad, int ff, bf16_t* act, int rows, const DeqInfo& dq, const QuantOut& qo, hipStream_t s);
+void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s, int dt = DT_BF16);
 void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d, hipStream_t s);
 void launch_fill_i32(int* p, int value, int n, hipStream_t s);
-void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
-void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s);
+void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s, int dt = DT_BF16);      // fp32 -> element type
+void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s, int dt = DT_BF16);      // element type -> fp32
+void launch_bf16_to_f16(const bf16_t* in, bf16_t* out, long n, hipStream_t s);                       // bf16 storage -> fp16 storage (RNE), in place allowed
 void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s);
+
+// ---- int8 mode: activation / weight quantisation (quant.hip) ----
+// Row-wise int8 of a weight matrix [N][K] (fp16 storage): CB, SCB (Int8Params.cuda(): int8_vectorwise_quant(W.half()))
+void launch_quant_weights(const bf16_t* w, int8_t* cb, float* scb, int N, int K, hipStream_t s);
+// One Linear8bitLt input X [M][K] (fp16 storage, row stride ld): outlier columns per GROUP of rows (= one reference call), row absmax
+// without the outliers, int8 rows.  flags: scratch [G][K] bytes.  group of row r = gmap ? gmap[r / gdiv] : r / gdiv.
+struct QuantActArgs {
+    const bf16_t* X; long ld; int M, K;
+    const int* gmap; int gdiv; int G;
+    unsigned char* flags;
+    int8_t* q; float* sca; int* oc_cnt; int* oc_list; int oc_ld;
+};
+void launch_quant_act(const QuantActArgs& a, hipStream_t s);
+// decode flavour: every row is its own group; one block per row
+void launch_quant_rows(const bf16_t* X, long ld, int M, int K, const QuantOut& qo, hipStream_t s);
+void launch_tile_weights_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s);
+// int8 encoder: V columns [col0, col0 + C) of the row-major QKV matrix -> V^T [seg][C][vt_ld]
+void launch_transpose_v(const bf16_t* qkv, long ld, int col0, bf16_t* vt, int n_seg, int T, int C, int vt_ld, long vt_seg_stride, hipStream_t s);

@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     if (lane == 0 && lmax > -1e29f) atomicMax(&segmax[b], ord_enc(lmax));
 }
 
+template <typename T>
 __global__ void logmel_finalize_kernel(const float* logspec, const int* segmax, const int* n_samples, int n_frames, int n_mels,
-                                       bf16_t* feats_fm /* [B][n_frames+2][n_mels], rows 0 and n_frames+1 stay zero */,
+                                       T* feats_fm /* [B][n_frames+2][n_mels], rows 0 and n_frames+1 stay zero */,
                                        float* feats_f32 /* optional [B][n_mels][n_frames] */) {
     const int b = blockIdx.y;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,12 +169,12 @@ __global__ void logmel_finalize_kernel(const float* logspec, const int* segmax, 
     float v = t < t_live ? logspec[((long)b * n_frames + t) * n_mels + m] : floor_v;
     v = fmaxf(v, gmax - 8.0f);
     v = (v + 4.0f) / 4.0f;
-    feats_fm[((long)b * (n_frames + 2) + 1 + t) * n_mels + m] = f2bf(v);
+    feats_fm[((long)b * (n_frames + 2) + 1 + t) * n_mels + m] = (T)v;      // asr.py:280-301: features cast to the model dtype
     if (feats_f32) feats_f32[((long)b * n_mels + m) * n_frames + t] = v;
 }
 
 void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev, int max_samples, const LogmelConst& lc,
-                   float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s) {
+                   float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s, int dt) {
     launch_fill_i32(segmax, (int)0x80808080, B, s);   // ordered-int encoding of a very negative float
     const int n_pad = n_frames * LM_HOP;
     const int n = max_samples < n_pad ? max_samples : n_pad;
@@ -182,5 +183,5 @@ void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev
     ensure_dyn_lds((const void*)logmel_power_kernel, LM_DYN_LDS);
     if (tiles > 0) hipLaunchKernelGGL(logmel_power_kernel, dim3(tiles, B), dim3(256), LM_DYN_LDS, s, pcm, pcm_stride, n_samples_dev, lc, logspec, segmax, n_frames, n_mels);
     const long tot = (long)n_frames * n_mels;
-    hipLaunchKernelGGL(logmel_finalize_kernel, dim3((tot + 255) / 256, B), dim3(256), 0, s, logspec, segmax, n_samples_dev, n_frames, n_mels, feats_fm, feats_f32);
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(logmel_finalize_kernel<T>, dim3((tot + 255) / 256, B), dim3(256), 0, s, logspec, segmax, n_samples_dev, n_frames, n_mels, (T*)feats_fm, feats_f32));
 }

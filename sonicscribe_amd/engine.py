@@ -26,7 +26,7 @@ EXPORTS = [
     "sonic_finalize_weights", "sonic_weight_bytes", "sonic_logmel", "sonic_encode", "sonic_transcribe_batch", "sonic_stage_pcm",
     "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
     "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_test_skinny_gu",
-    "sonic_set_forced_ids", "sonic_test_greedy",
+    "sonic_set_forced_ids", "sonic_test_greedy", "sonic_test_linear_int8",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library():
     lib.sonic_test_skinny_gu.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.sonic_test_linear_int8.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -363,6 +364,18 @@ def _test_greedy(self, slabs, B: int, want_logits: bool = False):
     return tok, lg
 
 
+def _test_linear_int8(self, X, W, bias=None, resid=None, group_rows=None, epi=EPI_BIAS):
+    """One Linear8bitLt call; X [M][K], W [N][K] fp16-valued. group_rows: rows per reference call (default: all rows one call)."""
+    X = np.ascontiguousarray(X, np.float32); W = np.ascontiguousarray(W, np.float32)
+    M, K = X.shape; N = W.shape[0]
+    out = np.empty((M, N // 2 if epi == EPI_SWIGLU else N), np.float32)
+    b = np.ascontiguousarray(bias, np.float32) if bias is not None else None
+    r = np.ascontiguousarray(resid, np.float32) if resid is not None else None
+    self._check(self.lib.sonic_test_linear_int8(self.h, _p(X), _p(W), _p(b), _p(r), _p(out), M, N, K, int(group_rows or M), epi))
+    return out
+
+
+Engine.test_linear_int8 = _test_linear_int8
 Engine.set_forced_ids = _set_forced_ids
 Engine.test_greedy = _test_greedy
 Engine.test_skinny_gu = _test_skinny_gu

@@ -67,7 +67,12 @@ def to_bf16_bits(x: np.ndarray) -> np.ndarray:
     return r.astype(np.uint16)
 
 
-def synth_fill(seed: int, name: str, n: int, scale: float, offset: float, bf16: bool) -> np.ndarray:
+def round_f16(x: np.ndarray) -> np.ndarray:
+    """fp32 -> IEEE half (round to nearest even) -> fp32."""
+    return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def synth_fill(seed: int, name: str, n: int, scale: float, offset: float, bf16) -> np.ndarray:
     key = np.uint64(tensor_key(seed, name))
     with np.errstate(over="ignore"):
         idx = np.arange(1, n + 1, dtype=np.uint64)
@@ -77,6 +82,8 @@ def synth_fill(seed: int, name: str, n: int, scale: float, offset: float, bf16: 
     v = r * np.float32(scale)
     v = np.float32(offset) + v
     v = v.astype(np.float32)
+    if int(bf16) == 2:          # a bf16 checkpoint loaded with torch_dtype=float16 (the int8 mode, asr.py:156)
+        return round_f16(round_bf16(v))
     return round_bf16(v) if bf16 else v
 
 
@@ -98,8 +105,8 @@ def kind_params(kind: str, shape: Tuple[int, ...]) -> Tuple[float, float]:
     return (float(np.float32(s)), 0.0)
 
 
-def synth_state_dict(dims: ModelDims, seed: int, bf16: bool) -> Dict[str, np.ndarray]:
-    """All parameters as fp32 numpy arrays (bf16-representable when ``bf16``)."""
+def synth_state_dict(dims: ModelDims, seed: int, bf16) -> Dict[str, np.ndarray]:
+    """All parameters as fp32 numpy arrays (bf16-representable when ``bf16``; fp16(bf16(.)) when ``bf16 == 2``)."""
     out: Dict[str, np.ndarray] = {}
     for name, shape, kind in tensor_inventory(dims):
         n = int(np.prod(shape))

@@ -1,0 +1,183 @@
+"""GPU tests of the INT8 path (BASELINE config 4): backend/asr.py mode="int8" = fp16 activations + bitsandbytes
+LLM.int8() linears (asr.py:148-210).  bitsandbytes is absent offline, so the checker is the restatement in oracle/sonic_oracle.c
+(linear_int8, MODE_INT8) -- PARITY UNPINNED against the real library, pinned only to its published algorithm.
+
+What is exact and what is not: the int8 x int8 -> int32 products are exact on both sides, and the dequantisation follows the same
+operation order, so a Linear8bitLt on identical inputs must agree bit for bit.  End to end, the fp16 ops between the linears
+(LayerNorm, attention, GELU) differ in fp32 summation order; a 1-ulp fp16 difference on an activation can move an int8 code by one,
+so whole-model logits are compared with a stated bound.
+"""
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from sonicscribe_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+SEED = 20260128
+
+
+def f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def eng8():
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    e = Engine(spec.TINY, 0, MODE_INT8, max_batch=8, max_ctx=512)
+    e.load_synthetic(SEED)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _ref_linear(orc, X, W, bias, group_rows):
+    cb, scb = orc.quantize_rows(W)
+    out = np.empty((X.shape[0], W.shape[0]), np.float32)
+    for r0 in range(0, X.shape[0], group_rows):
+        out[r0:r0 + group_rows] = orc.linear_int8(X[r0:r0 + group_rows], cb, scb, bias)
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,group_rows", [(16, 64, 128, 16), (100, 128, 256, 25), (300, 256, 384, 300), (777, 384, 512, 259), (1536, 512, 1280, 512),
+                                              (2048, 256, 5120, 1024), (600, 1280, 512, 200)])
+def test_linear8bit_bias_exact(eng8, orc, M, N, K, group_rows):
+    """One Linear8bitLt + bias against the oracle: must be BIT-EXACT (integer products, same dequantisation order).  Shapes cover the
+    128x128 and the 256x256 int8 MFMA kernels (M >= 512, N >= 256, K >= 512), ragged edges, several groups per call, and planted
+    outliers: single elements >= 6 (their column leaves the int8 product for the whole group) in some groups only."""
+    rng = np.random.default_rng(M + N + K)
+    X = f16(rng.standard_normal((M, K)) * 1.2); W = f16(rng.standard_normal((N, K)) * 0.06); b = f16(rng.standard_normal(N) * 0.1)
+    X[0, 3] = 6.0; X[M // 2, K - 1] = -11.5; X[M - 1, 64] = 7.25; X[M // 2, 17] = 5.99609375  # 6.0 itself is an outlier, the fp16 below it is not
+    got = eng8.test_linear_int8(X, W, b, group_rows=group_rows)
+    ref = _ref_linear(orc, X, W, b, group_rows)
+    assert np.array_equal(got, ref), (np.abs(got - ref).max(), int((got != ref).sum()))
+    dense = X.astype(np.float64) @ W.T.astype(np.float64) + b
+    assert np.abs(got - dense).max() < 0.25                                                   # and it is a sane approximation of the fp product
+
+
+def test_linear8bit_int8_mfma_layout(eng8, orc):
+    """Exact-integer data with an asymmetric weight matrix: a wrong lane / k map of v_mfma_i32_16x16x64_i8 cannot hide (cdna guide §3)."""
+    M, N, K = 64, 64, 256
+    X = np.zeros((M, K), np.float32); W = np.zeros((N, K), np.float32)
+    for m in range(M):
+        X[m, (m * 7) % K] = 1.0; X[m, (m * 3 + 1) % K] = 0.5
+    W = f16(((np.arange(N)[:, None] * 31 + np.arange(K)[None, :] * 17) % 127 - 63) / 64.0)
+    got = eng8.test_linear_int8(X, W, None)
+    ref = _ref_linear(orc, X, W, None, M)
+    assert np.array_equal(got, ref)
+
+
+def test_linear8bit_epilogues(eng8, orc):
+    import math
+    from sonicscribe_amd.engine import EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU
+    rng = np.random.default_rng(8)
+    for (M, N, K) in [(200, 256, 256), (1024, 512, 768)]:
+        X = f16(rng.standard_normal((M, K))); W = f16(rng.standard_normal((N, K)) * 0.08); b = f16(rng.standard_normal(N) * 0.1)
+        X[5, 9] = 8.0
+        R = f16(rng.standard_normal((M, N)))
+        lin = _ref_linear(orc, X, W, b, M)
+        got = eng8.test_linear_int8(X, W, b, resid=R, epi=EPI_BIAS_RESID)
+        assert np.array_equal(got, f16(lin + R))
+        erf = np.vectorize(math.erf)
+        gelu = f16((0.5 * lin * (1.0 + erf(lin.astype(np.float64) / math.sqrt(2.0)))).astype(np.float32))
+        got = eng8.test_linear_int8(X, W, b, epi=EPI_BIAS_GELU)
+        assert np.abs(got - gelu).max() <= 2.0 ** -10 * max(1.0, float(np.abs(gelu).max()))    # 1 fp16 ulp (fast erf / exp in the epilogue)
+        ff = N // 2
+        Wg = W[:ff]; Wu = W[ff:]
+        Wi = np.empty_like(W)
+        for g in range(ff // 16):
+            Wi[32 * g:32 * g + 16] = Wg[16 * g:16 * g + 16]; Wi[32 * g + 16:32 * g + 32] = Wu[16 * g:16 * g + 16]
+        gg = _ref_linear(orc, X, Wg, None, M); uu = _ref_linear(orc, X, Wu, None, M)
+        ref = f16(f16(gg / (1.0 + np.exp(-gg.astype(np.float64))).astype(np.float32)) * uu)
+        got = eng8.test_linear_int8(X, Wi, None, epi=EPI_SWIGLU)
+        assert np.abs(got - ref).max() <= 2.0 ** -9 * max(1.0, float(np.abs(ref).max()))
+
+
+def _prompt(n_samples, d):
+    return [1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(n_samples)) + [7, 301, 302, 303, 9, 11]
+
+
+def test_int8_transcribe_vs_oracle(eng8, orc):
+    """Whole path in int8 mode at TINY dims against the oracle's MODE_INT8: fp16 log-mel hand-off, fp16 conv stem / norms / attention,
+    Linear8bitLt everywhere else, fp16 lm_head, greedy; free-running and teacher-forced, a 5 s and a 20 s segment in one batch."""
+    d = spec.TINY
+    om = orc.Model(d, synth.synth_state_dict(d, SEED, 2), mode=orc.MODE_INT8)
+    segs = [synth.synth_pcm(10, 80000), synth.synth_pcm(11, 320000)]
+    prompts = [_prompt(len(s), d) for s in segs]
+    n_new = 8
+    rng = np.random.default_rng(5)
+    force = rng.integers(2, 900, (2, n_new)).astype(np.int32)
+    tol = 0.08
+    worst = 0.0
+    for forced in (None, force):
+        eng8.set_forced_ids(forced)
+        try:
+            ids, logits = eng8.transcribe_batch(segs, prompts, [n_new, n_new], want_logits=True)
+        finally:
+            eng8.set_forced_ids(None)
+        for i in range(2):
+            feats, mask = orc.logmel(segs[i])
+            r = om.transcribe(feats, int(mask.sum()), prompts[i], n_new, force_ids=None if forced is None else forced[i])
+            n = min(len(ids[i]), len(r["new_ids"]))
+            for st in range(n):
+                dl = float(np.abs(logits[st, i] - r["step_logits"][st]).max()); worst = max(worst, dl)
+                assert dl <= tol, (forced is not None, i, st, dl)
+                srt = np.sort(r["step_logits"][st]); margin = srt[-1] - srt[-2]
+                if ids[i][st] != r["new_ids"][st]:
+                    assert margin <= 2 * tol, (i, st, ids[i], r["new_ids"])
+                    break
+    print(f"int8 tiny: max|dlogit| vs oracle {worst:.4f}")
+    # graph-replayed loop == eager loop, batch == single
+    g, _ = eng8.transcribe_batch(segs, prompts, [n_new, n_new])
+    ee, _ = eng8.transcribe_batch(segs, prompts, [n_new, n_new], want_logits=True)
+    s0, _ = eng8.transcribe_batch([segs[1]], [prompts[1]], [n_new])
+    assert np.array_equal(g[0], ee[0]) and np.array_equal(g[1], ee[1]) and np.array_equal(s0[0], g[1])
+
+
+def test_int8_fullwidth_layer_vs_oracle(orc):
+    """Full-width layers (encoder 1280 / 5120, decoder 2048 / 6144 GQA 16:4) at depth 1 + 1, vocabulary 1024, two 20 s segments:
+    the 256x256 int8 GEMM at M = 3000 with every epilogue, the int8 decode-step kernels at their full-size tilings (K slices of 1024,
+    down_proj with 6 slabs), against the oracle."""
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    d = replace(spec.FULL, enc_layers=1, dec_layers=1, vocab=1024, audio_token_id=1000, eos_ids=(990, 991, 992))
+    seed = 7
+    e = Engine(d, 0, MODE_INT8, max_batch=2, max_ctx=320)
+    e.load_synthetic(seed)
+    st = {}
+    for name, shape, kind in spec.tensor_inventory(d):
+        scale, offset = synth.kind_params(kind, shape)
+        st[name] = orc.synth_fill(seed, name, int(np.prod(shape)), scale, offset, 2).reshape(shape)
+    om = orc.Model(d, st, mode=orc.MODE_INT8)
+    segs = [synth.synth_pcm(60 + i, 320000) for i in range(2)]
+    prompt = _prompt(320000, d)
+    n_new = 3
+    force = np.asarray([[100, 200, 300], [400, 500, 600]], np.int32)
+    e.set_forced_ids(force)
+    ids, logits = e.transcribe_batch(segs, [prompt, prompt], [n_new, n_new], want_logits=True)
+    e.set_forced_ids(None)
+    worst = 0.0
+    for i in range(2):
+        feats, mask = orc.logmel(segs[i])
+        r = om.transcribe(feats, int(mask.sum()), prompt, n_new, force_ids=force[i])
+        worst = max(worst, float(np.abs(logits[:, i] - r["step_logits"]).max()))
+    print(f"int8 full-width 1+1: max|dlogit| vs oracle {worst:.4f}")
+    assert worst <= 0.1
+    e.close()
+
+
+def test_asrmodel_int8_mode():
+    from sonicscribe_amd.asr import ASRModel
+    m = ASRModel.from_synthetic(spec.TINY, mode="int8", max_batch=4, max_ctx=512)
+    wav = synth.synth_pcm(70, 80000).astype(np.float32) / 32768.0
+    t = m.transcribe(wav[None], 16000, max_new_tokens=6)
+    assert isinstance(t, str) and len(t.split()) >= 1
+    info = m.get_model_info()
+    assert info["mode"] == "int8" and info["model_dtype"] == "torch.float16"
+    m.close()

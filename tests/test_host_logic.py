@@ -81,9 +81,9 @@ def test_library_refuses_without_gpu_or_bad_args():
     cd = engine.make_dims(spec.TINY)
     rc = lib.sonic_create(C.byref(cd), 0, 7, 4, 512, C.byref(h))       # bad mode
     assert rc != 0 and b"mode must be either" in lib.sonic_last_error(None)
-    rc = lib.sonic_create(C.byref(cd), 0, engine.MODE_INT8, 4, 512, C.byref(h))
-    assert rc == engine.SONIC_ERR_UNSUPPORTED
     if lib.sonic_device_count() == 0:
+        rc = lib.sonic_create(C.byref(cd), 0, engine.MODE_INT8, 4, 512, C.byref(h))   # int8 mode is built: it fails for the missing GPU only
+        assert rc == 2 and b"no HIP device" in lib.sonic_last_error(None)
         rc = lib.sonic_create(C.byref(cd), 0, 0, 4, 512, C.byref(h))
         assert rc != 0 and not h.value                                    # fails loudly, no CPU fallback
         with pytest.raises(RuntimeError):
@@ -94,10 +94,10 @@ def test_asrmodel_argument_errors():
     from sonicscribe_amd.asr import ASRModel
     with pytest.raises(ValueError):
         ASRModel("x", mode="fp8")
-    with pytest.raises(ImportError):
-        ASRModel("x", mode="int8")
     with pytest.raises(RuntimeError):
         ASRModel("x", device="cpu")
+    with pytest.raises(RuntimeError):
+        ASRModel("x", device="cpu", mode="int8")        # int8 mode exists (asr.py:148-210), but only on a GPU
 
 
 def test_checkpoint_name_mapping_and_config(tmp_path):
