@@ -171,7 +171,8 @@ def main():
     base = spec.FULL if a.dims == "full" else spec.TINY
     dims = replace(base, eos_ids=())       # random weights: never stop early, every row does the full 150 steps
     B = a.batch
-    eng = Engine(dims, local_rank, max_batch=B, max_ctx=512)
+    from sonicscribe_amd.engine import MODE_INT8, MODE_NATIVE
+    eng = Engine(dims, local_rank, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
     eng.load_synthetic(20260128)
     for kv in a.opt:
         k, v = kv.split("=")
@@ -230,7 +231,8 @@ def main():
         dec_ms = stage["decode_ms"] / a.steps / n_dec
         dec_gbs = (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         out = {
-            "metric": "20s-segments/sec/node + RTF, GLM-ASR-Nano bf16, batch=32, 1/2/4/8 MI355X",
+            "metric": "20s-segments/sec/node + RTF, GLM-ASR-Nano bf16, batch=32, 1/2/4/8 MI355X" if a.mode == "native" and B == BATCH else
+                      f"20s-segments/sec/node + RTF, GLM-ASR-Nano {a.mode}, batch={B} (BASELINE config {4 if a.mode == 'int8' else 2} variant)",
             "value": value, "unit": "20s-segments/sec", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8" if a.mode == "int8" else "bf16", "data": "synthetic",

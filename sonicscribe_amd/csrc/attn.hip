@@ -298,9 +298,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
             const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
             if (a.dq.sca) {
                 // int8 mode: int32 slabs of the quantised q/k/v projections -> fp16 module outputs (LLM.int8 dequant + outliers)
-                const int c4 = col & ~3;
-                const f32x4 d1 = deq4(a.dq, a.P, a.ksplit, a.mpad, b, c4, N), d2 = deq4(a.dq, a.P, a.ksplit, a.mpad, b, c4 + HALF, N);
-                x1 = d1[col & 3]; x2 = d2[col & 3];
+                x1 = deq1(a.dq, a.P, a.ksplit, a.mpad, b, col, N); x2 = deq1(a.dq, a.P, a.ksplit, a.mpad, b, col + HALF, N);
             } else {
                 // all slab loads in flight at once (a rolled loop would serialise one L2 round trip per slab); fixed summation order
                 float v1[8], v2[8];

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
                     const int seg = m / a.seg_T, t = m - seg * a.seg_T;
                     O4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv);
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv, I8Row{}, 0.f);   // (16-bit kinds only)
                     *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
                 }
             }
@@ -146,14 +146,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         for (int q = 0; q < 2; ++q) {
             const int oc = ((n0 + wc * 64) >> 1) + q * 16 + fg * 4;
             const int ng = n0 + wc * 64 + q * 32 + fg * 4;           // gate columns ng .. ng+3, up columns ng+16 ..
+            f32x4 sbg = {0.f, 0.f, 0.f, 0.f}, sbu = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (KD::I8) if (ng + 19 < a.N) { sbg = *(const f32x4*)(a.q.scb + ng); sbu = *(const f32x4*)(a.q.scb + ng + 16); }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = m0 + wr * 64 + mi * 16 + fr;
                 if (m < a.M && (n0 + wc * 64 + q * 32) < a.N) {
+                    const I8Row rw = i8_row<KD>(a, m);
                     O4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float g = gemm_lin<KD>(a, acc[2 * q][mi][j], m, ng + j, 0.f), u = gemm_lin<KD>(a, acc[2 * q + 1][mi][j], m, ng + 16 + j, 0.f);
+                        const float g = gemm_lin<KD>(a, acc[2 * q][mi][j], m, ng + j, 0.f, rw, sbg[j]), u = gemm_lin<KD>(a, acc[2 * q + 1][mi][j], m, ng + 16 + j, 0.f, rw, sbu[j]);
                         o[j] = (OT)(rT<OT>(silu_f(g)) * u);
                     }
                     *(O4*)(C + (long)m * a.ldc + oc) = o;
@@ -171,14 +174,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
             const f32x4 b4 = *(const f32x4*)(a.bias + n);
             bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
         }
+        f32x4 sb = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (KD::I8) sb = *(const f32x4*)(a.q.scb + n);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wr * 64 + mi * 16 + fr;
             if (m >= a.M) continue;
+            const I8Row rw = i8_row<KD>(a, m);
             O4 o;
             float l[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) l[j] = gemm_lin<KD>(a, acc[ni][mi][j], m, n + j, bv[j]);
+            for (int j = 0; j < 4; ++j) l[j] = gemm_lin<KD>(a, acc[ni][mi][j], m, n + j, bv[j], rw, sb[j]);
             if (EPI == EPI_BIAS_RESID) {
                 const O4 rv = *(const O4*)(R + (long)m * a.ldr + n);
 #pragma unroll

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int m = m0 + wr * 128 + mb * 16 + fg * 4 + j; m = m < a.M ? m : a.M - 1;
-                    o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc, bv);
+                    o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc, bv, I8Row{}, 0.f);   // (V^T tiles exist for 16-bit kinds only)
                 }
                 *(O4*)(smem + nl * CLD + (wr * 128 + mb * 16 + fg * 4) * 2) = o;
             }
@@ -283,18 +283,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         }
         return;
     }
+    // int8: statistics of the 8 rows this lane touches, loaded once (not per element)
+    I8Row rws[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) { int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1; rws[mb] = i8_row<KD>(a, m); }
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ol = wc * 32 + q * 16 + fg * 4;           // column in the 128-wide activated tile
             int ng = n0 + wc * 64 + q * 32 + fg * 4; ng = ng + 19 < a.N ? ng : 0;   // gate columns ng .., up columns ng + 16 .. (clamped: unused beyond N)
+            f32x4 sbg = {0.f, 0.f, 0.f, 0.f}, sbu = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (KD::I8) { sbg = *(const f32x4*)(a.q.scb + ng); sbu = *(const f32x4*)(a.q.scb + ng + 16); }
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
                 O4 o;
                 int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g = gemm_lin<KD>(a, acc[2 * q][mb][j], m, ng + j, 0.f), u = gemm_lin<KD>(a, acc[2 * q + 1][mb][j], m, ng + 16 + j, 0.f);
+                    const float g = gemm_lin<KD>(a, acc[2 * q][mb][j], m, ng + j, 0.f, rws[mb], sbg[j]), u = gemm_lin<KD>(a, acc[2 * q + 1][mb][j], m, ng + 16 + j, 0.f, rws[mb], sbu[j]);
                     o[j] = (OT)(rT<OT>(silu_f(g)) * u);
                 }
                 *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + ol * 2) = o;
@@ -319,16 +325,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
         }
         const int nc = n + 3 < a.N ? n : 0;                  // (clamped: columns beyond N are computed and dropped)
+        f32x4 sb = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (KD::I8) sb = *(const f32x4*)(a.q.scb + nc);
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             O4 o;
             int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
             if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j]));
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]));
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j]);   // RESID: the linear's own output; R is added below
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);   // RESID: the linear's own output; R is added below
             }
             *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
         }

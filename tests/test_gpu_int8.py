@@ -59,7 +59,7 @@ def test_linear8bit_bias_exact(eng8, orc, M, N, K, group_rows):
     ref = _ref_linear(orc, X, W, b, group_rows)
     assert np.array_equal(got, ref), (np.abs(got - ref).max(), int((got != ref).sum()))
     dense = X.astype(np.float64) @ W.T.astype(np.float64) + b
-    assert np.abs(got - dense).max() < 0.25                                                   # and it is a sane approximation of the fp product
+    assert np.abs(got - dense).max() < 0.02 * np.sqrt(K)                                      # and it is a sane approximation of the fp product (int8 noise ~ sqrt(K))
 
 
 def test_linear8bit_int8_mfma_layout(eng8, orc):

@@ -111,10 +111,18 @@ def test_gemm256_path(eng, M, N, K, epi):
     if bad.any():      # footprint of the failure: which tiles, and what the wrong values look like
         rows = np.where(bad.any(1))[0]; cols = np.where(bad.any(0))[0]
         again = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
-        raise AssertionError(f"{int(bad.sum())} bad elements, max err {np.abs(got - ref).max():.3f}; rows {rows.min()}..{rows.max()} ({len(rows)}), cols {cols.min()}..{cols.max()} "
+        msg = (f"{int(bad.sum())} bad elements, max err {np.abs(got - ref).max():.3f}; rows {rows.min()}..{rows.max()} ({len(rows)}), cols {cols.min()}..{cols.max()} "
                              f"({len(cols)}); row tiles {sorted(set((rows // 256).tolist()))[:12]}, col tiles {sorted(set((cols // 256).tolist()))[:12]}; "
                              f"bad values are zero: {bool(np.all(got[bad] == 0))}; a rerun is clean: {bool(not (np.abs(again - ref) > ulp_tol(ref_mag if epi == 2 else ref, 4) + 1e-3).any())}; "
-                             f"rerun identical to first: {bool(np.array_equal(again, got))}")
+                             f"rerun identical to first: {bool(np.array_equal(again, got))}; first bad (row, col, got, ref): "
+                             f"{[(int(r), int(c), float(got[r, c]), float(ref[r, c])) for r, c in list(zip(*np.where(bad)))[:6]]}")
+        try:      # keep the footprint of this rare, box-dependent failure where the driver's log tail cannot lose it
+            os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "gemm256_flake.txt"), "a") as fh:
+                fh.write(f"M={M} N={N} K={K} epi={epi}: {msg}\n")
+        except OSError:
+            pass
+        raise AssertionError(msg)
     eng.set_option("gemm_force128", 1)
     try:
         old = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
