@@ -133,6 +133,72 @@ def cpu_reference_baseline(timeout_s: float = 170.0):
     return out
 
 
+def run_streaming(a):
+    """BASELINE config 5's call pattern against one process: S concurrent sessions, each speaking for 20 s (64 ms chunks), a partial
+    decode of the last 20 chunks (1.28 s, 15 tokens: audio_manager.py:106-114, transcription_manager.py:19-28) every second while
+    speaking (connection_manager.py:89-92, config.py:40) and a final decode of the whole 20 s segment (150 tokens,
+    transcription_manager.py:30-41) 1.28 s after the speech ends (two silent VAD windows).  Sessions start staggered over one second.
+    Events are issued in REAL TIME through ASRModel.submit() - the non-blocking entry the asyncio callers await - and every
+    request's latency is submit -> result.  One utterance cycle per session (about 22.5 s of wall clock)."""
+    from sonicscribe_amd import spec, synth
+    from sonicscribe_amd.asr import ASRModel
+    base = spec.FULL if a.dims == "full" else spec.TINY
+    dims = replace(base, eos_ids=())
+    S = a.sessions
+    dev = "cuda:*" if a.gpus > 1 else "cuda:0"
+    model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512)
+    n_rep = len(model.models)
+    speech = SEG_SECONDS * 16000
+    pcm = [synth.synth_pcm(i, speech).astype(np.float32) / np.float32(32768.0) for i in range(S)]
+    # warm-up: graphs of the batch sizes the run will see, both step classes
+    for n in (1, 2, min(S, a.batch)):
+        [f.result() for f in [model.submit(pcm[i % S][None, :20480], 16000, 15) for i in range(n)]]
+        [f.result() for f in [model.submit(pcm[i % S][None], 16000, MAX_NEW) for i in range(n)]]
+    events = []
+    for s_ in range(S):
+        off = s_ / S
+        for k in range(1, SEG_SECONDS + 1):
+            events.append((off + k, s_, "partial", k))
+        events.append((off + SEG_SECONDS + 1.28, s_, "final", 0))
+    events.sort()
+    lat = {"partial": [], "final": []}
+    pending = []
+    t0 = time.perf_counter()
+    for t_ev, s_, kind, k in events:
+        now = time.perf_counter() - t0
+        if t_ev > now:
+            time.sleep(t_ev - now)
+        if kind == "partial":
+            end = min(speech, k * 16000)
+            audio = pcm[s_][None, max(0, end - 20480):end]
+            mn = 15
+        else:
+            audio, mn = pcm[s_][None], MAX_NEW
+        ts = time.perf_counter()
+        fut = model.submit(audio, 16000, mn, session=f"client-{s_}")
+        fut.add_done_callback(lambda f, ts=ts, kind=kind: lat[kind].append(time.perf_counter() - ts))
+        pending.append(fut)
+    for f in pending:
+        f.result()
+    wall = time.perf_counter() - t0
+    batches = [r.batches for r in model._dispatcher.replicas]
+    model.close()
+
+    def pct(v, q):
+        return float(np.percentile(np.asarray(v) * 1e3, q)) if v else None
+    out = {
+        "metric": f"streaming: {S} concurrent sessions on {n_rep} MI355X (64 ms chunks, 1 s partials of 1.28 s / 15 tokens, 20 s finals / {MAX_NEW} tokens), {a.mode}",
+        "value": len(lat["final"]) / wall, "unit": "finals/sec (real-time schedule)", "n_gpus": n_rep, "higher_is_better": True, "data": "synthetic",
+        "dtype": "int8" if a.mode == "int8" else "bf16", "sessions": S, "wall_s": wall,
+        "partial_latency_ms": {"p50": pct(lat["partial"], 50), "p99": pct(lat["partial"], 99), "max": pct(lat["partial"], 100), "n": len(lat["partial"])},
+        "final_latency_ms": {"p50": pct(lat["final"], 50), "p99": pct(lat["final"], 99), "max": pct(lat["final"], 100), "n": len(lat["final"])},
+        "device_batches_per_replica": batches,
+        "config": {"workload": "BASELINE config 5 call pattern, one process, requests through ASRModel.submit() (dispatch.Dispatcher: no linger, "
+                               "step-class buckets, session -> replica)", "sessions": S, "replicas": n_rep},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +210,8 @@ def main():
     ap.add_argument("--mode", default="native", choices=["native", "int8"], help="native = bf16 (BASELINE config 2); int8 = the repo's quantised option (config 4, use --batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="engine tuning knob for experiments (sonic_set_option)")
+    ap.add_argument("--streaming", action="store_true", help="BASELINE config 5: real-time session simulation (partial / final latency), one process")
+    ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-timed", type=int, default=3, help=argparse.SUPPRESS)
@@ -151,6 +219,9 @@ def main():
     a = ap.parse_args()
     if a.cpu_baseline_worker:
         _cpu_reference_worker(a.cpu_threads, a.cpu_timed, a.cpu_budget)
+        return
+    if a.streaming:
+        run_streaming(a)
         return
 
     rank = int(os.environ.get("RANK", "0"))

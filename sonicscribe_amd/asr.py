@@ -9,19 +9,24 @@ import this class instead of ``asr.ASRModel``.  What changed un
   * asr.py:407-422  HF model.generate            -> HIP encoder / prefill / hipGraph greedy loop
   * asr.py:425-429  batch_decode                 -> unchanged (tokenizer stays in Python)
 
-Concurrent callers (3 executor threads + the event loop, main.py:429-430, transcription_manager.py:58)
-are coalesced into one device batch by ``_Coalescer`` instead of serialising on the model.
+Concurrent callers (3 executor threads + the event loop, main.py:429-430, transcription_manager.py:58) are
+batched per device by ``dispatch.Dispatcher`` instead of serialising on the model; with ``device="cuda:*"`` one engine
+replica runs on every visible MI355X inside this one process (the reference is a single process, main.py:1001).
+``submit()`` / ``transcribe_async()`` return without blocking the caller, so the WebSocket event loop can keep all
+sessions' decodes in flight (INTEGRATION.md shows the change in transcription_manager.py).
 """
 from __future__ import annotations
 
-import threading
+import asyncio
 import time
+from concurrent.futures import Future
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Sequence, Union
 
 import numpy as np
 
 from . import frontend
+from .dispatch import Dispatcher
 from .engine import Engine, MODE_INT8, MODE_NATIVE, SonicError, device_count
 from .spec import FULL, ModelDims
 
@@ -66,93 +71,6 @@ class HFPrompt:
         return self.processor.batch_decode([list(map(int, ids))], skip_special_tokens=True)[0]
 
 
-# --------------------------------------------------------------------------------------- coalescer
-class _Request:
-    __slots__ = ("windows", "prompt", "max_new", "event", "ids", "error")
-
-    def __init__(self, windows, prompt, max_new):
-        self.windows, self.prompt, self.max_new = windows, prompt, max_new
-        self.event = threading.Event()
-        self.ids = None
-        self.error: Optional[BaseException] = None
-
-
-class _Coalescer:
-    """Gathers transcribe() calls from any number of threads into device batches."""
-
-    def __init__(self, engine: Engine, linger_s: float = 0.002):
-        self.engine, self.linger_s = engine, linger_s
-        self.q: List[_Request] = []
-        self.cv = threading.Condition()
-        self.stop = False
-        self.thread = threading.Thread(target=self._loop, name="sonic-coalescer", daemon=True)
-        self.thread.start()
-
-    def submit(self, req: _Request) -> _Request:
-        with self.cv:
-            if self.stop:
-                raise RuntimeError("ASR engine is closed")
-            self.q.append(req)
-            self.cv.notify()
-        req.event.wait()
-        if req.error is not None:
-            raise req.error
-        return req
-
-    def close(self):
-        with self.cv:
-            self.stop = True
-            self.cv.notify_all()
-        self.thread.join(timeout=5)
-
-    def _take(self) -> List[_Request]:
-        with self.cv:
-            while not self.q and not self.stop:
-                self.cv.wait()
-            if self.stop and not self.q:
-                return []
-            if len(self.q) < self.engine.max_batch:
-                self.cv.wait(self.linger_s)  # let concurrent callers join this batch
-            batch, used = [], 0
-            while self.q and used + len(self.q[0].windows) <= self.engine.max_batch:
-                r = self.q.pop(0)
-                batch.append(r)
-                used += len(r.windows)
-            if not batch and self.q:   # a single request larger than a batch
-                r = self.q.pop(0)
-                r.error = ValueError(f"audio spans {len(r.windows)} windows, engine max_batch is {self.engine.max_batch}")
-                r.event.set()
-            return batch
-
-    def _loop(self):
-        while True:
-            batch = self._take()
-            if not batch:
-                if self.stop:
-                    return
-                continue
-            try:
-                segs, req_win = [], [0]
-                for r in batch:
-                    segs.extend(r.windows)
-                    req_win.append(len(segs))
-                ids, _ = self.engine.transcribe_batch(segs, [r.prompt for r in batch], [r.max_new for r in batch], req_win=req_win)
-                for r, i in zip(batch, ids):
-                    r.ids = i
-            except BaseException as ex:  # per-request validation errors must not poison the neighbours
-                if len(batch) == 1:
-                    batch[0].error = ex
-                else:
-                    for r in batch:
-                        try:
-                            ids, _ = self.engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
-                            r.ids = ids[0]
-                        except BaseException as ex2:
-                            r.error = ex2
-            for r in batch:
-                r.event.set()
-
-
 # --------------------------------------------------------------------------------------- façade
 class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
@@ -164,10 +82,14 @@ class ASRModel:
         dev = str(device)
         if dev.startswith("cpu"):
             raise RuntimeError("sonicscribe_amd runs on MI355X only: DEVICE=cpu has no HIP path (no CPU fallback by design)")
-        self.device_index = int(dev.split(":")[1]) if ":" in dev else 0
-        if device_count() <= self.device_index:
-            raise RuntimeError(f"HIP device {self.device_index} not available")
-        self.device = f"cuda:{self.device_index}"
+        n_dev = device_count()
+        # "cuda" / "cuda:1" = one replica (the reference's surface); "cuda:*" = every visible GPU; "cuda:0,2,3" = those
+        spec_ = dev.split(":", 1)[1] if ":" in dev else "0"
+        self.device_indices = list(range(n_dev)) if spec_ in ("*", "all") else [int(x) for x in spec_.split(",") if x != ""]
+        if not self.device_indices or max(self.device_indices) >= n_dev:
+            raise RuntimeError(f"HIP device {spec_} not available ({n_dev} visible)")
+        self.device_index = self.device_indices[0]
+        self.device = f"cuda:{self.device_index}" if len(self.device_indices) == 1 else "cuda:" + ",".join(map(str, self.device_indices))
         self.mode = mode
         self.model_dtype = "bfloat16" if mode == "native" else "float16"                     # asr.py:61
         emode = MODE_NATIVE if mode == "native" else MODE_INT8
@@ -175,16 +97,21 @@ class ASRModel:
         self.target_sr = 16000
         self.is_glm_asr = True
         self.processor = None
+        self.models: List[Engine] = []
         if _synthetic_seed is not None:
             self.dims = _dims or FULL
-            self.model = Engine(self.dims, self.device_index, emode, max_batch, max_ctx)
-            self.model.load_synthetic(_synthetic_seed)
+            for di in self.device_indices:
+                eng = Engine(self.dims, di, emode, max_batch, max_ctx)
+                eng.load_synthetic(_synthetic_seed)
+                self.models.append(eng)
             self.prompt = SyntheticPrompt(self.dims)
         else:
             from . import weights
             self.dims = weights.load_dims(str(self.checkpoint_dir))
-            self.model = Engine(self.dims, self.device_index, emode, max_batch, max_ctx)
-            weights.load_checkpoint(self.model, str(self.checkpoint_dir))
+            for di in self.device_indices:
+                eng = Engine(self.dims, di, emode, max_batch, max_ctx)
+                weights.load_checkpoint(eng, str(self.checkpoint_dir))
+                self.models.append(eng)
             try:
                 from transformers import AutoProcessor
                 self.processor = AutoProcessor.from_pretrained(str(self.checkpoint_dir))
@@ -197,9 +124,10 @@ class ASRModel:
                 if not _allow_synthetic_prompt:
                     raise RuntimeError(f"could not load the processor / tokenizer from {self.checkpoint_dir}: {ex}") from ex
                 self.prompt = SyntheticPrompt(self.dims)
-        self._coalescer = _Coalescer(self.model)
+        self.model = self.models[0]                  # main.py:84-86 checks and deletes `.model`
+        self._dispatcher = Dispatcher(self.models)
         print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
-              f"{self.model.weight_bytes() / 2**20:.0f} MiB weights)")
+              f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s))")
 
     @classmethod
     def from_synthetic(cls, dims: ModelDims = FULL, seed: int = 20260128, device: str = "cuda", mode: str = "native", **kw) -> "ASRModel":
@@ -223,17 +151,38 @@ class ASRModel:
         n_audio, _ = frontend.request_audio_tokens(len(pcm), self.dims)
         return pcm, [pcm[s:e] for s, e in wins], n_audio
 
+    def submit(self, audio_tensor, sampling_rate: int = 16000, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None,
+               session: Optional[str] = None) -> "Future[str]":
+        """Non-blocking form of transcribe(): queues the request on a replica and returns a Future of the transcript.  `session`
+        (e.g. the WebSocket client id) keeps a session's decodes on one GPU."""
+        if not hasattr(self, "model"):
+            raise RuntimeError("ASR model has been released")
+        pcm, windows, n_audio = self._prepare(audio_tensor, sampling_rate)
+        prompt = self.prompt.build(frontend.build_instruction(hotwords), n_audio)
+        inner = self._dispatcher.submit(windows, prompt, int(max_new_tokens), session=session)
+        out: "Future[str]" = Future()
+
+        def done(f):
+            try:
+                out.set_result(self.prompt.decode(f.result()).strip())
+            except BaseException as ex:
+                out.set_exception(ex)
+        inner.add_done_callback(done)
+        return out
+
+    async def transcribe_async(self, audio_tensor, sampling_rate: int = 16000, max_new_tokens: int = 128,
+                               hotwords: Optional[List[str]] = None, session: Optional[str] = None) -> str:
+        """Awaitable transcribe() for the asyncio callers (connection_manager.py:127-245): the event loop is not blocked while the
+        device works, so all sessions' partial and final decodes can be in flight (and batched) together."""
+        return await asyncio.wrap_future(self.submit(audio_tensor, sampling_rate, max_new_tokens, hotwords, session))
+
     def transcribe(self, audio_tensor, sampling_rate: int = 16000, max_new_tokens: int = 128,
                    hotwords: Optional[List[str]] = None, return_debug_info: bool = False) -> Union[str, Dict[str, Any]]:
         if not hasattr(self, "model"):
             raise RuntimeError("ASR model has been released")
         t0 = time.time()
         try:
-            pcm, windows, n_audio = self._prepare(audio_tensor, sampling_rate)
-            instruction = frontend.build_instruction(hotwords)
-            prompt = self.prompt.build(instruction, n_audio)
-            req = self._coalescer.submit(_Request(windows, prompt, int(max_new_tokens)))
-            transcript = self.prompt.decode(req.ids).strip()
+            transcript = self.submit(audio_tensor, sampling_rate, max_new_tokens, hotwords).result()
             elapsed = time.time() - t0
             if return_debug_info:
                 n = audio_tensor.shape[-1] if hasattr(audio_tensor, "shape") else len(audio_tensor)
@@ -260,20 +209,24 @@ class ASRModel:
             segs.extend(wins)
             req_win.append(len(segs))
             prompts.append(self.prompt.build(instruction, n_audio))
-        ids, _ = self.model.transcribe_batch(segs, prompts, mn, req_win=req_win)
+        if len(self.models) == 1:
+            ids, _ = self.model.transcribe_batch(segs, prompts, mn, req_win=req_win)
+        else:            # independent segments: spread over the replicas (least-loaded placement), results in input order
+            futs = [self._dispatcher.submit(segs[req_win[i]:req_win[i + 1]], prompts[i], mn[i]) for i in range(len(audios))]
+            ids = [f.result() for f in futs]
         return [self.prompt.decode(i).strip() for i in ids]
 
     def get_model_info(self) -> Dict[str, Any]:
         return {"mode": self.mode, "device": str(self.device), "model_dtype": "torch." + self.model_dtype, "target_sampling_rate": self.target_sr,
                 "checkpoint_dir": str(self.checkpoint_dir), "is_glm_asr": self.is_glm_asr, "engine": "sonicscribe_amd/gfx950",
-                "gpu_name": "AMD Instinct MI355X", "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0}
+                "gpu_name": "AMD Instinct MI355X", "replicas": len(self.__dict__.get("models", [])), "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0}
 
     def close(self):
-        c = self.__dict__.pop("_coalescer", None)
+        c = self.__dict__.pop("_dispatcher", None)
         if c is not None:
             c.close()
-        m = self.__dict__.pop("model", None)
-        if m is not None:
+        self.__dict__.pop("model", None)
+        for m in self.__dict__.pop("models", []):
             m.close()
 
     def __delattr__(self, name):   # main.py:84-86 does `del asr_model.model`

@@ -1,0 +1,160 @@
+"""Request dispatcher in front of the HIP engine replicas (SURVEY.md §8e "in-process dispatcher", §8f1 "cross-session coalescer").
+
+The reference is ONE process with ONE model object (backend/main.py:1001 `workers: 1`, backend/models_manager.py:16-32) that is entered
+  * synchronously on the asyncio event-loop thread, once per partial / final decode of every WebSocket session
+    (backend/transcription_manager.py:43-65, called from backend/connection_manager.py:127-166, 169-245), and
+  * from up to three executor threads in file mode (backend/main.py:429-430, 616-624),
+so every decode of every session is serialised on one device.  Here one engine replica lives on every visible MI355X; each replica
+has a worker thread that drains its queue into device batches:
+
+  * no linger: a request that finds its replica idle starts at once; while a batch runs, arrivals queue up and form the next batch
+    by themselves (batching comes from load, never from waiting);
+  * buckets: a batch holds requests of one step class only (max_new_tokens <= 16 / <= 64 / <= 256 / more), so a 15-token partial
+    (transcription_manager.py:24) never rides a 150-step final (:37); within a class the oldest request goes first;
+  * placement: a request with a session key goes to replica hash(key) mod G (a session's partials and finals stay on one GPU), unless
+    that replica's backlog exceeds the least-loaded one's by more than a batch, then it is rebalanced; keyless requests (file mode:
+    independent segments) go to the least-loaded replica.  Segments are independent: no collective, no cross-replica state.
+
+Engines are duck-typed (`max_batch`, `transcribe_batch(segs, prompts, max_new, req_win=...)`) so the dispatcher is testable on CPU
+with stub engines; ctypes releases the GIL inside the real engine call, so G worker threads drive G GPUs concurrently.
+"""
+from __future__ import annotations
+
+import threading
+import time
+import zlib
+from concurrent.futures import Future
+from typing import Any, List, Optional, Sequence
+
+STEP_CLASSES = (16, 64, 256)      # upper bounds of max_new_tokens per bucket; anything larger shares the last bucket
+
+
+def step_class(max_new: int) -> int:
+    for i, ub in enumerate(STEP_CLASSES):
+        if max_new <= ub:
+            return i
+    return len(STEP_CLASSES)
+
+
+class Request:
+    __slots__ = ("windows", "prompt", "max_new", "future", "t_submit", "cls")
+
+    def __init__(self, windows: Sequence[Any], prompt: Sequence[int], max_new: int):
+        self.windows, self.prompt, self.max_new = list(windows), prompt, int(max_new)
+        self.future: Future = Future()
+        self.t_submit = time.perf_counter()
+        self.cls = step_class(self.max_new)
+
+
+class _Replica:
+    def __init__(self, engine, index: int):
+        self.engine, self.index = engine, index
+        self.q: List[Request] = []
+        self.cv = threading.Condition()
+        self.stop = False
+        self.busy_windows = 0            # windows of the batch on the device right now
+        self.batches = 0
+        self.thread = threading.Thread(target=self._loop, name=f"sonic-replica-{index}", daemon=True)
+        self.thread.start()
+
+    def load(self) -> int:
+        with self.cv:
+            return self.busy_windows + sum(len(r.windows) for r in self.q)
+
+    def put(self, req: Request):
+        with self.cv:
+            if self.stop:
+                raise RuntimeError("ASR engine is closed")
+            self.q.append(req)
+            self.cv.notify()
+
+    def _take(self) -> List[Request]:
+        with self.cv:
+            while not self.q and not self.stop:
+                self.cv.wait()
+            if not self.q:
+                return []
+            cap = self.engine.max_batch
+            head = self.q[0]
+            if len(head.windows) > cap:          # a single request larger than a device batch
+                self.q.pop(0)
+                head.future.set_exception(ValueError(f"audio spans {len(head.windows)} windows, engine max_batch is {cap}"))
+                return []
+            batch, used, rest = [], 0, []
+            for r in self.q:                     # oldest first; same step class as the head; whatever fits
+                if r.cls == head.cls and used + len(r.windows) <= cap:
+                    batch.append(r); used += len(r.windows)
+                else:
+                    rest.append(r)
+            self.q = rest
+            self.busy_windows = used
+            return batch
+
+    def _run(self, batch: List[Request]):
+        segs, req_win = [], [0]
+        for r in batch:
+            segs.extend(r.windows)
+            req_win.append(len(segs))
+        try:
+            ids, _ = self.engine.transcribe_batch(segs, [r.prompt for r in batch], [r.max_new for r in batch], req_win=req_win)
+            for r, i in zip(batch, ids):
+                r.future.set_result(i)
+        except BaseException as ex:              # a per-request validation error must not poison its neighbours: retry one by one
+            if len(batch) == 1:
+                batch[0].future.set_exception(ex)
+                return
+            for r in batch:
+                try:
+                    ids, _ = self.engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
+                    r.future.set_result(ids[0])
+                except BaseException as ex2:
+                    r.future.set_exception(ex2)
+
+    def _loop(self):
+        while True:
+            batch = self._take()
+            if batch:
+                self._run(batch)
+                self.batches += 1
+                with self.cv:
+                    self.busy_windows = 0
+            elif self.stop and not self.q:
+                return
+
+    def close(self):
+        with self.cv:
+            self.stop = True
+            self.cv.notify_all()
+        self.thread.join(timeout=30)
+        for r in self.q:
+            if not r.future.done():
+                r.future.set_exception(RuntimeError("ASR engine is closed"))
+
+
+class Dispatcher:
+    def __init__(self, engines: Sequence[Any]):
+        if not engines:
+            raise ValueError("at least one engine")
+        self.replicas = [_Replica(e, i) for i, e in enumerate(engines)]
+
+    def __len__(self):
+        return len(self.replicas)
+
+    def pick(self, session: Optional[str]) -> _Replica:
+        loads = [r.load() for r in self.replicas]
+        least = min(range(len(loads)), key=loads.__getitem__)
+        if session is None:
+            return self.replicas[least]
+        home = zlib.crc32(str(session).encode()) % len(self.replicas)      # (stable across processes, unlike hash())
+        if loads[home] - loads[least] > self.replicas[home].engine.max_batch:
+            return self.replicas[least]                                     # rebalance: the home replica is more than a batch behind
+        return self.replicas[home]
+
+    def submit(self, windows, prompt, max_new: int, session: Optional[str] = None) -> Future:
+        req = Request(windows, prompt, max_new)
+        self.pick(session).put(req)
+        return req.future
+
+    def close(self):
+        for r in self.replicas:
+            r.close()
