@@ -297,3 +297,27 @@ def test_two_engines_in_one_process():
     rb, _ = b.transcribe_batch([seg], [pb], [6])
     assert np.array_equal(rb[0], rb0[0])
     a.close(); b.close()
+
+
+def test_multi_replica_dispatch_and_async_entry():
+    """Two engine replicas in ONE process behind the dispatcher (the in-process multi-GPU form; on a one-GPU box both replicas sit on
+    device 0 via device="cuda:0,0"), fed through submit() / transcribe_async() the way the WebSocket callers would: results equal the
+    single-replica results, both replicas work, partials and finals do not share device batches."""
+    import asyncio
+    from sonicscribe_amd.asr import ASRModel
+    one = ASRModel.from_synthetic(spec.TINY, device="cuda:0", max_batch=4, max_ctx=512)
+    two = ASRModel.from_synthetic(spec.TINY, device="cuda:0,0", max_batch=4, max_ctx=512)
+    assert len(two.models) == 2 and two.get_model_info()["replicas"] == 2
+    wavs = [synth.synth_pcm(200 + i, 16000 * (2 + i % 3)).astype(np.float32) / 32768.0 for i in range(12)]
+    want_p = [one.transcribe(w[None, -20480:], 16000, max_new_tokens=15) for w in wavs]
+    want_f = [one.transcribe(w[None], 16000, max_new_tokens=40) for w in wavs]
+
+    async def run():
+        part = [two.transcribe_async(w[None, -20480:], 16000, 15, session=f"c{i}") for i, w in enumerate(wavs)]
+        fin = [two.transcribe_async(w[None], 16000, 40, session=f"c{i}") for i, w in enumerate(wavs)]
+        return await asyncio.gather(*part), await asyncio.gather(*fin)
+    got_p, got_f = asyncio.run(run())
+    assert list(got_p) == want_p and list(got_f) == want_f
+    assert all(r.batches > 0 for r in two._dispatcher.replicas)
+    assert two.transcribe_batch(wavs[:4], max_new_tokens=[8] * 4) == one.transcribe_batch(wavs[:4], max_new_tokens=[8] * 4)
+    one.close(); two.close()
