@@ -123,7 +123,11 @@ struct GemmArgs {
     bf16_t* Vt; int n_split; int seg_T; int vt_ld; long vt_seg_stride;  // Vt[seg][n - n_split][t], row stride vt_ld
     int dt;                          // DT_BF16 / DT_F16: element type of A, W (16-bit GEMM) and of C, R, Vt
     GemmI8 q;                        // q.sca != NULL: int8 GEMM, outputs fp16
+    // fused encoder RoPE (256x256 kernel, heads of 64 columns, rotary dim 32: modeling_glmasr.py:153-168): columns < rope_ncols are
+    // q / k heads whose first 32 dims are rotated in the epilogue, row m sits at position m % rope_T; table [rope_T][32] = cos | sin
+    const float* rope_cs; int rope_T, rope_ncols;
 };
+bool gemm256_eligible(const GemmArgs& a, int epi);
 
 // Operand kinds of the MFMA GEMM kernels: element, 16-byte fragment, accumulator, output element type
 struct KBF16 {

@@ -93,7 +93,7 @@ struct sonic_engine {
 
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
-    int opt_no_graph = 0, opt_gemm_timing = 0;
+    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0;
 
     // timing
     hipEvent_t ev[5]{};
@@ -628,9 +628,11 @@ static void gemm(sonic_engine* e, int epi, const bf16_t* A, long lda, const bf16
 struct QGroup { const int* gmap; int gdiv; int G; };
 // One nn.Linear of the model on X [M][K] (row stride ldx).  Native mode: the 16-bit GEMM.  int8 mode and a swapped module (q.cb):
 // Linear8bitLt = activation quantisation (3 streaming passes) + int8 MFMA GEMM whose epilogue dequantises and adds the outlier columns.
-static void qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
-                    int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp) {
-    if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return; }
+// rope_cs (optional): fuse the encoder's partial RoPE on columns < rope_ncols into the epilogue; returns whether it was fused (only the
+// 256x256 kernel does it), else the caller runs the separate RoPE pass.
+static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
+                    int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp, const float* rope_cs = nullptr, int rope_T = 0, int rope_ncols = 0) {
+    if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return false; }
     QuantActArgs qa{};
     qa.X = X; qa.ld = ldx; qa.M = M; qa.K = K; qa.gmap = grp.gmap; qa.gdiv = grp.gdiv; qa.G = grp.G; qa.flags = e->q_flags;
     qa.q = e->qa; qa.sca = e->q_sca; qa.oc_cnt = e->q_oc_cnt; qa.oc_list = e->q_oc_list; qa.oc_ld = e->q_kmax;
@@ -639,7 +641,10 @@ static void qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const b
     a.A = (const bf16_t*)e->qa; a.lda = K; a.W = (const bf16_t*)q.cb; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = DT_F16;
     a.q.sca = e->q_sca; a.q.scb = q.scb; a.q.x16 = X; a.q.ldx16 = ldx; a.q.oc_cnt = e->q_oc_cnt; a.q.oc_list = e->q_oc_list; a.q.oc_ld = e->q_kmax;
     a.q.row_group = grp.gmap; a.q.group_div = grp.gdiv;
+    const bool fuse = false && rope_cs && !g_opts.gemm_force128 && gemm256_eligible(a, epi);   // int8 kind: the fused form spills (gemm256.hip), RoPE stays its own pass
+    if (fuse) { a.rope_cs = rope_cs; a.rope_T = rope_T; a.rope_ncols = rope_ncols; }
     launch_gemm(a, epi, e->st);
+    return fuse;
 }
 
 static int run_mel(sonic_engine* e, int W, bool want_f32) {
@@ -685,9 +690,11 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
             // Linear8bitLt q / k / v share their input, hence one quantisation and one fused int8 GEMM; Q | K | V land row-major
             // ([M][3C]) and V is transposed by its own pass (the fused V^T epilogue plus the dequantisation spills registers)
             mark(0);
-            qlinear(e, EPI_BIAS, e->ln, C, nullptr, L.qqkv, L.bqkv, e->qkv_rm, 3L * C, M, 3 * C, C, nullptr, 0, grp);
+            const bool can_fuse = e->hd_e == 64 && d.enc_rotary_dim == 32 && !e->opt_no_fused_rope;
+            const bool roped = qlinear(e, EPI_BIAS, e->ln, C, nullptr, L.qqkv, L.bqkv, e->qkv_rm, 3L * C, M, 3 * C, C, nullptr, 0, grp,
+                                       can_fuse ? e->enc_cs : nullptr, T, 2 * C);
             mark(1);
-            launch_rope_enc(e->qkv_rm, 3L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
+            if (!roped) launch_rope_enc(e->qkv_rm, 3L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
             launch_transpose_v(e->qkv_rm, 3L * C, 2 * C, e->vt, W, T, C, e->Tp, (long)C * e->Tp, e->st);
             f.Q = e->qkv_rm; f.q_ld = 3L * C; f.K = e->qkv_rm + C; f.k_ld = 3L * C;
             f.q_seq_stride = (long)T * 3 * C; f.k_seq_stride = (long)T * 3 * C;
@@ -695,10 +702,13 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
             GemmArgs a{};
             a.A = e->ln; a.lda = C; a.W = L.wqkv; a.bias = L.bqkv; a.C = e->qk; a.ldc = 2L * C; a.M = M; a.N = 3 * C; a.K = C; a.batch = 1; a.dt = dt;
             a.Vt = e->vt; a.n_split = 2 * C; a.seg_T = T; a.vt_ld = e->Tp; a.vt_seg_stride = (long)C * e->Tp;
+            // partial RoPE of q / k in the GEMM's epilogue (the rotation pairs are in one lane's accumulators): no separate HBM pass
+            const bool roped = e->hd_e == 64 && d.enc_rotary_dim == 32 && !e->opt_no_fused_rope && !g_opts.gemm_force128 && gemm256_eligible(a, EPI_QKV_VT);
+            if (roped) { a.rope_cs = e->enc_cs; a.rope_T = T; a.rope_ncols = 2 * C; }
             mark(0);
             launch_gemm(a, EPI_QKV_VT, e->st);
             mark(1);
-            launch_rope_enc(e->qk, 2L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
+            if (!roped) launch_rope_enc(e->qk, 2L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
             f.Q = e->qk; f.q_ld = 2L * C; f.K = e->qk + C; f.k_ld = 2L * C;
             f.q_seq_stride = (long)T * 2 * C; f.k_seq_stride = (long)T * 2 * C;
         }
@@ -1427,6 +1437,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
+    if (!strcmp(key, "no_fused_rope")) { e->opt_no_fused_rope = value; return SONIC_OK; }  // encoder RoPE as its own pass (A/B against the fused epilogue)
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
 }
 

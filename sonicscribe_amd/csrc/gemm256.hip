@@ -316,6 +316,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         }
         return;
     }
+    // fused partial RoPE (encoder q / k heads): a head is this wave's 64 columns; dims [0,16) are accumulator block 0 and their
+    // rotation partners [16,32) block 1 of the same lane, so the rotate-half pair never leaves the registers
+    // (compiled into the 16-bit QKV epilogue only: on top of the int8 dequantisation it makes the kernel spill inside its K loop)
+    const bool rope = !KD::I8 && EPI == EPI_QKV_VT && a.rope_cs && (n0 + wc * 64) < a.rope_ncols;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int nl = wc * 64 + nb * 16 + fg * 4, n = n0 + nl;
@@ -327,10 +331,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int nc = n + 3 < a.N ? n : 0;                  // (clamped: columns beyond N are computed and dropped)
         f32x4 sb = {0.f, 0.f, 0.f, 0.f};
         if constexpr (KD::I8) sb = *(const f32x4*)(a.q.scb + nc);
+        if (rope && nb == 1) continue;                       // written together with block 0
+        float bv1[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sb1 = {0.f, 0.f, 0.f, 0.f};
+        if (rope && nb == 0) {
+            if (a.bias) { const f32x4 b4 = *(const f32x4*)(a.bias + nc + 16); bv1[0] = b4[0]; bv1[1] = b4[1]; bv1[2] = b4[2]; bv1[3] = b4[3]; }
+            if constexpr (KD::I8) sb1 = *(const f32x4*)(a.q.scb + nc + 16);
+        }
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             O4 o;
             int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
+            if (rope && nb == 0) {
+                const float* cs = a.rope_cs + (long)(m % a.rope_T) * 32 + fg * 4;
+                const f32x4 c4 = *(const f32x4*)cs, s4 = *(const f32x4*)(cs + 16);
+                O4 o2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x1 = gemm_lin<KD>(a, acc[0][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);
+                    const float x2 = gemm_lin<KD>(a, acc[1][mb][j], m, nc + 16 + j, bv1[j], rws[mb], sb1[j]);
+                    o[j] = (OT)(rT<OT>(x1 * c4[j]) + rT<OT>(-x2 * s4[j]));
+                    o2[j] = (OT)(rT<OT>(x2 * c4[j]) + rT<OT>(x1 * s4[j]));
+                }
+                *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
+                *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + (nl + 16) * 2) = o2;
+                continue;
+            }
             if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]));

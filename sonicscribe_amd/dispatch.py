@@ -114,8 +114,8 @@ class _Replica:
         while True:
             batch = self._take()
             if batch:
+                self.batches += 1                # (counted before the futures complete: a waiter may read it right after its result)
                 self._run(batch)
-                self.batches += 1
                 with self.cv:
                     self.busy_windows = 0
             elif self.stop and not self.q:
