@@ -324,7 +324,8 @@ def main():
         }
         try:
             with open(os.path.join(ROOT, "profiles", "round2_pmc_decode.json")) as f:
-                out["roofline"]["traffic_from_profile"] = json.load(f)
+                pm = json.load(f)
+            out["roofline"]["traffic_from_profile"] = {k: pm[k] for k in ("hbm_bytes_per_token_step", "fetch_bytes_x2", "write_bytes", "note", "source") if k in pm}
         except Exception:
             pass
         # the other rooflines SURVEY.md 8d names:
