@@ -43,6 +43,7 @@ struct sonic_engine {
     std::mutex mu;
     std::string err;
     std::vector<void*> allocs;
+    std::vector<std::pair<void*, size_t>> uc_allocs;     // uncached blocks: returned to the process-wide pool, never to hipFree
     int64_t weight_bytes = 0;
     bool finalized = false;
 
@@ -128,12 +129,17 @@ static hipError_t h2d(sonic_engine* e, void* dst, const void* src, size_t bytes)
     return hipStreamSynchronize(e->st);
 }
 
+// zero fill by a kernel on the engine stream (hipMemsetAsync on a non-blocking stream: see TmpBuf::get)
+static void zero_fill(sonic_engine* e, void* q, size_t bytes) {
+    size_t left = bytes / 4; int* w = (int*)q;
+    while (left > 0) { const int c = left > (1u << 30) ? (1 << 30) : (int)left; launch_fill_i32(w, 0, c, e->st); w += c; left -= c; }
+}
 template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
     void* q = nullptr;
-    const size_t bytes = (n ? n : 1) * sizeof(Tt);
+    const size_t bytes = ((n ? n : 1) * sizeof(Tt) + 3) / 4 * 4;
     HIPC(e, hipMalloc(&q, bytes));
     e->allocs.push_back(q);
-    if (zero) HIPC(e, hipMemsetAsync(q, 0, bytes, e->st));
+    if (zero) zero_fill(e, q, bytes);
     *p = (Tt*)q;
     return SONIC_OK;
 }
@@ -142,12 +148,29 @@ template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool
 // weight copies and the KV cache.  Nothing of theirs then sits in (or has to be written back from) an XCD's L2 at a kernel boundary,
 // and the L2 keeps the X images the blocks of a kernel share.  Measured on the 149-step decode of the bench: 208.1 -> 204.8 ms with
 // the activation buffers alone, a further -1.8 ms with the KV cache and -0.6 ms with the tiled weights.  Falls back to hipMalloc.
+//
+// Uncached blocks are NEVER handed back to hipFree: sonic_destroy parks them in a process-wide pool and later engines reuse them (exact
+// size, same device).  Round 2 found that memory recycled between uncached and ordinary allocations comes back with stale data at
+// cache-line granularity: with engines and test buffers created and destroyed in one process, ordinary buffers that reused formerly
+// uncached pages read back wrong rows (test_gemm256_path: 3 of 5 full-suite runs failed, 0 of 6 with uncached allocations disabled).
+// A production process creates its engines once, so it never recycled; the pool makes the test processes safe as well.
+static std::mutex g_uc_mu;
+static std::multimap<std::pair<int, size_t>, void*> g_uc_pool;
+static void* uc_take(int dev, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_uc_mu);
+    auto it = g_uc_pool.find({dev, bytes});
+    if (it == g_uc_pool.end()) return nullptr;
+    void* p = it->second; g_uc_pool.erase(it); return p;
+}
+static void uc_give(int dev, size_t bytes, void* p) { std::lock_guard<std::mutex> lk(g_uc_mu); g_uc_pool.insert({{dev, bytes}, p}); }
 template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
-    void* q = nullptr;
-    const size_t bytes = (n ? n : 1) * sizeof(Tt);
-    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return dalloc(e, p, n, zero); }
-    e->allocs.push_back(q);
-    if (zero) HIPC(e, hipMemsetAsync(q, 0, bytes, e->st));
+    const size_t bytes = ((n ? n : 1) * sizeof(Tt) + 3) / 4 * 4;
+    void* q = getenv("SONIC_NO_UC") ? nullptr : uc_take(e->device, bytes);
+    if (!q) {
+        if (getenv("SONIC_NO_UC") || hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return dalloc(e, p, n, zero); }
+    }
+    e->uc_allocs.push_back({q, bytes});
+    if (zero) zero_fill(e, q, bytes);
     *p = (Tt*)q;
     return SONIC_OK;
 }
@@ -408,6 +431,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->st) (void)hipStreamSynchronize(e->st);
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : e->allocs) (void)hipFree(p);
+    for (auto& u : e->uc_allocs) uc_give(e->device, u.second, u.first);
     if (e->dump) (void)hipFree(e->dump);
     if (e->force_d) (void)hipFree(e->force_d);
     if (e->taps) (void)hipFree(e->taps);
@@ -1217,11 +1241,16 @@ struct TmpBuf {
     hipStream_t st;
     explicit TmpBuf(hipStream_t s) : st(s) {}
     ~TmpBuf() { for (void* p : v) (void)hipFree(p); }
-    // zero-fill on the ENGINE stream: a null-stream hipMemset is not ordered against a non-blocking stream's kernels
+    // Zero-fill with a KERNEL on the engine stream.  hipMemsetAsync on this non-blocking stream was seen not to be reliably ordered
+    // against its neighbours (a stale log-mel maximum survived one in round 1); here a late zero fill would wipe a buffer that a
+    // conversion kernel or a GEMM has already written - the signature of the intermittent test_gemm256_path failures (gross errors on
+    // a few tiles, clean on an immediate rerun, never in the engine's own long-lived buffers).
     template <typename Tt> Tt* get(size_t n) {
         void* p = nullptr;
-        if (hipMalloc(&p, (n ? n : 1) * sizeof(Tt)) != hipSuccess) return nullptr;
-        (void)hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(Tt), st);
+        const size_t bytes = (((n ? n : 1) * sizeof(Tt)) + 3) / 4 * 4;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        size_t left = bytes / 4; int* q = (int*)p;
+        while (left > 0) { const int c = left > (1u << 30) ? (1 << 30) : (int)left; launch_fill_i32(q, 0, c, st); q += c; left -= c; }
         (void)hipStreamSynchronize(st);
         v.push_back(p);
         return (Tt*)p;
