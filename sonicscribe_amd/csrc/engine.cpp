@@ -865,7 +865,7 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
     const QuantOut q_att{e->att_q, e->QD, e->sca_att, e->oc_att, e->ol_att, e->QD};
     const QuantOut q_act{e->act_q, FF, e->sca_act, e->oc_act, e->ol_act, FF};
     auto deq = [&](const QuantOut& q, const QW& w, int K, const bf16_t* x16) {
-        DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
+        DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.cbt = w.cbt; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
         dq.row_group = nullptr; dq.group_div = 1;
         return dq;
     };

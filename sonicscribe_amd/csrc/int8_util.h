@@ -8,6 +8,13 @@
 #define MM_DEQUANT_CONST 6.200012e-05f          // 1 / (127 * 127), bitsandbytes csrc/kernels.cu
 #define INT8_DEQ_W 7.874015718698502e-3f        // 1 / 127, int8_vectorwise_dequant
 
+// int8 weight W[n][k] out of the row-major matrix or, when present, the fragment-tiled copy (element (n, k) at
+// ((n/16)*(K/64) + k/64)*1024 + (((k%64)/16)*16 + n%16)*16 + k%16, gemm.hip tile_weights_i8_kernel)
+__device__ __forceinline__ float deq_w(const DeqInfo& q, int n, int k) {
+    if (q.cbt) return (float)q.cbt[((long)(n >> 4) * (q.K >> 6) + (k >> 6)) * 1024 + ((((k & 63) >> 4) * 16) + (n & 15)) * 16 + (k & 15)];
+    return (float)q.cb[(long)n * q.K + k];
+}
+
 // four consecutive output columns [col, col+4) of row `row`: int32 slab sum -> dequant -> (+ outlier columns), all as fp16 values.
 // Every load (slabs, statistics, outlier count) is issued before the first use: a rolled slab loop costs one L2 round trip per slab.
 __device__ __forceinline__ f32x4 deq4(const DeqInfo& q, const float* P, int ks, int mpad, int row, int col, int N) {
@@ -33,7 +40,7 @@ __device__ __forceinline__ f32x4 deq4(const DeqInfo& q, const float* P, int ks, 
             const float xv = (float)xr[k];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float wdq = rT<f16_t>(__fmul_rn(__fmul_rn((float)q.cb[(long)(col + j) * q.K + k], sb[j]), INT8_DEQ_W));
+                const float wdq = rT<f16_t>(__fmul_rn(__fmul_rn(deq_w(q, col + j, k), sb[j]), INT8_DEQ_W));
                 a2[j] = __fadd_rn(a2[j], __fmul_rn(xv, wdq));      // (no FMA contraction: the oracle rounds product and sum separately)
             }
         }
@@ -61,7 +68,7 @@ __device__ __forceinline__ float deq1(const DeqInfo& q, const float* P, int ks, 
         float a2 = 0.f;
         for (int i = 0; i < n; ++i) {
             const int k = q.oc_list[(long)g * q.oc_ld + i];
-            a2 = __fadd_rn(a2, __fmul_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn((float)q.cb[(long)col * q.K + k], sb), INT8_DEQ_W))));
+            a2 = __fadd_rn(a2, __fmul_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn(deq_w(q, col, k), sb), INT8_DEQ_W))));
         }
         v = rT<f16_t>(__fadd_rn(v, a2));
     }

@@ -10,6 +10,8 @@ struct DeqInfo {
     const float* sca;                 // [M] row absmax of the GEMM's quantised input; NULL = plain mode (slabs hold fp32 partial sums)
     const float* scb;                 // [N] row absmax of the weights
     const int8_t* cb; int K;          // [N][K] row-major int8 weights
+    const int8_t* cbt;                // optional fragment-tiled copy (launch_tile_weights_i8): a column gather W[:, k] touches one 64-byte
+                                      // span per 16 rows there instead of one cache line per row
     const bf16_t* x16; long ldx16;    // the GEMM's unquantised input (fp16 storage)
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
     const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div

@@ -114,7 +114,7 @@ def test_int8_transcribe_vs_oracle(eng8, orc):
     n_new = 8
     rng = np.random.default_rng(5)
     force = rng.integers(2, 900, (2, n_new)).astype(np.int32)
-    tol = 0.08
+    tol = 0.1        # measured 0.073: a 1-ulp fp16 difference on an activation can move an int8 code by one (1/127 of the row's range)
     worst = 0.0
     for forced in (None, force):
         eng8.set_forced_ids(forced)
