@@ -140,7 +140,8 @@ int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int it
  * "pe", "dx", "dqkv", "dq", "datt", "dact", "enc_x"); tests / diagnostics only */
 int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
 /* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
- * "no_graph" (eager decode loop), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*) */
+ * "no_graph" (eager decode loop), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
+ * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table) */
 int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus

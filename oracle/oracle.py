@@ -123,6 +123,13 @@ def synth_fill(seed: int, name: str, n: int, scale: float, offset: float, bf16) 
 MODE_FP32, MODE_BF16, MODE_FP16, MODE_INT8 = 0, 1, 2, 3
 
 
+def gelu(x: np.ndarray, bf16: bool = True) -> np.ndarray:
+    """erf GELU in fp32 (the op order of torch GELU(approximate="none")), rounded to bf16 when asked."""
+    y = np.array(x, np.float32, order="C")
+    lib().oracle_gelu(_p(y), y.size, int(bf16))
+    return y
+
+
 def quantize_rows(w: np.ndarray):
     """Int8Params.cuda(): row-wise absmax int8 of a [N][K] fp16-valued matrix -> (CB int8 [N][K], SCB fp32 [N])."""
     w = np.ascontiguousarray(w, np.float32)

@@ -126,7 +126,14 @@ struct GemmArgs {
     // fused encoder RoPE (256x256 kernel, heads of 64 columns, rotary dim 32: modeling_glmasr.py:153-168): columns < rope_ncols are
     // q / k heads whose first 32 dims are rotated in the epilogue, row m sits at position m % rope_T; table [rope_T][32] = cos | sin
     const float* rope_cs; int rope_T, rope_ncols;
+    // bf16 GELU by table (256x256 kernel, EPI_BIAS_GELU): GELU of a bf16 value is a function of 65536 inputs; the compact table
+    // (GELU_LUT_N bf16 bit patterns: both signs x exponents 2^-14 .. 2^3 x 128 mantissas) is copied to LDS and indexed by the bits
+    const unsigned short* gelu_lut;
 };
+#define GELU_LUT_E0 113                     // biased exponent of 2^-14
+#define GELU_LUT_NE 18                      // exponents 2^-14 .. 2^3  (|x| < 16)
+#define GELU_LUT_HALF (GELU_LUT_NE * 128)
+#define GELU_LUT_N (2 * GELU_LUT_HALF)      // 4608 entries = 9216 bytes
 bool gemm256_eligible(const GemmArgs& a, int epi);
 
 // Operand kinds of the MFMA GEMM kernels: element, 16-byte fragment, accumulator, output element type

@@ -52,6 +52,7 @@ struct sonic_engine {
     bf16_t *conv1w = nullptr, *conv2w = nullptr; float *conv1b = nullptr, *conv2b = nullptr;
     std::vector<EncLayerW> enc;
     float *enc_nw = nullptr, *enc_nb = nullptr;
+    unsigned short* gelu_lut = nullptr;     // bf16 GELU table (gemm256 EPI_BIAS_GELU epilogue), native mode
     bf16_t *pj1w = nullptr, *pj2w = nullptr; float *pj1b = nullptr, *pj2b = nullptr; QW qpj1, qpj2;
     // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
     int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
@@ -94,7 +95,7 @@ struct sonic_engine {
 
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
-    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0;
+    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
 
     // timing
     hipEvent_t ev[5]{};
@@ -308,6 +309,21 @@ static int build_constants(sonic_engine* e) {
         HIPC(e, h2d(e, *out, t.data(), t.size() * 4));
         return SONIC_OK;
     };
+    if (!e->i8) {
+        // GELU of every bf16 value with |x| in [2^-14, 16), computed exactly as the reference op sequence does it in fp32
+        // (0.5 * x * (1 + erff(x / sqrt 2)), modeling_glmasr.py:299-300 / torch GELU(approximate="none")) and rounded to bf16 once
+        std::vector<unsigned short> lut(GELU_LUT_N);
+        for (int sgn = 0; sgn < 2; ++sgn)
+            for (int i = 0; i < GELU_LUT_HALF; ++i) {
+                const uint32_t bits = ((uint32_t)sgn << 31) | ((uint32_t)((GELU_LUT_E0 << 7) + i) << 16);
+                float x; memcpy(&x, &bits, 4);
+                const float y = bf16_round_host(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
+                uint32_t yb; memcpy(&yb, &y, 4);
+                lut[sgn * GELU_LUT_HALF + i] = (unsigned short)(yb >> 16);
+            }
+        TRY(dalloc(e, &e->gelu_lut, GELU_LUT_N));
+        HIPC(e, h2d(e, e->gelu_lut, lut.data(), GELU_LUT_N * 2));
+    }
     TRY(rope_table(e->T, d.enc_rotary_dim, d.enc_theta, &e->enc_cs));
     TRY(rope_table(e->max_ctx, d.dec_head_dim, d.dec_theta, &e->dec_cs));
     return SONIC_OK;
@@ -646,6 +662,7 @@ static void gemm(sonic_engine* e, int epi, const bf16_t* A, long lda, const bf16
                  int M, int N, int K, const bf16_t* R = nullptr, long ldr = 0) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = e->dt;
+    a.gelu_lut = e->opt_no_gelu_lut ? nullptr : e->gelu_lut;
     launch_gemm(a, epi, e->st);
 }
 // Rows -> reference-call groups for LLM.int8's outlier columns: group of row r = gmap ? gmap[r / gdiv] : r / gdiv, G groups
@@ -1467,6 +1484,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
     if (!strcmp(key, "no_fused_rope")) { e->opt_no_fused_rope = value; return SONIC_OK; }  // encoder RoPE as its own pass (A/B against the fused epilogue)
+    if (!strcmp(key, "no_gelu_lut")) { e->opt_no_gelu_lut = value; return SONIC_OK; }      // GELU by arithmetic instead of the LDS table (A/B)
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
 }
 

@@ -95,6 +95,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     };
 
+    // bf16 GELU table -> LDS behind the tile ring (9 KiB, one wave, issued first: older than every operand DMA, so the counted waits of
+    // the K loop cover it)
+    constexpr bool LUT = EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value;
+    if constexpr (LUT) {
+        if (wid == 0 && a.gelu_lut) {
+#pragma unroll
+            for (int i = 0; i < GELU_LUT_N * 2 / 1024; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)a.gelu_lut + i * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(smem + LDS256_BYTES + i * 1024), 16, 0, 0);
+        }
+    }
     Acc acc[4][8];   // [n-block][m-block]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -358,6 +369,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 continue;
             }
             if (EPI == EPI_BIAS_GELU) {
+                if constexpr (LUT) {
+                    if (a.gelu_lut) {
+                        const unsigned short* lut = (const unsigned short*)(smem + LDS256_BYTES);
+                        // branch-free: every lane reads the table at a clamped index (the four reads of a fragment in flight together),
+                        // the two out-of-table cases are selects afterwards
+                        float l[4]; unsigned t[4]; int idx[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            l[j] = gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);                  // a bf16 value
+                            const unsigned b = __float_as_uint(l[j]) >> 16;
+                            idx[j] = (int)(b & 0x7FFFu) - (GELU_LUT_E0 << 7);
+                            t[j] = lut[min((unsigned)idx[j], (unsigned)(GELU_LUT_HALF - 1)) + ((b >> 15) ? GELU_LUT_HALF : 0)];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(t[j]));          // (keeps the reads unconditional and batched)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // outside the table: |x| < 2^-14 -> 0.5 x (the erf term is below half a bf16 ulp); |x| >= 16 -> x or -0
+                            const float lo = 0.5f * l[j], hi = fmaxf(l[j], -0.0f);
+                            float y = __uint_as_float(t[j] << 16);
+                            y = idx[j] < 0 ? lo : y;
+                            y = idx[j] >= GELU_LUT_HALF ? hi : y;
+                            o[j] = (OT)y;
+                        }
+                        *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]));
             } else {
@@ -386,9 +425,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 
 
 template <typename KD, int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
-    ensure_dyn_lds((const void*)gemm256_kernel<KD, EPI, STG>, LDS256_BYTES);
+    constexpr int LDS = LDS256_BYTES + ((EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value) ? GELU_LUT_N * 2 : 0);
+    ensure_dyn_lds((const void*)gemm256_kernel<KD, EPI, STG>, LDS);
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
-    hipLaunchKernelGGL((gemm256_kernel<KD, EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS256_BYTES, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<KD, EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS, s, a);
 }
 template <int EPI> static void launch256(const GemmArgs& a, hipStream_t s) {
     if (a.q.sca) { if constexpr (EPI != EPI_QKV_VT) launch256v<KI8, EPI, true>(a, s); }

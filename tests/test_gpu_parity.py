@@ -39,6 +39,19 @@ def ulp_tol(ref, n_ulp=2.0):
     return n_ulp * np.maximum(np.abs(ref), 1e-2) * 2.0 ** -8
 
 
+def assert_bf16_close(got, ref, what, n_ulp_of_max=2.0, min_exact=0.4, max_mean=5e-3):
+    """Activation tensors of a bf16 layer stack: the HIP path and the oracle round at the same op boundaries, so most elements agree
+    BIT FOR BIT and the rest differ by isolated bf16 flips.  Bounds (measured with tools/measure_enc_err.py: 50-67 % of the elements
+    exact, max |diff| = 1-2 ulp of the tensor's largest magnitude, mean |diff| 1.4e-3 .. 3.6e-3):
+      * max |diff| <= n_ulp_of_max bf16 ulps of max |ref|;  * at least min_exact of the elements identical;  * mean |diff| <= max_mean."""
+    d = np.abs(got - ref)
+    top = float(np.abs(ref).max())
+    ulp_top = 2.0 ** (np.floor(np.log2(max(top, 2.0 ** -8))) - 7)
+    exact = float(np.mean(got == ref))
+    assert d.max() <= n_ulp_of_max * ulp_top and exact >= min_exact and d.mean() <= max_mean, \
+        (what, float(d.max()), n_ulp_of_max * ulp_top, exact, float(d.mean()))
+
+
 # ------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1500, 256, 384), (33, 132, 64)])
 def test_gemm_bias(eng, orc, M, N, K):
@@ -128,7 +141,41 @@ def test_gemm256_path(eng, M, N, K, epi):
         old = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
     finally:
         eng.set_option("gemm_force128", 0)
+    if epi == 1:      # the 128x128 kernel computes GELU by arithmetic (erfc form), the 256x256 one by table (reference op order):
+        eng.set_option("no_gelu_lut", 1)   # compare like with like here; table against arithmetic is test_gelu_table_bit_exact
+        try:
+            got = eng.test_gemm(A, W, b, epi=1)
+        finally:
+            eng.set_option("no_gelu_lut", 0)
     assert np.mean(old != got) < 0.02      # same math, different summation order: only isolated bf16 flips
+
+
+def test_gelu_table_bit_exact(eng, orc):
+    """The fc1 epilogue looks GELU up in an LDS table indexed by the bf16 bits of the pre-activation.  With operands whose products and
+    sums are exact in fp32 (small dyadic values) the pre-activation does not depend on the summation order, so the output must equal
+    the oracle's GELU bit for bit -- over the table range, below it (|x| < 2^-14 -> 0.5 x) and above it (|x| >= 16 -> x or -0)."""
+    rng = np.random.default_rng(5)
+    M, N, K = 512, 512, 256
+    A = rng.integers(-4, 5, (M, K)).astype(np.float32) / 4.0
+    W = rng.integers(-2, 3, (N, K)).astype(np.float32) / 8.0
+    b = np.zeros(N, np.float32)
+    b[:64] = 2.0 ** -16; b[64:128] = -2.0 ** -15                 # columns whose bias alone lands below the table on zero sums
+    W[:128, 8:] = 0.0                                            # (few terms: many exact zeros and tiny sums there)
+    W[128:192] *= 8.0                                            # columns that leave the table at the top (|x| >= 16)
+    l = bf((A.astype(np.float64) @ W.T.astype(np.float64) + b).astype(np.float32))
+    assert (np.abs(l) >= 16).any() and ((np.abs(l) < 2.0 ** -14) & (l != 0)).any() and (l == 0).any()
+    got = eng.test_gemm(A, W, b, epi=1)
+    ref = orc.gelu(l, bf16=True)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (int((got != ref).sum()), np.abs(got - ref).max())
+    eng.set_option("no_gelu_lut", 1)
+    try:
+        arith = eng.test_gemm(A, W, b, epi=1)
+    finally:
+        eng.set_option("no_gelu_lut", 0)
+    # the arithmetic epilogue uses the erfc form for x < 0 (no cancellation), the reference op order cancels in fp32 there: the two
+    # agree to an ulp except in that tail, where the values are < 2e-3 in magnitude
+    d = np.abs(arith - got)
+    assert np.all(d <= ulp_tol(got, 1) + 2e-4), d.max()
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 256), (32, 256, 256), (32, 1024, 512), (40, 512, 2048), (64, 128, 768), (33, 48, 1024), (32, 2048, 6144),
@@ -267,15 +314,11 @@ def test_encoder_vs_oracle_and_golden(eng, orc, golden_dir):
         r = om.transcribe(feats, int(mask.sum()), g[p + "prompt_ids"], 1, want=("enc_layers", "enc_out"))
         assert int(n_audio[0]) == int(g[p + "n_audio"])
         for li in range(d.enc_layers):
-            e = np.abs(layers[0, li] - r["enc_layers"][li])
-            assert e.max() < 0.25 and e.mean() < 6e-3, (li, e.max(), e.mean())
-        e = np.abs(emb[0, : n_audio[0]] - r["audio_embeds"][: n_audio[0]])
-        assert e.max() < 0.15 and e.mean() < 5e-3, (e.max(), e.mean())
-        # and against the reference fixtures themselves
-        e = np.abs(emb[0, : n_audio[0]] - g[p + "audio_embeds"])
-        assert e.max() < 0.15 and e.mean() < 5e-3, (e.max(), e.mean())
-        e = np.abs(enc_out[0][::31] - g[p + "enc_out_sub"])
-        assert e.max() < 0.25 and e.mean() < 6e-3
+            assert_bf16_close(layers[0, li], r["enc_layers"][li], f"encoder layer {li}")
+        assert_bf16_close(emb[0, : n_audio[0]], r["audio_embeds"][: n_audio[0]], "audio embeds", min_exact=0.2)
+        # and against the reference fixtures themselves (torch's own summation order: a little further than the oracle)
+        assert_bf16_close(emb[0, : n_audio[0]], g[p + "audio_embeds"], "audio embeds vs reference", n_ulp_of_max=3.0, min_exact=0.15)
+        assert_bf16_close(enc_out[0][::31], g[p + "enc_out_sub"], "encoder output vs reference", n_ulp_of_max=3.0, min_exact=0.3)
 
 
 def test_transcribe_vs_golden(eng, golden_dir):
@@ -466,10 +509,8 @@ def test_fullwidth_layer_vs_oracle(orc):
     for i in range(2):
         feats, mask = orc.logmel(segs[i])
         r = om.transcribe(feats, int(mask.sum()), prompt, n_new, want=("enc_layers", "enc_out"))
-        el = np.abs(layers[i, 0] - r["enc_layers"][0])
-        assert el.max() < 0.5 and el.mean() < 8e-3, (el.max(), el.mean())
-        ee = np.abs(emb[i, :n_audio] - r["audio_embeds"][:n_audio])
-        assert ee.max() < 0.25 and ee.mean() < 8e-3, (ee.max(), ee.mean())
+        assert_bf16_close(layers[i, 0], r["enc_layers"][0], "full-width encoder layer")
+        assert_bf16_close(emb[i, :n_audio], r["audio_embeds"][:n_audio], "full-width audio embeds", min_exact=0.2)
         for st in range(n_new):                                # step 0 = prefill; steps 1.. = decode kernels (fused o_proj/residual/RMSNorm/gate-up)
             if st and ids[i][st - 1] != r["new_ids"][st - 1]:
                 break                                          # histories diverged on a near-tie: later steps are not comparable
