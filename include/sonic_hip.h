@@ -139,6 +139,9 @@ int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int it
 /* debug read-back of an internal bf16 activation buffer as fp32 ("prefill_tap" with index = 0 (embeddings) .. dec_layers,
  * "pe", "dx", "dqkv", "dq", "datt", "dact", "enc_x"); tests / diagnostics only */
 int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
+/* diagnostics: in-kernel timestamps (100 MHz device wall clock) of the decode kernels of one decoder layer, recorded while the option
+ * "ktrace" = layer index is set: out[slot][block < 512][8 points], slots 0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down */
+int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n);
 /* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
  * "no_graph" (eager decode loop), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
  * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table) */

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     T* Vc = (T*)a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
     const int cm1 = a.ctx_max - 1;
 
+    KT(a, 0);
     V8 kf[4], vv[4], kfn[4], vvn[4];
     auto load = [&](int k0, V8 (&kd)[4], V8 (&vd)[4]) {
         const int kr = min(k0 + r, cm1);
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     } else {
         n = min(max(a.kv_len[b], 1), a.ctx_max);
     }
+    KT(a, 1);
     // q as the MFMA B operand: column r = head (zero beyond the group), k = head-dim
     V8 qf[4];
 #pragma unroll
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         for (int u = 0; u < 4; ++u) vv[u] = *(const V8*)&s_q[GMAX + 1][r * 8];
         step(0, kf, vv, 1);
     }
+    KT(a, 2);
     // merge: per wave the row sums over the 4 key quarters, the outputs over the 4 V-owner groups; then the 8 waves
     lsum = rows_sum(lsum);
     if (g == 0 && r < 4) s_l[wid][r] = lsum;
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
             if (g == 0) s_acc[wid][h][r * 8 + i] = v;
         }
     __syncthreads();
+    KT(a, 3);
     for (int idx = tid; idx < G * HD; idx += 512) {
         const int h = idx / HD, e = idx % HD;
         float M = -1e30f;
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][h] - M); num += f * s_acc[w][h][e]; den += f * s_l[w][h]; }
         ((T*)a.O)[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = (T)(num / den);
     }
+    KT(a, 4);
 }
 
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {

@@ -160,7 +160,10 @@ struct SkinnyArgs {
     int M, N, K, ksplit;
     int dt;                          // DT_BF16 / DT_F16
     int i8;                          // int8 operands (Linear8bitLt decode step): int32 slabs, dequantised by the consumer
+    long long* kt;                   // diagnostics: per-block timestamps [block][8] (100 MHz wall clock), null in production
 };
+// in-kernel timeline point `slot` of this block (thread 0 only); a null pointer costs one scalar compare
+#define KT(a, slot) do { if ((a).kt && threadIdx.x == 0) (a).kt[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
 
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);

@@ -30,6 +30,7 @@ struct DevTensor {
 // int8 mode (asr.py:169-210): a quantised Linear keeps row-wise int8 weights + row absmax instead of its 16-bit matrix
 struct QW { int8_t* cb = nullptr; float* scb = nullptr; int8_t* cbt = nullptr; };   // cbt: fragment-tiled copy for the decode step
 struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; QW qqkv, qo, q1, q2; };
+#define KT_SLOT_BLOCKS 512                                   // "ktrace" diagnostics: blocks recorded per kernel slot, 8 timestamps each
 struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          // row-major (prefill GEMM)
                    bf16_t *wqkv_t, *wo_t, *wgu_t, *wgu_t8, *wdown_t;                    // fragment-tiled copies (decode skinny GEMM)
                    QW qqkv, qo, qgu, qdown; };
@@ -96,6 +97,7 @@ struct sonic_engine {
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
+    long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
 
     // timing
     hipEvent_t ev[5]{};
@@ -459,6 +461,15 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     delete e;
 }
 
+extern "C" int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n) {
+    if (!e || !out) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->kt) return fail(e, SONIC_ERR_INVALID, "ktrace is off");
+    const int64_t have = (int64_t)8 * KT_SLOT_BLOCKS * 8;
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipMemcpy(out, e->kt, (size_t)(n < have ? n : have) * 8, hipMemcpyDeviceToHost));
+    return SONIC_OK;
+}
 extern "C" const char* sonic_last_error(sonic_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 extern "C" int64_t sonic_weight_bytes(sonic_engine* e) { return e ? e->weight_bytes : 0; }
 extern "C" int sonic_synchronize(sonic_engine* e) {
@@ -797,8 +808,9 @@ static int keep_rows(const sonic_dims& d, int n_valid_frames) {  // modeling_glm
 }
 static int frames_of(int n_samples) { return n_samples > 0 ? (n_samples + 159) / 160 : 0; }
 
-static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, float* P, int M, int N, int K, int* ks_out) {
-    SkinnyArgs a{};
+static long long* kt_slot(sonic_engine* e, int l, int slot) { return (e->kt && l == e->kt_layer) ? e->kt + (long)slot * KT_SLOT_BLOCKS * 8 : nullptr; }
+static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, float* P, int M, int N, int K, int* ks_out, long long* kt = nullptr) {
+    SkinnyArgs a{}; a.kt = kt;
     a.X = X; a.ldx = ldx; a.W = W; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit(N, K); a.dt = e->dt;
     if (ks_out) *ks_out = a.ksplit;
     launch_skinny(a, e->st);
@@ -837,8 +849,8 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
-        skinny(e, e->shn, D, L.wqkv_t, e->slab, R, e->qkvN, D, &ks);
-        DecodeAttnArgs da{};
+        skinny(e, e->shn, D, L.wqkv_t, e->slab, R, e->qkvN, D, &ks, kt_slot(e, l, 0));
+        DecodeAttnArgs da{}; da.kt = kt_slot(e, l, 1);
         da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = dt;     // RoPE + KV append fused into the attention kernel
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
@@ -848,9 +860,9 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         if (fuse_o) {
             // o_proj + residual add (+ row sum-of-squares partials) -> gate/up with RMSNorm applied while staging X + SwiGLU:
             // two kernels instead of o_proj, add+RMSNorm, gate/up, SwiGLU
-            SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1;
+            SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1; oa.kt = kt_slot(e, l, 2);
             launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
-            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
+            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.kt = kt_slot(e, l, 3);
             launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 16, L.ln2, d.dec_rms_eps, e->st);
         } else {
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
@@ -863,7 +875,7 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st, dt);
         }
         }
-        skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks);
+        skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks, kt_slot(e, l, 4));
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, dt);
     }
@@ -1484,6 +1496,12 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
     if (!strcmp(key, "no_fused_rope")) { e->opt_no_fused_rope = value; return SONIC_OK; }  // encoder RoPE as its own pass (A/B against the fused epilogue)
+    if (!strcmp(key, "ktrace")) {              // diagnostics: record in-kernel timestamps of decoder layer `value` (-1: off); sonic_debug_ktrace reads them
+        HIPC(e, hipSetDevice(e->device));
+        if (value >= 0 && !e->kt) { TRY(dalloc(e, &e->kt, (size_t)8 * KT_SLOT_BLOCKS * 8)); }
+        if (e->kt) zero_fill(e, e->kt, (size_t)8 * KT_SLOT_BLOCKS * 8 * 8);
+        e->kt_layer = value; drop_graphs(e); return SONIC_OK;
+    }
     if (!strcmp(key, "no_gelu_lut")) { e->opt_no_gelu_lut = value; return SONIC_OK; }      // GELU by arithmetic instead of the LDS table (A/B)
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);
 }

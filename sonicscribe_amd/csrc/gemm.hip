@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     const int wn = wid % WN, wk = wid / WN;
     const int n0 = blockIdx.x * (WN * 16) + wn * 16;
     const int kb = blockIdx.y * BKk;
+    KT(a, 0);
     // X slice first (small, out of L2): it has to be complete in LDS - for all waves - before the first MFMA
     {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
@@ -361,8 +362,10 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mb][e] = 0;
+    KT(a, 1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KSW) : "memory");      // this wave's X pieces are in LDS
     __builtin_amdgcn_s_barrier();                                    // (raw barrier: __syncthreads would add a vmcnt(0) fence)
+    KT(a, 2);
 #pragma unroll
     for (int u = 0; u < KSW; ++u) {
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[u]) : "n"(KSW - 1 - u) : "memory");
@@ -374,7 +377,9 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
             acc[mb] = KD::mfma(wf[u], xf, acc[mb]);
         }
     }
+    KT(a, 3);
     __syncthreads();
+    KT(a, 4);
     Acc* red = (Acc*)smem;   // [WK][WN][MB][64]
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) red[((wk * WN + wn) * MB + mb) * 64 + lane] = acc[mb];
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
             a.P[dst] = s;
         }
     }
+    KT(a, 5);
 }
 
 // skinny_gu_kernel: decode-step gate/up projection with SwiGLU fused (modeling_llama.py:163-176).
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
     static_assert(PW % RG == 0 || RG % PW == 0, "a wave's pieces must tile whole K blocks or sit inside one");
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
     constexpr int SSN = KS8 * 2;                                    // f32x4 of partials per lane: K/16 blocks, two lane halves
+    KT(a, 0);
     f32x4 ssv[SSN];
     f32x4 nw[NORM ? KBW * 2 : 1];
     if (NORM) {
@@ -459,6 +466,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 #define GU_WADDR(f) (wp + ((long)((f) / KS8) * (K >> 5) + (f) % KS8) * 512)
 #pragma unroll
     for (int f = 0; f < WPRE; ++f) wf[f] = __builtin_nontemporal_load((const bf16x8*)GU_WADDR(f));
+    KT(a, 1);
     if (NORM) {
         // Every lane rewrites exactly the 16 bytes its own DMA deposited, so only this wave's vmcnt orders it - no barrier.
         __builtin_amdgcn_sched_barrier(0);            // keep all loads above in flight (the scheduler would sink W below the rewrite)
@@ -505,8 +513,11 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
     for (int j = 0; j < TPB; ++j)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    KT(a, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KT(a, 3);
     __syncthreads();
+    KT(a, 4);
 #pragma unroll
     for (int u = 0; u < KS8; ++u) {
         const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
@@ -518,6 +529,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
             for (int j = 0; j < TPB; ++j) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xf, acc[j][mb], 0, 0, 0);
         }
     }
+    KT(a, 5);
     __syncthreads();
     f32x4* red = (f32x4*)smem;   // [wk 8][tile TPB][MB][64]
 #pragma unroll
@@ -538,6 +550,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         }
         if (m < a.M) act[(long)m * ff + blockIdx.x * NC + c] = f2bf(rbf(silu_f(rbf(gs))) * rbf(us));
     }
+    KT(a, 6);
 }
 
 // skinny_o_kernel: decode-step o_proj with the residual add fused (modeling_llama.py:306-309).  Like skinny_gu_kernel the block sees the
@@ -555,6 +568,7 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
     const int row0 = blockIdx.y * mpad, M = a.M - row0 < mpad ? a.M - row0 : mpad;
     const bf16_t* X = a.X + (long)row0 * a.ldx;
     x += (long)row0 * ldxres;
+    KT(a, 0);
     bf16x8 wf[KS8];
     {
         const bf16_t* wp = a.W + ((long)blockIdx.x * (K >> 5) + wk * KS8) * 512 + lane * 8;
@@ -576,14 +590,18 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
     const int em = (tid >> 4) & 15, ec = tid & 15;
     const bf16_t xres = x[(long)(em < M ? em : M - 1) * ldxres + blockIdx.x * 16 + ec];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    KT(a, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KT(a, 2);
     __syncthreads();
+    KT(a, 3);
 #pragma unroll
     for (int u = 0; u < KS8; ++u) {
         const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
         const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + r * 128 + (((half * 4 + g) ^ (r & 7)) << 4));
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc, 0, 0, 0);
     }
+    KT(a, 4);
     __syncthreads();
     f32x4* red = (f32x4*)smem;                       // [wk 8][64]
     float* sq = (float*)(smem + 8 * 1024);           // [16 rows][16 cols] squares of the updated residual
@@ -608,6 +626,7 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
         for (int c = 0; c < 16; ++c) t += sq[tid * 16 + c];
         SS[((long)(blockIdx.x >> 2) * 32 + row0 + tid) * 4 + (blockIdx.x & 3)] = t;      // [block / 4][32 rows][4], see skinny_gu_kernel
     }
+    KT(a, 5);
 }
 
 template <int MB, int KS8, int TPB, bool NORM> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {

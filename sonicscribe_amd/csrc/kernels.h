@@ -50,6 +50,7 @@ struct DecodeAttnArgs {
     float scale;
     int dt;
     DeqInfo dq;           // int8 mode: P holds int32 slabs of the quantised QKV projection
+    long long* kt;        // diagnostics: per-block timestamps (common.h KT)
 };
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s);
 

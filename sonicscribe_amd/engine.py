@@ -25,7 +25,7 @@ EXPORTS = [
     "sonic_device_count", "sonic_create", "sonic_destroy", "sonic_last_error", "sonic_load_tensor", "sonic_load_synthetic",
     "sonic_finalize_weights", "sonic_weight_bytes", "sonic_logmel", "sonic_encode", "sonic_transcribe_batch", "sonic_stage_pcm",
     "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
-    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_test_skinny_gu",
+    "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_debug_ktrace", "sonic_test_skinny_gu",
     "sonic_set_forced_ids", "sonic_test_greedy", "sonic_test_linear_int8",
 ]
 
@@ -106,6 +106,7 @@ def load_library():
     lib.sonic_bench_gemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.sonic_bench_skinny.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.sonic_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.sonic_debug_ktrace.argtypes = [vp, C.c_void_p, C.c_int64]
     lib.sonic_debug_read.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int64]
     lib.sonic_test_skinny_gu.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -330,6 +331,13 @@ def _set_option(self, key: str, value: int):
     self._check(self.lib.sonic_set_option(self.h, key.encode(), value))
 
 
+def _debug_ktrace(self) -> np.ndarray:
+    """[slot 8][block 512][point 8] device wall-clock ticks (10 ns) of the decode kernels of the layer set by option "ktrace"."""
+    out = np.zeros((8, 512, 8), np.int64)
+    self._check(self.lib.sonic_debug_ktrace(self.h, _p(out), out.size))
+    return out
+
+
 def _debug_read(self, name: str, shape, index: int = 0) -> np.ndarray:
     out = np.empty(shape, np.float32)
     self._check(self.lib.sonic_debug_read(self.h, name.encode(), index, _p(out), out.size))
@@ -380,6 +388,7 @@ Engine.set_forced_ids = _set_forced_ids
 Engine.test_greedy = _test_greedy
 Engine.test_skinny_gu = _test_skinny_gu
 Engine.debug_read = _debug_read
+Engine.debug_ktrace = _debug_ktrace
 Engine.bench_skinny = _bench_skinny
 Engine.set_option = _set_option
 
