@@ -149,7 +149,12 @@ def run_streaming(a):
     model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512)
     n_rep = len(model.models)
     speech = SEG_SECONDS * 16000
-    pcm = [synth.synth_pcm(i, speech).astype(np.float32) / np.float32(32768.0) for i in range(S)]
+    wire = [synth.synth_pcm(i, speech) for i in range(S)]                          # int16, as the WebSocket delivers it
+    pcm = [w.astype(np.float32) / np.float32(32768.0) for w in wire]
+    ring = a.ingest == "ring"
+    CH = 1024                                                                      # samples per 64 ms chunk (config.py:23-24)
+    n_chunks = speech // CH
+    streams = [model.open_stream(f"client-{i}") for i in range(S)] if ring else []
     # warm-up: graphs of the batch sizes the run will see, both step classes
     for n in (1, 2, min(S, a.batch)):
         [f.result() for f in [model.submit(pcm[i % S][None, :20480], 16000, 15) for i in range(n)]]
@@ -157,17 +162,35 @@ def run_streaming(a):
     events = []
     for s_ in range(S):
         off = s_ / S
+        if ring:                                                                    # every 64 ms chunk arrives at its own time
+            for j in range(n_chunks):
+                events.append((off + (j + 1) * CH / 16000.0, s_, "chunk", j))
         for k in range(1, SEG_SECONDS + 1):
-            events.append((off + k, s_, "partial", k))
+            events.append((off + k + 1e-4, s_, "partial", k))
         events.append((off + SEG_SECONDS + 1.28, s_, "final", 0))
     events.sort()
     lat = {"partial": [], "final": []}
     pending = []
+    append_s, n_app, late = 0.0, 0, 0.0
     t0 = time.perf_counter()
     for t_ev, s_, kind, k in events:
         now = time.perf_counter() - t0
         if t_ev > now:
             time.sleep(t_ev - now)
+        else:
+            late = max(late, now - t_ev)
+        if kind == "chunk":
+            ta = time.perf_counter()
+            streams[s_].add_audio_chunk(wire[s_][k * CH:(k + 1) * CH].tobytes())
+            append_s += time.perf_counter() - ta; n_app += 1
+            continue
+        if ring:                                                                    # decode a chunk range that is already on the device
+            last = streams[s_].next_chunk_id - 1
+            ts = time.perf_counter()
+            fut = streams[s_].submit_chunks(max(0, last - 19), last, 15) if kind == "partial" else streams[s_].submit_chunks(0, last, MAX_NEW)
+            fut.add_done_callback(lambda f, ts=ts, kind=kind: lat[kind].append(time.perf_counter() - ts))
+            pending.append(fut)
+            continue
         if kind == "partial":
             end = min(speech, k * 16000)
             audio = pcm[s_][None, max(0, end - 20480):end]
@@ -182,6 +205,8 @@ def run_streaming(a):
         f.result()
     wall = time.perf_counter() - t0
     batches = [r.batches for r in model._dispatcher.replicas]
+    for st in streams:
+        st.close()
     model.close()
 
     def pct(v, q):
@@ -193,8 +218,10 @@ def run_streaming(a):
         "partial_latency_ms": {"p50": pct(lat["partial"], 50), "p99": pct(lat["partial"], 99), "max": pct(lat["partial"], 100), "n": len(lat["partial"])},
         "final_latency_ms": {"p50": pct(lat["final"], 50), "p99": pct(lat["final"], 99), "max": pct(lat["final"], 100), "n": len(lat["final"])},
         "device_batches_per_replica": batches,
+        "ingest": {"kind": a.ingest, "appends": n_app, "mean_append_us": (append_s / n_app * 1e6) if n_app else None, "max_event_lateness_ms": late * 1e3},
         "config": {"workload": "BASELINE config 5 call pattern, one process, requests through ASRModel.submit() (dispatch.Dispatcher: no linger, "
-                               "step-class buckets, session -> replica)", "sessions": S, "replicas": n_rep},
+                               "step-class buckets, session -> replica)" + ("; every 64 ms wire chunk appended to the session's device ring as it "
+                               "arrives (AudioStream.add_audio_chunk), decodes name chunk ranges" if ring else ""), "sessions": S, "replicas": n_rep},
     }
     print(json.dumps(out), flush=True)
 
@@ -212,6 +239,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="engine tuning knob for experiments (sonic_set_option)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE config 5: real-time session simulation (partial / final latency), one process")
     ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
+    ap.add_argument("--ingest", default="host", choices=["host", "ring"], help="--streaming: decodes hand over host tensors (the reference's call) or name chunk "
+                    "ranges of per-session device rings fed chunk by chunk (SURVEY 8 f2)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-timed", type=int, default=3, help=argparse.SUPPRESS)

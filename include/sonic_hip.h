@@ -107,6 +107,31 @@ int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets,
 int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                      const int32_t* max_new, int want_step_logits);
 int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+/* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as
+ * 2048-byte chunks in a host dict (backend/audio_manager.py:21-33, fed from backend/main.py:813-842) and concatenates on the host for
+ * every partial / final decode (audio_manager.py:99-123).  A decode names sample ranges of rings instead of handing over host buffers;
+ * the reference's conversions between the wire and the feature extractor -- int16 -> float32 / 32768
+ * (backend/transcription_manager.py:45-54), peak normalisation over the request and the PCM_16 round trip (backend/asr.py:247-276) --
+ * run on the device, bit-identical with the host path.  Appends use the ring's own stream and lock: they do not wait for a batch that
+ * is decoding.  A ring belongs to the engine it was created on and must be destroyed before it. */
+typedef struct sonic_ring sonic_ring;
+int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, sonic_ring** out);
+void sonic_ring_destroy(sonic_ring* r);
+/* append n samples (any chunk size <= capacity); *first_index = absolute sample index of pcm[0].  Returns at once: the samples are
+ * copied to a pinned mirror and their H2D copy is queued; decodes that name them order behind it */
+int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, int64_t* first_index);
+int64_t sonic_ring_head(sonic_ring* r);     /* samples appended so far */
+/* sonic_transcribe_batch with every window either host samples (rings == NULL or rings[w] == NULL: int16 PCM already peak-normalised,
+ * host_off[W+1]; ring windows have empty host ranges) or samples [ring_start[w], ring_start[w] + ring_n[w]) of rings[w], which must
+ * still be inside the ring's last `capacity` samples.  The windows of one request (req_win) share one peak.  Without req_win R == W. */
+int sonic_transcribe_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
+                           const int64_t* ring_start, const int32_t* ring_n, int W, const int32_t* req_win, int R,
+                           const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new,
+                           int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+/* the staging half alone (then sonic_run_staged / sonic_fetch_tokens) */
+int sonic_stage_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
+                      const int64_t* ring_start, const int32_t* ring_n, int W, const int32_t* req_win, int R);
+
 /* Teacher forcing (parity tests; mirrors the oracle's force_ids): while set, token n of request r is ids[r * ld + n] instead of
  * the argmax -- logits are still computed and returned, EOS / budget rules apply to the forced token (HF:generation/utils.py:2925-2936
  * with next_tokens replaced).  ids == NULL clears.  Forced runs use the eager decode loop. */

@@ -71,6 +71,66 @@ class HFPrompt:
         return self.processor.batch_decode([list(map(int, ids))], skip_special_tokens=True)[0]
 
 
+class AudioStream:
+    """Device-resident counterpart of the reference's per-connection chunk store.
+
+    The reference keeps every 2048-byte WebSocket chunk in a host dict keyed by chunk id (backend/audio_manager.py:21-33, fed from
+    backend/main.py:813-842), and for every partial / final decode concatenates a chunk range on the host
+    (audio_manager.py:99-123), converts it to float (backend/transcription_manager.py:45-54) and hands the tensor to
+    ASRModel.transcribe.  Here a chunk goes straight into a ring in HBM on the session's GPU; a decode names a chunk range and the
+    int16 -> float -> peak-normalise -> PCM_16 steps run on the device (csrc/ingest.hip), bit-identical with the host path.
+    """
+
+    def __init__(self, model: "ASRModel", session: str, replica: int, buffer_seconds: float):
+        self.model, self.session, self.replica = model, session, replica
+        self.ring = model.models[replica].ring_create(int(buffer_seconds * model.target_sr))
+        self._chunks: Dict[int, tuple] = {}       # chunk id -> (first sample index, samples)
+        self.next_chunk_id = 0
+
+    def add_audio_chunk(self, audio_data: bytes) -> int:
+        """audio_manager.py:21-33: store one wire chunk, return its chunk id."""
+        first = self.ring.append(audio_data)
+        cid = self.next_chunk_id
+        self.next_chunk_id += 1
+        self._chunks[cid] = (first, len(audio_data) // 2)
+        floor = self.ring.head - self.ring.capacity           # chunks that have left the ring (audio_manager.py:35-59 drops them by age)
+        for old in [c for c, (f, _) in self._chunks.items() if f < floor]:
+            del self._chunks[old]
+        return cid
+
+    def submit_chunks(self, start_chunk_id: int, end_chunk_id: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> "Future[str]":
+        """Transcribe chunks start..end inclusive (audio_manager.py:76-79 get_chunks_by_range + :115-123 concatenation)."""
+        ids = [c for c in range(start_chunk_id, end_chunk_id + 1) if c in self._chunks]
+        if not ids:
+            raise ValueError(f"no audio left in the buffer for chunks {start_chunk_id}..{end_chunk_id}")
+        for a, b in zip(ids, ids[1:]):
+            if b != a + 1:
+                raise ValueError("chunk range is not contiguous in the buffer")
+        first = self._chunks[ids[0]][0]
+        n = sum(self._chunks[c][1] for c in ids)
+        m = self.model
+        windows = [self.ring.slice(first + s, e - s) for s, e in frontend.split_windows(n, m.dims)]
+        n_audio, _ = frontend.request_audio_tokens(n, m.dims)
+        prompt = m.prompt.build(frontend.build_instruction(hotwords), n_audio)
+        inner = m._dispatcher.submit(windows, prompt, int(max_new_tokens), replica=self.replica)
+        out: "Future[str]" = Future()
+
+        def done(f):
+            try:
+                out.set_result(m.prompt.decode(f.result()).strip())
+            except BaseException as ex:
+                out.set_exception(ex)
+        inner.add_done_callback(done)
+        return out
+
+    async def transcribe_chunks(self, start_chunk_id: int, end_chunk_id: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> str:
+        return await asyncio.wrap_future(self.submit_chunks(start_chunk_id, end_chunk_id, max_new_tokens, hotwords))
+
+    def close(self):
+        self.ring.close()
+        self._chunks.clear()
+
+
 # --------------------------------------------------------------------------------------- façade
 class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
@@ -169,6 +229,13 @@ class ASRModel:
                 out.set_exception(ex)
         inner.add_done_callback(done)
         return out
+
+    def open_stream(self, session: str, buffer_seconds: float = 30.0) -> AudioStream:
+        """A streaming session whose audio stays on the device (config.py:25 MAX_AUDIO_BUFFER_SECONDS = 30): chunks are appended to a
+        ring on the session's GPU, partial / final decodes name chunk ranges (AudioStream)."""
+        if not hasattr(self, "model"):
+            raise RuntimeError("ASR model has been released")
+        return AudioStream(self, session, self._dispatcher.home(session), buffer_seconds)
 
     async def transcribe_async(self, audio_tensor, sampling_rate: int = 16000, max_new_tokens: int = 128,
                                hotwords: Optional[List[str]] = None, session: Optional[str] = None) -> str:

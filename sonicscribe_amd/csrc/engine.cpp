@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -98,6 +99,7 @@ struct sonic_engine {
     LaunchOpts opts;
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
+    int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
 
     // timing
     hipEvent_t ev[5]{};
@@ -387,7 +389,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     const size_t Mp = (size_t)Bm * T + 128;
     int s;
 #define A(x) do { s = (x); if (s != SONIC_OK) return bail(s); } while (0)
-    A(dalloc(e, &e->pcm, (size_t)Bm * d.n_frames * 160)); A(dalloc(e, &e->n_samples_d, Bm));
+    A(dalloc(e, &e->pcm, (size_t)Bm * d.n_frames * 160)); A(dalloc(e, &e->n_samples_d, Bm)); A(dalloc(e, &e->ring_peak, Bm));
     A(dalloc(e, &e->logspec, (size_t)Bm * d.n_frames * d.n_mels)); A(dalloc(e, &e->segmax, Bm));
     A(dalloc(e, &e->feats_fm, (size_t)Bm * (d.n_frames + 2) * d.n_mels + 4096));
     A(dalloc(e, &e->h1, (size_t)Bm * (d.n_frames + 2) * C + 4096));
@@ -1126,6 +1128,148 @@ static int stage_pcm_locked(sonic_engine* e, const int16_t* pcm, const int64_t* 
     HIPC(e, hipStreamSynchronize(e->st));
     e->W = W;
     return SONIC_OK;
+}
+
+static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+// ------------------------------------------------------------------------------------------ device-resident ingest
+// A ring holds the raw wire PCM of one session in HBM (the reference keeps the chunks in a host dict, audio_manager.py:21-33, and
+// concatenates them on the host for every decode, :106-123).  Appends run on the ring's own stream under the ring's own lock, so the
+// event-loop thread that feeds 2048-byte chunks never waits for a batch that is decoding under the engine lock.
+struct sonic_ring {
+    sonic_engine* e = nullptr;
+    int16_t* buf = nullptr;
+    int16_t* host = nullptr;               // pinned mirror: an append is a host memcpy + an async H2D copy, the caller never waits for the
+                                           // device (a synchronous 2 KB copy queues behind whatever kernels occupy the GPU: 0.6-1.4 ms measured)
+    int64_t cap = 0, head = 0;             // capacity in samples; samples appended so far (absolute index of the next one)
+    std::mutex mu;
+    hipStream_t st = nullptr;
+    hipEvent_t read_ev = nullptr; bool read_pending = false;   // last staging kernel that read this ring (appends order behind it)
+    hipEvent_t app_ev = nullptr; bool app_pending = false;     // last append (staging kernels order behind it)
+};
+
+extern "C" int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, sonic_ring** out) {
+    if (!e || !out) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (capacity_samples < 1024 || capacity_samples > ((int64_t)1 << 31)) return fail(e, SONIC_ERR_INVALID, "ring capacity %lld out of range", (long long)capacity_samples);
+    sonic_ring* r = new sonic_ring();
+    r->e = e; r->cap = capacity_samples;
+    if (hipMalloc((void**)&r->buf, (size_t)capacity_samples * 2) != hipSuccess) { delete r; return fail(e, SONIC_ERR_OOM, "HIP out of memory (ring of %lld samples)", (long long)capacity_samples); }
+    if (hipHostMalloc((void**)&r->host, (size_t)capacity_samples * 2, hipHostMallocDefault) != hipSuccess) { (void)hipFree(r->buf); delete r; return fail(e, SONIC_ERR_OOM, "pinned host memory exhausted (ring mirror)"); }
+    if (hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->read_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->app_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(r->buf); (void)hipHostFree(r->host); if (r->st) (void)hipStreamDestroy(r->st); if (r->read_ev) (void)hipEventDestroy(r->read_ev);
+        delete r; return fail(e, SONIC_ERR_HIP, "ring stream / event creation failed");
+    }
+    zero_fill(e, r->buf, (size_t)capacity_samples * 2);
+    HIPC(e, hipStreamSynchronize(e->st));
+    *out = r;
+    return SONIC_OK;
+}
+extern "C" void sonic_ring_destroy(sonic_ring* r) {
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        (void)hipSetDevice(r->e->device);
+        (void)hipStreamSynchronize(r->st);
+        if (r->read_pending) (void)hipEventSynchronize(r->read_ev);
+        (void)hipFree(r->buf); (void)hipHostFree(r->host); (void)hipStreamDestroy(r->st); (void)hipEventDestroy(r->read_ev); (void)hipEventDestroy(r->app_ev);
+    }
+    delete r;
+}
+extern "C" int64_t sonic_ring_head(sonic_ring* r) {
+    if (!r) return -1;
+    std::lock_guard<std::mutex> lk(r->mu);
+    return r->head;
+}
+// append n samples; *first_index = absolute index of pcm[0].  Returns at once (the samples are copied to the pinned mirror, the caller may
+// reuse pcm); the H2D copy is queued on the ring's stream and every later staging kernel orders behind it.
+extern "C" int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, int64_t* first_index) {
+    if (!r || (!pcm && n > 0) || n < 0) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (n > r->cap) return SONIC_ERR_INVALID;
+    if (hipSetDevice(r->e->device) != hipSuccess) return SONIC_ERR_HIP;
+    if (r->read_pending) { (void)hipStreamWaitEvent(r->st, r->read_ev, 0); r->read_pending = false; }   // do not overwrite what a staging kernel still reads
+    const int64_t pos = r->head % r->cap, first = n < r->cap - pos ? n : r->cap - pos;
+    // (a mirror slot is rewritten one full capacity later -- 30 s of audio -- long after its copy has left)
+    hipError_t er = hipSuccess;
+    if (first > 0) { memcpy(r->host + pos, pcm, (size_t)first * 2); er = hipMemcpyAsync(r->buf + pos, r->host + pos, (size_t)first * 2, hipMemcpyHostToDevice, r->st); }
+    if (er == hipSuccess && n > first) { memcpy(r->host, pcm + first, (size_t)(n - first) * 2); er = hipMemcpyAsync(r->buf, r->host, (size_t)(n - first) * 2, hipMemcpyHostToDevice, r->st); }
+    if (er == hipSuccess && n > 0) { er = hipEventRecord(r->app_ev, r->st); r->app_pending = true; }
+    if (er != hipSuccess) return SONIC_ERR_HIP;
+    if (first_index) *first_index = r->head;
+    r->head += n;
+    return SONIC_OK;
+}
+
+// windows of a batch from host memory (rings == NULL or rings[w] == NULL: int16 PCM already normalised by the caller, as
+// sonic_stage_pcm) and / or from rings (raw wire PCM: a1 + a2 on the device, peak over the windows of one request)
+static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
+                              const int64_t* ring_start, const int32_t* ring_n, const int32_t* req_win, int R) {
+    const sonic_dims& d = e->d;
+    if (W < 1 || W > e->Bm || W > RING_MAX_WIN) return fail(e, SONIC_ERR_INVALID, "window count %d out of range 1..%d", W, e->Bm < RING_MAX_WIN ? e->Bm : RING_MAX_WIN);
+    if (req_win) { if (R < 1 || R > W || req_win[0] != 0 || req_win[R] != W) return fail(e, SONIC_ERR_INVALID, "req_win does not cover the %d windows", W); }
+    else if (R != W) return fail(e, SONIC_ERR_INVALID, "without req_win every window is its own request");
+    const long cap = (long)d.n_frames * 160;
+    RingStageArgs ra{};
+    int max_n = 0; bool any_ring = false;
+    std::vector<sonic_ring*> used;
+    for (int r = 0, w = 0; r < R; ++r) {
+        const int w1 = req_win ? req_win[r + 1] : r + 1;
+        if (w1 <= w) return fail(e, SONIC_ERR_INVALID, "request %d has no window", r);
+        for (; w < w1; ++w) {
+            ra.req_of[w] = r;
+            sonic_ring* rg = rings ? rings[w] : nullptr;
+            if (rg) {
+                if (rg->e != e) return fail(e, SONIC_ERR_INVALID, "window %d: ring belongs to another engine", w);
+                const int64_t n = ring_n[w], st = ring_start[w];
+                std::lock_guard<std::mutex> lk(rg->mu);
+                if (n < 0 || n > cap || st < 0 || st + n > rg->head || st < rg->head - rg->cap)
+                    return fail(e, SONIC_ERR_INVALID, "window %d: samples [%lld, %lld) are not in the ring (holds [%lld, %lld))", w, (long long)st, (long long)(st + n),
+                                (long long)(rg->head > rg->cap ? rg->head - rg->cap : 0), (long long)rg->head);
+                if (rg->app_pending) (void)hipStreamWaitEvent(e->st, rg->app_ev, 0);      // the appended samples are (or will be) in HBM first
+                ra.ring[w] = rg->buf; ra.ring_cap[w] = rg->cap; ra.start[w] = st % rg->cap; ra.n[w] = (int)n;
+                e->n_samples_h[w] = (int)n;
+                if ((int)n > max_n) max_n = (int)n;
+                any_ring = true;
+                if (std::find(used.begin(), used.end(), rg) == used.end()) used.push_back(rg);
+            } else {
+                if (!host_pcm || !host_off) return fail(e, SONIC_ERR_INVALID, "window %d: neither ring nor host samples", w);
+                const int64_t n = host_off[w + 1] - host_off[w];
+                if (n < 0 || n > cap) return fail(e, SONIC_ERR_INVALID, "window %d has %lld samples (max %ld)", w, (long long)n, cap);
+                e->n_samples_h[w] = (int)n;
+                if (n > 0) HIPC(e, hipMemcpyAsync(e->pcm + (size_t)w * cap, host_pcm + host_off[w], (size_t)n * 2, hipMemcpyHostToDevice, e->st));
+            }
+        }
+    }
+    if (any_ring) {
+        ra.peak = e->ring_peak; ra.pcm = e->pcm; ra.win_cap = cap;
+        launch_fill_i32(e->ring_peak, 0, e->Bm, e->st);
+        launch_ring_stage(ra, W, max_n, e->st);
+        for (sonic_ring* rg : used) {       // appends to these rings order behind the staging kernels
+            std::lock_guard<std::mutex> lk(rg->mu);
+            (void)hipEventRecord(rg->read_ev, e->st); rg->read_pending = true;
+        }
+    }
+    HIPC(e, hipMemcpyAsync(e->n_samples_d, e->n_samples_h.data(), (size_t)W * 4, hipMemcpyHostToDevice, e->st));
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    e->W = W;
+    return SONIC_OK;
+}
+extern "C" int sonic_stage_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings, const int64_t* ring_start,
+                                 const int32_t* ring_n, int W, const int32_t* req_win, int R) {
+    if (!e) return SONIC_ERR_INVALID;
+    ENTER(e);
+    return stage_mixed_locked(e, W, host_pcm, host_off, rings, ring_start, ring_n, req_win, R);
+}
+extern "C" int sonic_transcribe_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings, const int64_t* ring_start,
+                                      const int32_t* ring_n, int W, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                                      const int32_t* max_new, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
+    if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
+    ENTER(e);
+    TRY(stage_mixed_locked(e, W, host_pcm, host_off, rings, ring_start, ring_n, req_win, R));
+    TRY(run_all(e, req_win, R, prompt_ids, prompt_off, max_new, step_logits != nullptr));
+    return fetch_locked(e, out_ids, out_ld, out_len, step_logits);
 }
 
 extern "C" int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W) {

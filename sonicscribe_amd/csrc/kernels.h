@@ -111,6 +111,19 @@ void launch_swiglu_quant(const float* P, int ksplit, int mpad, int ff, bf16_t* a
 void launch_rope_enc(bf16_t* qk, long ld, int M, int T, int heads2, int hd, int rd, const float* cs, hipStream_t s, int dt = DT_BF16);
 void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* audio, bf16_t* x, int n_tok, int d, hipStream_t s);
 void launch_fill_i32(int* p, int value, int n, hipStream_t s);
+
+// device-resident ingest (ingest.hip): stage windows from per-session rings of raw wire PCM with the reference's a1 + a2 arithmetic
+#define RING_MAX_WIN 64
+struct RingStageArgs {
+    const short* ring[RING_MAX_WIN];   // per window: ring base, or null for a host window (already staged by the caller)
+    long ring_cap[RING_MAX_WIN];       // ring capacity in samples
+    long start[RING_MAX_WIN];          // position of the window's first sample in the ring (absolute index modulo capacity)
+    int n[RING_MAX_WIN];               // samples in the window
+    int req_of[RING_MAX_WIN];          // request the window belongs to (the peak is per request)
+    int* peak;                         // [requests] max |s|, zeroed by the caller
+    short* pcm; long win_cap;          // engine PCM staging [W][win_cap]
+};
+void launch_ring_stage(const RingStageArgs& a, int W, int max_n, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s, int dt = DT_BF16);      // fp32 -> element type
 void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s, int dt = DT_BF16);      // element type -> fp32
 void launch_bf16_to_f16(const bf16_t* in, bf16_t* out, long n, hipStream_t s);                       // bf16 storage -> fp16 storage (RNE), in place allowed

@@ -15,7 +15,8 @@ has a worker thread that drains its queue into device batches:
     that replica's backlog exceeds the least-loaded one's by more than a batch, then it is rebalanced; keyless requests (file mode:
     independent segments) go to the least-loaded replica.  Segments are independent: no collective, no cross-replica state.
 
-Engines are duck-typed (`max_batch`, `transcribe_batch(segs, prompts, max_new, req_win=...)`) so the dispatcher is testable on CPU
+A window is either host PCM or a slice of a session's device ring (engine.RingSlice); ring requests are pinned to the
+replica that owns the ring.  Engines are duck-typed (`max_batch`, `transcribe_batch(segs, prompts, max_new, req_win=...)`) so the dispatcher is testable on CPU
 with stub engines; ctypes releases the GIL inside the real engine call, so G worker threads drive G GPUs concurrently.
 """
 from __future__ import annotations
@@ -140,19 +141,24 @@ class Dispatcher:
     def __len__(self):
         return len(self.replicas)
 
+    def home(self, session: str) -> int:
+        """Index of the replica a session key maps to (stable across processes, unlike hash())."""
+        return zlib.crc32(str(session).encode()) % len(self.replicas)
+
     def pick(self, session: Optional[str]) -> _Replica:
         loads = [r.load() for r in self.replicas]
         least = min(range(len(loads)), key=loads.__getitem__)
         if session is None:
             return self.replicas[least]
-        home = zlib.crc32(str(session).encode()) % len(self.replicas)      # (stable across processes, unlike hash())
+        home = self.home(session)
         if loads[home] - loads[least] > self.replicas[home].engine.max_batch:
             return self.replicas[least]                                     # rebalance: the home replica is more than a batch behind
         return self.replicas[home]
 
-    def submit(self, windows, prompt, max_new: int, session: Optional[str] = None) -> Future:
+    def submit(self, windows, prompt, max_new: int, session: Optional[str] = None, replica: Optional[int] = None) -> Future:
+        """`replica` pins the request (windows that are slices of a device ring can only be decoded where the ring lives)."""
         req = Request(windows, prompt, max_new)
-        self.pick(session).put(req)
+        (self.replicas[replica] if replica is not None else self.pick(session)).put(req)
         return req.future
 
     def close(self):

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -27,6 +27,7 @@ EXPORTS = [
     "sonic_run_staged", "sonic_fetch_tokens", "sonic_get_timings", "sonic_synchronize", "sonic_test_gemm", "sonic_test_skinny",
     "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_debug_ktrace", "sonic_test_skinny_gu",
     "sonic_set_forced_ids", "sonic_test_greedy", "sonic_test_linear_int8",
+    "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
 ]
 
 
@@ -94,6 +95,14 @@ def load_library():
     lib.sonic_encode.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.sonic_transcribe_batch.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.sonic_stage_pcm.argtypes = [vp, vp, vp, C.c_int]
+    lib.sonic_ring_create.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    lib.sonic_ring_destroy.argtypes = [vp]
+    lib.sonic_ring_destroy.restype = None
+    lib.sonic_ring_append.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    lib.sonic_ring_head.argtypes = [vp]
+    lib.sonic_ring_head.restype = C.c_int64
+    lib.sonic_transcribe_mixed.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
+    lib.sonic_stage_mixed.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int]
     lib.sonic_run_staged.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
     lib.sonic_fetch_tokens.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.sonic_get_timings.argtypes = [vp, C.POINTER(SonicTimings)]
@@ -126,6 +135,59 @@ def _p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class RingSlice:
+    """Samples [start, start + n) of a device ring: a decode window that never visits the host."""
+    __slots__ = ("ring", "start", "n")
+
+    def __init__(self, ring: "Ring", start: int, n: int):
+        self.ring, self.start, self.n = ring, int(start), int(n)
+
+    def __len__(self):
+        return self.n
+
+
+class Ring:
+    """Raw wire PCM (int16) of one streaming session in HBM (sonic_ring_*)."""
+
+    def __init__(self, engine: "Engine", capacity_samples: int):
+        self.engine, self.capacity = engine, int(capacity_samples)
+        h = C.c_void_p()
+        engine._check(engine.lib.sonic_ring_create(engine.h, self.capacity, C.byref(h)))
+        self.h = h
+        if not hasattr(engine, "_rings"):
+            engine._rings = []
+        engine._rings.append(self)
+
+    def append(self, pcm) -> int:
+        """pcm: bytes (little-endian int16, as on the wire) or an int16 array.  Returns the absolute index of its first sample."""
+        a = np.frombuffer(pcm, dtype=np.int16) if isinstance(pcm, (bytes, bytearray, memoryview)) else np.ascontiguousarray(pcm, dtype=np.int16)
+        first = C.c_int64(0)
+        rc = self.engine.lib.sonic_ring_append(self.h, _p(a) if a.size else None, a.size, C.byref(first))
+        if rc != 0:
+            raise RuntimeError(f"sonic_ring_append failed with status {rc}")
+        return int(first.value)
+
+    @property
+    def head(self) -> int:
+        return int(self.engine.lib.sonic_ring_head(self.h))
+
+    def slice(self, start: int, n: int) -> RingSlice:
+        return RingSlice(self, start, n)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.lib.sonic_ring_destroy(self.h)
+            self.h = None
+            if self in getattr(self.engine, "_rings", []):
+                self.engine._rings.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One model replica on one MI355X."""
 
@@ -153,8 +215,14 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for r in list(getattr(self, "_rings", ())):      # rings belong to their engine and go first
+                r.close()
             self.lib.sonic_destroy(self.h)
             self.h = None
+
+    def ring_create(self, capacity_samples: int) -> "Ring":
+        """Device-resident PCM ring of one streaming session (include/sonic_hip.h sonic_ring_*)."""
+        return Ring(self, capacity_samples)
 
     def __del__(self):
         try:
@@ -230,9 +298,36 @@ class Engine:
         ids = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)
         return np.ascontiguousarray(ids), offs
 
-    def transcribe_batch(self, segments: Sequence[np.ndarray], prompts: Sequence[Sequence[int]], max_new: Sequence[int],
+    def _pack_mixed(self, segments):
+        """Windows that are RingSlice objects stay on the device; the rest is packed like _pack_pcm (ring windows: empty host ranges)."""
+        W = len(segments)
+        host = [np.zeros(0, np.int16) if isinstance(s, RingSlice) else s for s in segments]
+        pcm, offs = self._pack_pcm(host)
+        rings = (C.c_void_p * W)(*[s.ring.h if isinstance(s, RingSlice) else None for s in segments])
+        start = np.array([s.start if isinstance(s, RingSlice) else 0 for s in segments], np.int64)
+        n = np.array([s.n if isinstance(s, RingSlice) else 0 for s in segments], np.int32)
+        for s in segments:
+            if isinstance(s, RingSlice) and s.ring.engine is not self:
+                raise ValueError("a ring slice can only be decoded by the engine that owns the ring")
+        return pcm, offs, rings, start, n
+
+    def transcribe_batch(self, segments: Sequence[Any], prompts: Sequence[Sequence[int]], max_new: Sequence[int],
                          req_win: Optional[Sequence[int]] = None, want_logits: bool = False):
-        """segments: int16 PCM windows (<= 30 s each); one prompt per request. Returns (ids list, logits or None)."""
+        """segments: int16 PCM windows (<= 30 s each, already peak-normalised) or RingSlice objects (raw wire PCM resident in a device
+        ring; normalised on the device over the windows of their request); one prompt per request. Returns (ids list, logits or None)."""
+        if any(isinstance(s, RingSlice) for s in segments):
+            pcm, offs, rings, start, n = self._pack_mixed(segments)
+            ids, poffs = self._pack_prompts(prompts)
+            R = len(prompts)
+            mn = np.ascontiguousarray(max_new, dtype=np.int32)
+            out_ld = int(mn.max())
+            out = np.zeros((R, out_ld), np.int32)
+            out_len = np.zeros(R, np.int32)
+            rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+            logits = np.zeros((out_ld, R, self.dims.vocab), np.float32) if want_logits else None
+            self._check(self.lib.sonic_transcribe_mixed(self.h, _p(pcm), _p(offs), rings, _p(start), _p(n), len(segments), _p(rw), R, _p(ids), _p(poffs),
+                                                        _p(mn), _p(out), out_ld, _p(out_len), _p(logits)))
+            return [out[r, : out_len[r]].copy() for r in range(R)], logits
         pcm, offs = self._pack_pcm(segments)
         ids, poffs = self._pack_prompts(prompts)
         R = len(prompts)
@@ -246,7 +341,13 @@ class Engine:
                                                     _p(out), out_ld, _p(out_len), _p(logits)))
         return [out[r, : out_len[r]].copy() for r in range(R)], logits
 
-    def stage_pcm(self, segments: Sequence[np.ndarray]):
+    def stage_pcm(self, segments: Sequence[Any], req_win: Optional[Sequence[int]] = None):
+        if any(isinstance(s, RingSlice) for s in segments):
+            pcm, offs, rings, start, n = self._pack_mixed(segments)
+            rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+            R = len(rw) - 1 if rw is not None else len(segments)
+            self._check(self.lib.sonic_stage_mixed(self.h, _p(pcm), _p(offs), rings, _p(start), _p(n), len(segments), _p(rw), R))
+            return
         pcm, offs = self._pack_pcm(segments)
         self._check(self.lib.sonic_stage_pcm(self.h, _p(pcm), _p(offs), len(segments)))
 

@@ -156,3 +156,19 @@ def test_asyncio_callers_overlap():
     assert dt < 24 * 0.02 * 0.6                         # batched: far less than 24 serial device calls
     assert ticks >= 5                                   # the event loop kept running while the "device" worked
     d.close()
+
+
+def test_pinned_replica_and_session_home():
+    """Requests whose windows live in a device ring are pinned to the ring's replica (Dispatcher.submit(replica=...)); a session's home
+    replica is the same crc32 rule pick() uses, so a stream and the session's other decodes land on one GPU."""
+    engines = [StubEngine(), StubEngine(), StubEngine()]
+    d = Dispatcher(engines)
+    homes = {s: d.home(s) for s in ("client-1", "client-2", "client-3", "client-4", "client-5")}
+    assert all(0 <= h < 3 for h in homes.values()) and len(set(homes.values())) > 1
+    assert homes == {s: d.home(s) for s in homes}                     # stable
+    for s, h in homes.items():
+        assert d.pick(s).index == h                                   # idle replicas: a session stays at home
+    futs = [d.submit([seg(i)], [1, 2, 3], 8, replica=2) for i in range(6)]
+    [f.result(timeout=10) for f in futs]
+    assert sum(b[0] for b in engines[2].batches) == 6 and not engines[0].batches and not engines[1].batches
+    d.close()
