@@ -172,6 +172,51 @@ def test_int8_fullwidth_layer_vs_oracle(orc):
     e.close()
 
 
+def test_int8_bench_config_full_depth_vs_oracle(orc):
+    """BASELINE config 4 at its real size: 32 + 28 layers, vocabulary 59264, INT8 mode, 64 x 20 s segments in one batch (what
+    `bench.py --mode int8 --batch 64` times).  Two steps under teacher forcing:
+      * rows 0 and 41: prefill + decode logits against the int8 oracle at full depth;
+      * rows 0, 21, 42, 63: the batch result against single-segment runs (outlier columns are found per request, so a request's
+        result must not depend on its neighbours).
+    Bound: the fp16 ops between the linears differ in summation order from the oracle's, and one flipped fp16 ulp can move an int8
+    code; over 60 layers the logits (|x| <= ~5) are held to 0.25; the measured value is printed."""
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    d = spec.FULL
+    B, n_new, n_samples = 64, 2, 320000
+    e = Engine(d, 0, MODE_INT8, max_batch=B, max_ctx=512)
+    e.load_synthetic(SEED)
+    segs = [synth.synth_pcm(i, n_samples) for i in range(B)]
+    prompt = _prompt(n_samples, d)
+    rng = np.random.default_rng(77)
+    bad = set(d.eos_ids) | {d.audio_token_id}
+    force = np.asarray([[t for t in rng.integers(2, d.vocab, 8) if int(t) not in bad][:n_new] for _ in range(B)], np.int32)
+    e.set_forced_ids(force)
+    ids, logits = e.transcribe_batch(segs, [prompt] * B, [n_new] * B, want_logits=True)
+    assert all(np.array_equal(ids[r], force[r]) for r in range(B)) and np.isfinite(logits).all()
+    worst_single = 0.0
+    for r in (0, 21, 42, 63):
+        e.set_forced_ids(force[r:r + 1])
+        _, l1 = e.transcribe_batch([segs[r]], [prompt], [n_new], want_logits=True)
+        worst_single = max(worst_single, float(np.abs(l1[:, 0] - logits[:, r]).max()))
+    e.set_forced_ids(None)
+    e.close()
+    st = {}
+    for name, shape, kind in spec.tensor_inventory(d):
+        scale, offset = synth.kind_params(kind, shape)
+        st[name] = orc.synth_fill(SEED, name, int(np.prod(shape)), scale, offset, 2).reshape(shape)
+    om = orc.Model(d, st, mode=orc.MODE_INT8)
+    del st
+    worst = 0.0
+    for r in (0, 41):
+        feats, mask = orc.logmel(segs[r])
+        ref = om.transcribe(feats, int(mask.sum()), prompt, n_new, force_ids=force[r])
+        worst = max(worst, float(np.abs(logits[:, r] - ref["step_logits"]).max()))
+    print(f"int8 full depth, batch 64: max|dlogit| vs oracle {worst:.4f}, batch vs single {worst_single:.4f}, "
+          f"logit range [{logits.min():.2f}, {logits.max():.2f}]")
+    assert worst <= 0.25, worst
+    assert worst_single <= 0.25, worst_single
+
+
 def test_asrmodel_int8_mode():
     from sonicscribe_amd.asr import ASRModel
     m = ASRModel.from_synthetic(spec.TINY, mode="int8", max_batch=4, max_ctx=512)
