@@ -86,6 +86,7 @@ class AudioStream:
         self.ring = model.models[replica].ring_create(int(buffer_seconds * model.target_sr))
         self._chunks: Dict[int, tuple] = {}       # chunk id -> (first sample index, samples)
         self.next_chunk_id = 0
+        self._oldest = 0                          # smallest chunk id still in the ring
 
     def add_audio_chunk(self, audio_data: bytes) -> int:
         """audio_manager.py:21-33: store one wire chunk, return its chunk id."""
@@ -93,9 +94,10 @@ class AudioStream:
         cid = self.next_chunk_id
         self.next_chunk_id += 1
         self._chunks[cid] = (first, len(audio_data) // 2)
-        floor = self.ring.head - self.ring.capacity           # chunks that have left the ring (audio_manager.py:35-59 drops them by age)
-        for old in [c for c, (f, _) in self._chunks.items() if f < floor]:
-            del self._chunks[old]
+        floor = first + len(audio_data) // 2 - self.ring.capacity     # chunks that have left the ring (audio_manager.py:35-59 drops them by age)
+        while self._oldest < cid and self._chunks[self._oldest][0] < floor:
+            del self._chunks[self._oldest]
+            self._oldest += 1
         return cid
 
     def submit_chunks(self, start_chunk_id: int, end_chunk_id: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> "Future[str]":

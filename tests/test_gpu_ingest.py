@@ -138,4 +138,13 @@ def test_audio_stream_facade_equals_transcribe():
     with pytest.raises(ValueError):
         st.submit_chunks(len(ids) + 5, len(ids) + 9)
     st.close()
+    # a buffer shorter than the audio: chunks that left the ring are skipped, as get_chunks_by_range skips the ids that
+    # _cleanup_old_chunks removed (audio_manager.py:35-59, 76-79)
+    short = m.open_stream("client-43", buffer_seconds=2.0)
+    ids = [short.add_audio_chunk(data[i:i + CHUNK]) for i in range(0, len(data), CHUNK)]
+    kept = sorted(short._chunks)
+    assert kept[-1] == ids[-1] and 0 < len(kept) <= 2 * 16000 // 1024 and kept == list(range(kept[0], kept[-1] + 1))
+    got = short.submit_chunks(0, ids[-1], max_new_tokens=10).result()
+    assert got == m.transcribe(frontend.pcm_bytes_to_float(data[kept[0] * CHUNK:]), 16000, max_new_tokens=10)
+    short.close()
     m.close()
