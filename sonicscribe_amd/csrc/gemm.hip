@@ -463,9 +463,12 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
     constexpr int WPRE = NORM ? WTOT / 2 : WTOT, WREM = WTOT - WPRE;
     bf16x8 wf[WTOT];                                                 // [tile j][k-step u] of this wave's K eighth
     const bf16_t* wp = a.W + ((long)blockIdx.x * TPB * (K >> 5) + wk * KS8) * 512 + lane * 8;
-#define GU_WADDR(f) (wp + ((long)((f) / KS8) * (K >> 5) + (f) % KS8) * 512)
+    // W fragments by inline asm (nt), so that every wait on them is hand-counted: beside LDS-DMA the compiler's own bookkeeping waits
+    // vmcnt(0) at the first use of an ordinary load.  The 13-bit instruction offset reaches four 1 KiB fragments per base address.
+#define GU_WBASE(f) (wp + ((long)((f) / KS8) * (K >> 5) + (((f) % KS8) / 4) * 4) * 512)
+#define GU_WLOAD(f) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[f]) : "v"(GU_WBASE(f)), "n"((((f) % KS8) % 4) * 1024) : "memory")
 #pragma unroll
-    for (int f = 0; f < WPRE; ++f) wf[f] = __builtin_nontemporal_load((const bf16x8*)GU_WADDR(f));
+    for (int f = 0; f < WPRE; ++f) GU_WLOAD(f);
     KT(a, 1);
     if (NORM) {
         // Every lane rewrites exactly the 16 bytes its own DMA deposited, so only this wave's vmcnt orders it - no barrier.
@@ -502,32 +505,74 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
             asm volatile("ds_write_b128 %0, %1" ::"v"(lbase + tt * 1024), "v"(o) : "memory");
 #pragma unroll
             for (int f = WPRE + tt * WREM / PW; f < WPRE + (tt + 1) * WREM / PW; ++f)      // the next W fragment(s) go out behind this piece
-                wf[f] = __builtin_nontemporal_load((const bf16x8*)GU_WADDR(f));
+                GU_WLOAD(f);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-#undef GU_WADDR
+#undef GU_WLOAD
+#undef GU_WBASE
     f32x4 acc[TPB][MB];
 #pragma unroll
     for (int j = 0; j < TPB; ++j)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     KT(a, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Every wave staged (and, NORM, rewrote) exactly the X pieces of its own K eighth (PW pieces = KS8 / 2 whole 64-wide K blocks), so
+    // for KS8 >= 2 nothing here depends on another wave: no barrier before the MFMAs, only this wave's own counted waits.  Fragments
+    // were requested in the order f = j * KS8 + u and vmcnt retires in order: tile j is multiplied as soon as ITS fragments have
+    // landed, while the later tiles' are still in flight (X, requested before all of W, is covered by the first wait).
+    if constexpr (KS8 < 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < WTOT; ++f) asm volatile("" : "+v"(wf[f]));
+        __syncthreads();
+    }
     KT(a, 3);
-    __syncthreads();
+    bf16x8 xfr[KS8][MB];
+    if constexpr (KS8 >= 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WTOT - KS8 < 63 ? WTOT - KS8 : 63) : "memory");   // X + tile 0's fragments
+        // X fragments by inline asm: behind an LDS-DMA the compiler cannot see retired, it would put vmcnt(0) in front of a ds_read
+        const unsigned xbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+        for (int u = 0; u < KS8; ++u) {
+            const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mb * 16 + r;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[u][mb]) : "v"(xbase + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4)) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < KS8; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) asm volatile("" : "+v"(xfr[u][mb]));
+    } else {
+#pragma unroll
+        for (int u = 0; u < KS8; ++u) {
+            const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mb * 16 + r;
+                xfr[u][mb] = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+            }
+        }
+    }
     KT(a, 4);
 #pragma unroll
-    for (int u = 0; u < KS8; ++u) {
-        const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
+    for (int j = 0; j < TPB; ++j) {
+        if constexpr (KS8 >= 2) {
+            // fragments of tiles > j may still be in flight: (TPB - 1 - j) * KS8 younger requests
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TPB - 1 - j) * KS8) : "memory");
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int m = mb * 16 + r;
-            const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
-#pragma unroll
-            for (int j = 0; j < TPB; ++j) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xf, acc[j][mb], 0, 0, 0);
+            for (int u = 0; u < KS8; ++u) asm volatile("" : "+v"(wf[j * KS8 + u]));      // (uses stay below the wait)
         }
+#pragma unroll
+        for (int u = 0; u < KS8; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xfr[u][mb], acc[j][mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // tile j's MFMAs go out before the wait for tile j + 1
     }
     KT(a, 5);
     __syncthreads();

@@ -25,7 +25,7 @@ names = ["qkv (skinny_xs)", "attention", "o_proj (skinny_o)", "gate/up (skinny_g
 points = {0: ["entry", "loads issued", "X in LDS", "last W multiplied", "synced", "slabs written"],
           1: ["entry", "prologue done (slab sum, RoPE, append)", "KV loop done", "merged in LDS", "O written"],
           2: ["entry", "loads issued", "all landed", "synced", "MFMA done", "end"],
-          3: ["entry", "first loads issued", "norm pass done, all W issued", "all landed", "synced", "MFMA done", "end"],
+          3: ["entry", "first loads issued", "norm pass done, all W issued", "X + tile 0 landed (wave 0)", "X fragments read", "MFMA done (wave 0)", "end"],
           4: ["entry", "loads issued", "X in LDS", "last W multiplied", "synced", "slabs written"]}
 t_ref = None
 prev_end = None
