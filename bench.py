@@ -145,7 +145,7 @@ def run_streaming(a):
     base = spec.FULL if a.dims == "full" else spec.TINY
     dims = replace(base, eos_ids=())
     S = a.sessions
-    dev = "cuda:*" if a.gpus > 1 else "cuda:0"
+    dev = "cuda:*" if a.gpus > 1 else "cuda:" + ",".join(["0"] * max(1, a.replicas_per_gpu))     # several replicas on one GPU fill each other's decode bubbles
     model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512)
     n_rep = len(model.models)
     speech = SEG_SECONDS * 16000
@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="engine tuning knob for experiments (sonic_set_option)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE config 5: real-time session simulation (partial / final latency), one process")
     ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
+    ap.add_argument("--replicas-per-gpu", type=int, default=1, help="--streaming on one GPU: engine replicas sharing it (DESIGN.md 4: concurrent decode chains)")
     ap.add_argument("--ingest", default="host", choices=["host", "ring"], help="--streaming: decodes hand over host tensors (the reference's call) or name chunk "
                     "ranges of per-session device rings fed chunk by chunk (SURVEY 8 f2)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)

@@ -135,6 +135,16 @@ static hipError_t h2d(sonic_engine* e, void* dst, const void* src, size_t bytes)
 }
 
 // zero fill by a kernel on the engine stream (hipMemsetAsync on a non-blocking stream: see TmpBuf::get)
+// Device -> host on the ENGINE stream.  The synchronous hipMemcpy goes through the legacy stream, which implicitly synchronises with
+// other streams of the process: with several engines in one process (replicas on one or several GPUs) it failed with "operation would
+// make the legacy stream depend on a capturing blocking stream" while another engine's thread was capturing its decode graph.
+static hipError_t d2h_async(sonic_engine* e, void* dst, const void* src, size_t bytes) {
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->st);
+}
+static hipError_t d2h(sonic_engine* e, void* dst, const void* src, size_t bytes) {
+    hipError_t r = d2h_async(e, dst, src, bytes);
+    return r == hipSuccess ? hipStreamSynchronize(e->st) : r;
+}
 static void zero_fill(sonic_engine* e, void* q, size_t bytes) {
     size_t left = bytes / 4; int* w = (int*)q;
     while (left > 0) { const int c = left > (1u << 30) ? (1 << 30) : (int)left; launch_fill_i32(w, 0, c, e->st); w += c; left -= c; }
@@ -469,7 +479,7 @@ extern "C" int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n) {
     if (!e->kt) return fail(e, SONIC_ERR_INVALID, "ktrace is off");
     const int64_t have = (int64_t)8 * KT_SLOT_BLOCKS * 8;
     HIPC(e, hipStreamSynchronize(e->st));
-    HIPC(e, hipMemcpy(out, e->kt, (size_t)(n < have ? n : have) * 8, hipMemcpyDeviceToHost));
+    HIPC(e, d2h(e, out, e->kt, (size_t)(n < have ? n : have) * 8));
     return SONIC_OK;
 }
 extern "C" const char* sonic_last_error(sonic_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
@@ -782,14 +792,14 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
             launch_bf16_to_f32(e->x, tap, (long)M * C, e->st, dt);
             HIPC(e, hipStreamSynchronize(e->st));
             for (int b = 0; b < W; ++b)
-                HIPC(e, hipMemcpy(enc_layers_out + ((size_t)b * d.enc_layers + l) * T * C, tap + (size_t)b * T * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
+                HIPC(e, d2h(e, enc_layers_out + ((size_t)b * d.enc_layers + l) * T * C, tap + (size_t)b * T * C, (size_t)T * C * 4));
         }
     }
     launch_layernorm(e->x, e->enc_nw, e->enc_nb, e->ln, M, C, d.enc_ln_eps, e->st, dt);
     if (enc_out_host) {
         launch_bf16_to_f32(e->ln, tap, (long)M * C, e->st, dt);
         HIPC(e, hipStreamSynchronize(e->st));
-        HIPC(e, hipMemcpy(enc_out_host, tap, (size_t)M * C * 4, hipMemcpyDeviceToHost));
+        HIPC(e, d2h(e, enc_out_host, tap, (size_t)M * C * 4));
     }
     if (tap) (void)hipFree(tap);
     // 4-frame merge is a view: [M][C] == [W*Ta][4C] (modeling_glmasr.py:392-397)
@@ -1289,10 +1299,11 @@ static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* 
     const int R = e->R;
     if (R < 1) return fail(e, SONIC_ERR_INVALID, "nothing to fetch");
     std::vector<int> nn(64), kvl(64), tps(64), fin(64);
-    HIPC(e, hipMemcpy(nn.data(), e->n_new, 64 * 4, hipMemcpyDeviceToHost));
-    HIPC(e, hipMemcpy(kvl.data(), e->kv_len, 64 * 4, hipMemcpyDeviceToHost));
-    HIPC(e, hipMemcpy(tps.data(), e->tok_pos, 64 * 4, hipMemcpyDeviceToHost));
-    HIPC(e, hipMemcpy(fin.data(), e->finished, 64 * 4, hipMemcpyDeviceToHost));
+    HIPC(e, d2h_async(e, nn.data(), e->n_new, 64 * 4));
+    HIPC(e, d2h_async(e, kvl.data(), e->kv_len, 64 * 4));
+    HIPC(e, d2h_async(e, tps.data(), e->tok_pos, 64 * 4));
+    HIPC(e, d2h_async(e, fin.data(), e->finished, 64 * 4));
+    HIPC(e, hipStreamSynchronize(e->st));
     // invariants of the greedy controller: a running row's context grows by one per launch; a finished row stopped growing with the
     // launch that finished it (kv_len = prompt + tokens - 1), so no row ever leaves its [max_ctx] cache region
     for (int r = 0; r < R && r < (int)e->last_qlen.size(); ++r) {
@@ -1307,13 +1318,14 @@ static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* 
         if (out_len) out_len[r] = nn[r];
         if (out_ids) {
             if (nn[r] > out_ld) return fail(e, SONIC_ERR_INVALID, "out_ld too small");
-            HIPC(e, hipMemcpy(out_ids + (size_t)r * out_ld, e->out_ids + (size_t)r * e->out_cap, (size_t)nn[r] * 4, hipMemcpyDeviceToHost));
+            HIPC(e, d2h_async(e, out_ids + (size_t)r * out_ld, e->out_ids + (size_t)r * e->out_cap, (size_t)nn[r] * 4));
         }
     }
     if (step_logits) {
         if (!e->dump_steps) return fail(e, SONIC_ERR_INVALID, "step logits were not requested for the last run");
-        HIPC(e, hipMemcpy(step_logits, e->dump, (size_t)e->dump_steps * R * e->d.vocab * 4, hipMemcpyDeviceToHost));
+        HIPC(e, d2h_async(e, step_logits, e->dump, (size_t)e->dump_steps * R * e->d.vocab * 4));
     }
+    HIPC(e, hipStreamSynchronize(e->st));
     return SONIC_OK;
 }
 
@@ -1366,7 +1378,7 @@ extern "C" int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* 
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
     const sonic_dims& d = e->d;
-    if (feats_out) HIPC(e, hipMemcpy(feats_out, e->feats_f32, (size_t)B * d.n_mels * d.n_frames * 4, hipMemcpyDeviceToHost));
+    if (feats_out) HIPC(e, d2h(e, feats_out, e->feats_f32, (size_t)B * d.n_mels * d.n_frames * 4));
     if (mask_out)
         for (int b = 0; b < B; ++b) {
             const int v = frames_of(e->n_samples_h[b]);
@@ -1400,7 +1412,7 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
         HIPC(e, hipMalloc((void**)&t2, m * 4));
         launch_bf16_to_f32(e->pe, t2, (long)m, e->st, e->dt);
         hipError_t r3 = hipStreamSynchronize(e->st);
-        if (r3 == hipSuccess) r3 = hipMemcpy(embeds_out, t2, m * 4, hipMemcpyDeviceToHost);
+        if (r3 == hipSuccess) r3 = d2h(e, embeds_out, t2, m * 4);
         (void)hipFree(t2);
         HIPC(e, r3);
     }
@@ -1447,7 +1459,7 @@ static int down_bf16(sonic_engine* e, TmpBuf& tb, const bf16_t* d, float* h, siz
     launch_bf16_to_f32(d, f, (long)n, e->st, e->dt);
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
-    HIPC(e, hipMemcpy(h, f, n * 4, hipMemcpyDeviceToHost));
+    HIPC(e, d2h(e, h, f, n * 4));
     return SONIC_OK;
 }
 
@@ -1483,7 +1495,7 @@ extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
     std::vector<float> h((size_t)ks * mpad * N);
-    HIPC(e, hipMemcpy(h.data(), P, h.size() * 4, hipMemcpyDeviceToHost));
+    HIPC(e, d2h(e, h.data(), P, h.size() * 4));
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
             float s = 0;
@@ -1726,9 +1738,9 @@ extern "C" int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
     std::vector<int> out(64);
-    HIPC(e, hipMemcpy(out.data(), ids, 64 * 4, hipMemcpyDeviceToHost));
+    HIPC(e, d2h(e, out.data(), ids, 64 * 4));
     for (int b = 0; b < B; ++b) tok_out[b] = out[b];
-    if (logits_out) HIPC(e, hipMemcpy(logits_out, dump, (size_t)B * V * 4, hipMemcpyDeviceToHost));
+    if (logits_out) HIPC(e, d2h(e, logits_out, dump, (size_t)B * V * 4));
     return SONIC_OK;
 }
 

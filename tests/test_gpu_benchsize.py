@@ -299,6 +299,42 @@ def test_two_engines_in_one_process():
     a.close(); b.close()
 
 
+def test_two_engines_capture_and_fetch_concurrently():
+    """Two engines on one GPU driven from two threads, every call with a batch size the engine has not seen yet (so each call captures a
+    decode graph) while the other thread is fetching results: the device -> host copies must not touch the legacy stream (the
+    synchronous hipMemcpy failed here with 'operation would make the legacy stream depend on a capturing blocking stream').  Results
+    equal the sequential ones."""
+    import threading
+    from sonicscribe_amd.engine import Engine
+    engs = [Engine(spec.TINY, 0, max_batch=8, max_ctx=512) for _ in range(2)]
+    for e in engs:
+        e.load_synthetic(SEED)
+    segs = [synth.synth_pcm(90 + i, 16000 * (2 + i % 3)) for i in range(8)]
+    prompts = [tiny_prompt(len(s)) for s in segs]
+    want = [engs[0].transcribe_batch([segs[i]], [prompts[i]], [6])[0][0] for i in range(8)]
+    for e in engs:
+        e.set_option("no_graph", 0)                      # (drops the graphs captured above: every batch size below captures again)
+    got = [[None] * 8 for _ in engs]
+    errs = []
+
+    def work(k):
+        try:
+            order = range(1, 9) if k == 0 else range(8, 0, -1)
+            for n in order:                              # batch sizes 1..8, opposite orders in the two threads
+                ids, _ = engs[k].transcribe_batch(segs[:n], prompts[:n], [6] * n)
+                for i in range(n):
+                    assert np.array_equal(ids[i], want[i]), (k, n, i)
+                got[k][n - 1] = True
+        except BaseException as ex:
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    assert all(all(g) for g in got)
+    for e in engs:
+        e.close()
+
+
 def test_multi_replica_dispatch_and_async_entry():
     """Two engine replicas in ONE process behind the dispatcher (the in-process multi-GPU form; on a one-GPU box both replicas sit on
     device 0 via device="cuda:0,0"), fed through submit() / transcribe_async() the way the WebSocket callers would: results equal the
