@@ -134,6 +134,22 @@ struct GemmArgs {
 #define GELU_LUT_NE 18                      // exponents 2^-14 .. 2^3  (|x| < 16)
 #define GELU_LUT_HALF (GELU_LUT_NE * 128)
 #define GELU_LUT_N (2 * GELU_LUT_HALF)      // 4608 entries = 9216 bytes
+// GELU of a bf16 value l by the table (LDS copy in the 256x256 kernel, the global copy in the 128x128 one: both kernels must give the same
+// bits, or a request's result would depend on which kernel its batch size selects).  Branch-free: a clamped read + two selects.
+__device__ __forceinline__ int gelu_lut_index(float l) {
+    return (int)((__float_as_uint(l) >> 16) & 0x7FFFu) - (GELU_LUT_E0 << 7);
+}
+__device__ __forceinline__ int gelu_lut_slot(float l, int idx) {
+    return (int)min((unsigned)idx, (unsigned)(GELU_LUT_HALF - 1)) + ((__float_as_uint(l) >> 31) ? GELU_LUT_HALF : 0);
+}
+__device__ __forceinline__ float gelu_lut_value(float l, int idx, unsigned t) {
+    // outside the table: |x| < 2^-14 -> 0.5 x (the erf term is below half a bf16 ulp); |x| >= 16 -> x or -0
+    const float lo = 0.5f * l, hi = fmaxf(l, -0.0f);
+    float y = __uint_as_float(t << 16);
+    y = idx < 0 ? lo : y;
+    y = idx >= GELU_LUT_HALF ? hi : y;
+    return y;
+}
 bool gemm256_eligible(const GemmArgs& a, int epi);
 
 // Operand kinds of the MFMA GEMM kernels: element, 16-byte fragment, accumulator, output element type

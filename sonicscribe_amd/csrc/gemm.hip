@@ -12,6 +12,8 @@
 // under the current tile's MFMAs; one barrier per K step.  MFMA roles are swapped (A-operand = W
 // rows, B-operand = activation rows) so each lane ends up with 4 consecutive output columns of one
 // row and the epilogue stores 8-byte bf16 quads.
+#include <type_traits>
+
 #include "common.h"
 #include "int8_util.h"
 
@@ -190,8 +192,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (OT)(l[j] + (float)rv[j]);
             } else if (EPI == EPI_BIAS_GELU) {
+                if (std::is_same<KD, KBF16>::value && a.gelu_lut) {      // the same table as the 256x256 kernel, read from global memory
+                    unsigned t[4]; int idx[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(l[j]);
+                    for (int j = 0; j < 4; ++j) { idx[j] = gelu_lut_index(l[j]); t[j] = a.gelu_lut[gelu_lut_slot(l[j], idx[j])]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_lut_value(l[j], idx[j], t[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(l[j]);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (OT)l[j];

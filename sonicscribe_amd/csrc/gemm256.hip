@@ -378,21 +378,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             l[j] = gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);                  // a bf16 value
-                            const unsigned b = __float_as_uint(l[j]) >> 16;
-                            idx[j] = (int)(b & 0x7FFFu) - (GELU_LUT_E0 << 7);
-                            t[j] = lut[min((unsigned)idx[j], (unsigned)(GELU_LUT_HALF - 1)) + ((b >> 15) ? GELU_LUT_HALF : 0)];
+                            idx[j] = gelu_lut_index(l[j]);
+                            t[j] = lut[gelu_lut_slot(l[j], idx[j])];
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(t[j]));          // (keeps the reads unconditional and batched)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // outside the table: |x| < 2^-14 -> 0.5 x (the erf term is below half a bf16 ulp); |x| >= 16 -> x or -0
-                            const float lo = 0.5f * l[j], hi = fmaxf(l[j], -0.0f);
-                            float y = __uint_as_float(t[j] << 16);
-                            y = idx[j] < 0 ? lo : y;
-                            y = idx[j] >= GELU_LUT_HALF ? hi : y;
-                            o[j] = (OT)y;
-                        }
+                        for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_lut_value(l[j], idx[j], t[j]);
                         *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
                         continue;
                     }

@@ -117,7 +117,8 @@ def test_bench_config_full_depth_vs_oracle(orc):
     instances bench.py times (gemm256 at M = 48000, flash attention over 32 x 20 heads, prefill at M = 8320, the decode step's fused
     kernels at 32 rows, lm_head + greedy at V = 59264).  Three steps under teacher forcing with a varying id sequence:
       * rows 0 and 17: prefill + decode logits against the bf16 oracle at full depth;
-      * every row: the batch result against a single-segment run of the same engine (per-segment results must not depend on batching).
+      * every row: the batch result against a single-segment run of the same engine: per-segment results must not depend on batching,
+        bit for bit.
     Bound: 8 bf16 ulp of 2^-6 (0.125) on logits of magnitude <= ~5 after 60 layers; measured values are printed."""
     from sonicscribe_amd.engine import Engine
     d = spec.FULL
@@ -162,7 +163,10 @@ def test_bench_config_full_depth_vs_oracle(orc):
     print(f"full depth: max|dlogit| vs oracle {worst_orc:.4f}, batch vs single {worst_single:.4f}, near-tie steps {flips}, "
           f"logit range [{logits.min():.2f}, {logits.max():.2f}]")
     assert worst_orc <= tol, worst_orc
-    assert worst_single <= tol, worst_single
+    # by construction, not by tolerance: every kernel sums an output element in an order that does not depend on the batch (fixed slab
+    # order, the 128x128 and 256x256 GEMMs accumulate alike and share their epilogue arithmetic), so a segment's logits are the same
+    # bits alone or in a batch of 32
+    assert worst_single == 0.0, worst_single
 
 
 # ------------------------------------------------------------------------------------------ trajectories that vary

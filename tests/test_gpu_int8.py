@@ -214,7 +214,7 @@ def test_int8_bench_config_full_depth_vs_oracle(orc):
     print(f"int8 full depth, batch 64: max|dlogit| vs oracle {worst:.4f}, batch vs single {worst_single:.4f}, "
           f"logit range [{logits.min():.2f}, {logits.max():.2f}]")
     assert worst <= 0.25, worst
-    assert worst_single <= 0.25, worst_single
+    assert worst_single == 0.0, worst_single       # outlier columns and scales are per request: a request's bits do not depend on its batch
 
 
 def test_asrmodel_int8_mode():

@@ -141,13 +141,9 @@ def test_gemm256_path(eng, M, N, K, epi):
         old = eng.test_gemm(A, W, None if epi == 3 else b, resid=(R if epi == 2 else None), epi=epi)
     finally:
         eng.set_option("gemm_force128", 0)
-    if epi == 1:      # the 128x128 kernel computes GELU by arithmetic (erfc form), the 256x256 one by table (reference op order):
-        eng.set_option("no_gelu_lut", 1)   # compare like with like here; table against arithmetic is test_gelu_table_bit_exact
-        try:
-            got = eng.test_gemm(A, W, b, epi=1)
-        finally:
-            eng.set_option("no_gelu_lut", 0)
-    assert np.mean(old != got) < 0.02      # same math, different summation order: only isolated bf16 flips
+    # Both kernels accumulate every output element over k in the same order (32-wide MFMA steps, ascending) and share the epilogue
+    # arithmetic (the GELU table included), so a row's result does not depend on which kernel its batch size selects: bit-identical.
+    assert np.array_equal(old.view(np.uint32), got.view(np.uint32)), float(np.mean(old != got))
 
 
 def test_gelu_table_bit_exact(eng, orc):
