@@ -1,7 +1,7 @@
 """Randomised concurrency soak of the facade (run on the GPU box): T threads fire transcribe() / submit() / stream requests of random
 length (0.1 - 40 s: one or two 30 s windows), budget and hotwords at a multi-replica ASRModel; every transcript must equal the one the
 same model gave for that request alone beforehand (a segment's result does not depend on what it is batched with, bit for bit).
-  python tools/soak.py [seconds] [threads] [mode]"""
+  python tools/soak.py [seconds] [threads] [mode] [tiny|full]"""
 import sys, os, time, threading, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,11 +11,12 @@ from sonicscribe_amd.asr import ASRModel
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 mode = sys.argv[3] if len(sys.argv) > 3 else "native"
-m = ASRModel.from_synthetic(spec.TINY, device="cuda:0,0", mode=mode, max_batch=8, max_ctx=1024)
+full = len(sys.argv) > 4 and sys.argv[4] == "full"
+m = ASRModel.from_synthetic(spec.FULL if full else spec.TINY, device="cuda:0,0", mode=mode, max_batch=8, max_ctx=1024)
 rng = random.Random(1234)
 HOT = [None, ["alpha"], ["Beta", "gamma delta"], ["x"] * 3]
 cases = []
-for i in range(48):
+for i in range(16 if full else 48):
     n = int(16000 * rng.choice([0.1, 0.3, 1.28, 2.0, 5.0, 7.7, 12.0, 20.0, 31.0, 40.0]))
     raw = (synth.synth_pcm(1000 + i, n).astype(np.float64) * rng.uniform(0.05, 1.0)).round().astype(np.int16)
     cases.append({"raw": raw, "max_new": rng.choice([1, 3, 8, 15, 24, 40]), "hot": rng.choice(HOT)})
