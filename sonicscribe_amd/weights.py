@@ -25,11 +25,18 @@ _RENAMES = (
 
 
 def canonical_name(name: str) -> str:
-    if name.startswith("model.") or name.startswith("lm_head."):
-        return name
-    for src, dst in _RENAMES:
-        if name.startswith(src):
-            return dst + name[len(src):]
+    """On-disk tensor name -> module name.  The rules are transformers' own load-time renamings for this model family
+    (conversion_mapping.py "qwen2_audio": ^language_model.model -> model.language_model, ^language_model.lm_head -> lm_head,
+    ^audio_tower / ^multi_modal_projector -> model.*).  transformers 5.x `save_pretrained` writes the decoder as
+    `language_model.model.model.*` (its reverse mapping applied on top of the legacy prefix) and loads that back without missing keys,
+    so the doubled `model.` is accepted here as well (tests/test_hf_checkpoint_layout.py)."""
+    if not (name.startswith("model.") or name.startswith("lm_head.")):
+        for src, dst in _RENAMES:
+            if name.startswith(src):
+                name = dst + name[len(src):]
+                break
+    while name.startswith("model.language_model.model."):
+        name = "model.language_model." + name[len("model.language_model.model."):]
     return name
 
 
