@@ -50,3 +50,67 @@ def test_live_hf_generate_vs_engine_through_hf_checkpoint(tmp_path):
                 assert margin <= 2 * tol, (seed, s, margin)      # ids are bit-exact outside near-ties
                 break                                            # histories diverged on a near-tie: later steps are not comparable
     e.close()
+
+
+def _synthetic_processor(d):
+    """A GlmAsrProcessor around a word-level tokenizer whose special ids are the model's (audio placeholder, the three EOS ids)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast, WhisperFeatureExtractor
+    from transformers.models.glmasr.processing_glmasr import GlmAsrProcessor
+    specials = {d.audio_token_id: "<|pad|>", d.eos_ids[0]: "<|endoftext|>", d.eos_ids[1]: "<|user|>", d.eos_ids[2]: "<|assistant|>",
+                4: "<|begin_of_audio|>", 5: "<|end_of_audio|>", 0: "<unk>"}
+    words = iter(["Please", "transcribe", "this", "audio", "into", "text", ".", ":", '"', ",", "Pay", "special", "attention", "to", "these",
+                  "important", "terms", "alpha", "beta"])
+    vocab = {}
+    for i in range(d.vocab):
+        vocab[specials[i] if i in specials else (next(words, None) or f"w{i}")] = i
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.WhitespaceSplit(), pre_tokenizers.Punctuation()])
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="<unk>", pad_token="<|endoftext|>", eos_token="<|endoftext|>",
+                                  additional_special_tokens=[s for s in specials.values() if s != "<unk>"])
+    template = ("{% for m in messages %}<|user|>{% for c in m['content'] %}{% if c['type'] == 'audio' %}<|begin_of_audio|><|pad|><|end_of_audio|>"
+                "{% else %}{{ c['text'] }}{% endif %}{% endfor %}{% endfor %}{% if add_generation_prompt %}<|assistant|>{% endif %}")
+    return GlmAsrProcessor(WhisperFeatureExtractor(feature_size=128), tok, chat_template=template), template
+
+
+def test_facade_on_a_complete_checkpoint_directory_vs_live_reference_sequence(tmp_path):
+    """ASRModel(checkpoint_dir) as models_manager.py:26-32 constructs it, on a directory that holds what a download holds (config.json,
+    safetensors, tokenizer, chat template, processor / feature-extractor config - all written by the HF library), against the
+    reference's own sequence run live: peak-normalise + PCM_16 round trip (asr.py:247-276), chat-template prompt with the audio
+    placeholder expanded by the processor (:375-399), generate(do_sample=False) (:411-422), batch_decode(skip_special_tokens)[0].strip()
+    (:425-429).  Transcripts must be equal strings, with and without hotwords, for one- and two-window audio."""
+    from oracle import gen_golden as G
+    from sonicscribe_amd import frontend
+    from sonicscribe_amd.asr import ASRModel, HFPrompt
+    d = spec.TINY
+    model, _ = G.build_tiny(torch.bfloat16)
+    model.save_pretrained(str(tmp_path), safe_serialization=True)
+    proc, template = _synthetic_processor(d)
+    proc.save_pretrained(str(tmp_path))
+    m = ASRModel(str(tmp_path), device="cuda", mode="native", max_batch=4, max_ctx=1024)       # no _allow_synthetic_prompt: the real path
+    assert isinstance(m.prompt, HFPrompt) and m.dims == d and m.target_sr == 16000
+    for seed, seconds, hot, max_new in ((3, 5.0, None, 12), (4, 20.0, ["Alpha", "beta"], 16), (5, 36.0, None, 10)):
+        n = int(seconds * 16000)
+        wav = synth.synth_pcm(seed, n).astype(np.float32) / np.float32(32768.0) * np.float32(0.5)      # not peak-normalised on purpose
+        got = m.transcribe(torch.from_numpy(wav)[None], sampling_rate=16000, max_new_tokens=max_new, hotwords=hot)
+        # the reference sequence, live
+        audio = frontend.normalise_to_int16(wav).astype(np.float32) / np.float32(32768.0)      # what HF reads back from the temp WAV
+        messages = [{"role": "user", "content": [{"type": "audio", "url": ""}, {"type": "text", "text": frontend.build_instruction(hot)}]}]
+        text = proc.tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=True, chat_template=template)
+        inputs = proc(text=text, audio=[audio], return_tensors="pt")
+        with torch.no_grad():
+            gen = model.generate(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                                 input_features=inputs["input_features"].to(torch.bfloat16), input_features_mask=inputs["input_features_mask"],
+                                 max_new_tokens=max_new, do_sample=False, return_dict_in_generate=True, output_logits=True)
+        new = gen.sequences[:, inputs["input_ids"].shape[1]:]
+        want = proc.batch_decode(new, skip_special_tokens=True)[0].strip()
+        logits = torch.stack([l[0] for l in gen.logits]).float().numpy()
+        srt = np.sort(logits, axis=1)
+        print(f"{seconds:.0f} s, hotwords {hot}: min margin {(srt[:, -1] - srt[:, -2]).min():.3f}; engine {got!r}; reference {want!r}")
+        if (srt[:, -1] - srt[:, -2]).min() > 8 * 2.0 ** -6:       # no near-tie on the reference's trajectory: strings must be identical
+            assert got == want, (seconds, got, want)
+        else:                                                      # a near-tie may flip one id: the common prefix must still be long
+            a, b = got.split(), want.split()
+            same = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+            assert same >= 1, (seconds, got, want)
+    m.close()
