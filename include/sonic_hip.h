@@ -113,7 +113,8 @@ int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* o
  * the reference's conversions between the wire and the feature extractor -- int16 -> float32 / 32768
  * (backend/transcription_manager.py:45-54), peak normalisation over the request and the PCM_16 round trip (backend/asr.py:247-276) --
  * run on the device, bit-identical with the host path.  Appends use the ring's own stream and lock: they do not wait for a batch that
- * is decoding.  A ring belongs to the engine it was created on and must be destroyed before it. */
+ * is decoding.  A ring belongs to the engine it was created on; sonic_destroy frees the rings that are still alive (their handles
+ * are dead after that). */
 typedef struct sonic_ring sonic_ring;
 int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, sonic_ring** out);
 void sonic_ring_destroy(sonic_ring* r);

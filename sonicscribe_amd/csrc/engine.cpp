@@ -100,6 +100,7 @@ struct sonic_engine {
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
     int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
+    std::vector<struct sonic_ring*> rings;          // rings created on this engine and not yet destroyed (freed with the engine at the latest)
 
     // timing
     hipEvent_t ev[5]{};
@@ -455,10 +456,13 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     return SONIC_OK;
 }
 
+static void ring_free(struct sonic_ring* r);
 extern "C" void sonic_destroy(sonic_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->st) (void)hipStreamSynchronize(e->st);
+    for (sonic_ring* r : e->rings) ring_free(r);       // rings the caller left behind go with their engine
+    e->rings.clear();
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& u : e->uc_allocs) uc_give(e->device, u.second, u.first);
@@ -1172,11 +1176,11 @@ extern "C" int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, soni
     }
     zero_fill(e, r->buf, (size_t)capacity_samples * 2);
     HIPC(e, hipStreamSynchronize(e->st));
+    e->rings.push_back(r);
     *out = r;
     return SONIC_OK;
 }
-extern "C" void sonic_ring_destroy(sonic_ring* r) {
-    if (!r) return;
+static void ring_free(sonic_ring* r) {
     {
         std::lock_guard<std::mutex> lk(r->mu);
         (void)hipSetDevice(r->e->device);
@@ -1185,6 +1189,15 @@ extern "C" void sonic_ring_destroy(sonic_ring* r) {
         (void)hipFree(r->buf); (void)hipHostFree(r->host); (void)hipStreamDestroy(r->st); (void)hipEventDestroy(r->read_ev); (void)hipEventDestroy(r->app_ev);
     }
     delete r;
+}
+extern "C" void sonic_ring_destroy(sonic_ring* r) {
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lk(r->e->mu);      // (not while a batch that may be staging from this ring holds the engine)
+        auto& v = r->e->rings;
+        v.erase(std::remove(v.begin(), v.end(), r), v.end());
+    }
+    ring_free(r);
 }
 extern "C" int64_t sonic_ring_head(sonic_ring* r) {
     if (!r) return -1;

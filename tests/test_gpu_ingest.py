@@ -148,3 +148,25 @@ def test_audio_stream_facade_equals_transcribe():
     assert got == m.transcribe(frontend.pcm_bytes_to_float(data[kept[0] * CHUNK:]), 16000, max_new_tokens=10)
     short.close()
     m.close()
+
+
+def test_rings_die_with_their_engine():
+    """sonic_destroy frees the rings that are still alive (C-level contract in include/sonic_hip.h); the Python wrappers close the
+    rings first, and closing a stream after its model is a no-op."""
+    from sonicscribe_amd.asr import ASRModel
+    from sonicscribe_amd.engine import Engine
+    e = Engine(spec.TINY, 0, max_batch=2, max_ctx=512)
+    e.load_synthetic(3)
+    rings = [e.ring_create(16000) for _ in range(3)]
+    for r in rings:
+        r.append(np.arange(1000, dtype=np.int16))
+    rings[0].close()                                   # one destroyed by the caller, two left to the engine
+    e.lib.sonic_destroy(e.h)                           # the C call itself, not Engine.close()
+    e.h = None
+    for r in rings:
+        r.h = None                                     # (their handles are dead now)
+    m = ASRModel.from_synthetic(spec.TINY, max_batch=2, max_ctx=512)
+    st = m.open_stream("c")
+    st.add_audio_chunk(np.zeros(1024, np.int16).tobytes())
+    m.close()
+    st.close()                                         # after the model: nothing left to free, must not crash
