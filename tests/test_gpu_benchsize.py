@@ -361,3 +361,29 @@ def test_multi_replica_dispatch_and_async_entry():
     assert all(r.batches > 0 for r in two._dispatcher.replicas)
     assert two.transcribe_batch(wavs[:4], max_new_tokens=[8] * 4) == one.transcribe_batch(wavs[:4], max_new_tokens=[8] * 4)
     one.close(); two.close()
+
+
+@pytest.mark.parametrize("seconds", [65.0, 305.0, 655.0])
+def test_long_requests_vs_oracle(orc, seconds):
+    """Requests of many 30 s windows behind one prompt (the reference processor accepts up to 655 s = 21 windows, 7883 prompt tokens):
+    engine (max_ctx 8192) against the multi-window oracle, TINY dimensions."""
+    from sonicscribe_amd import frontend
+    from sonicscribe_amd.engine import Engine
+    d = replace(spec.TINY, eos_ids=())
+    e = Engine(d, 0, max_batch=32, max_ctx=8192)
+    e.load_synthetic(5)
+    om = orc.Model(d, synth.synth_state_dict(d, 5, bf16=True), bf16=True)
+    n = int(seconds * 16000)
+    pcm = frontend.normalise_to_int16(synth.synth_pcm(9, n).astype(np.float32) / 32768.0)
+    wins = [pcm[s:t] for s, t in frontend.split_windows(len(pcm), d)]
+    n_audio, _ = frontend.request_audio_tokens(n, d)
+    prompt = [1, 17, 23, 5] + [d.audio_token_id] * n_audio + [7, 301, 302, 9]
+    ids, logits = e.transcribe_batch(wins, [prompt], [6], req_win=[0, len(wins)], want_logits=True)
+    fm = [orc.logmel(w) for w in wins]
+    ref = om.transcribe(np.stack([f for f, _ in fm]), [int(m.sum()) for _, m in fm], prompt, 6)
+    assert len(wins) == min(21, -(-n // 480000))
+    assert np.abs(logits[:, 0] - ref["step_logits"]).max() <= 4 * 2.0 ** -6
+    srt = np.sort(ref["step_logits"], axis=1)
+    if (srt[:, -1] - srt[:, -2]).min() > 8 * 2.0 ** -6:
+        assert np.array_equal(ids[0], ref["new_ids"])
+    e.close()
