@@ -24,6 +24,15 @@ t0 = time.time()
 for c in cases:      # reference results, one request at a time
     c["want"] = m.transcribe(frontend.pcm_bytes_to_float(c["raw"].tobytes()), 16000, max_new_tokens=c["max_new"], hotwords=c["hot"])
 print(f"{len(cases)} reference transcripts in {time.time() - t0:.1f} s", flush=True)
+def free_mb():
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        return fr.value / 2 ** 20 if hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0 else float("nan")
+    except Exception:
+        return float("nan")
+free0 = free_mb()
 stop = time.time() + seconds
 errors, done = [], [0] * T
 
@@ -65,7 +74,8 @@ def worker(k):
 
 ts = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
 [t.start() for t in ts]; [t.join() for t in ts]
-print(f"{sum(done)} requests from {T} threads in {seconds:.0f} s, batches per replica {[r.batches for r in m._dispatcher.replicas]}, errors: {len(errors)}")
+print(f"{sum(done)} requests from {T} threads in {seconds:.0f} s, batches per replica {[r.batches for r in m._dispatcher.replicas]}, errors: {len(errors)}; "
+      f"device memory free before / after the load: {free0:.0f} / {free_mb():.0f} MiB")
 for e in errors[:10]:
     print("  ", e)
 m.close()
