@@ -1159,6 +1159,7 @@ struct sonic_ring {
     hipStream_t st = nullptr;
     hipEvent_t read_ev = nullptr; bool read_pending = false;   // last staging kernel that read this ring (appends order behind it)
     hipEvent_t app_ev = nullptr; bool app_pending = false;     // last append (staging kernels order behind it)
+    int64_t unsynced = 0;                  // samples whose H2D copy may still be reading the pinned mirror
 };
 
 extern "C" int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, sonic_ring** out) {
@@ -1213,8 +1214,11 @@ extern "C" int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, i
     if (hipSetDevice(r->e->device) != hipSuccess) return SONIC_ERR_HIP;
     if (r->read_pending) { (void)hipStreamWaitEvent(r->st, r->read_ev, 0); r->read_pending = false; }   // do not overwrite what a staging kernel still reads
     const int64_t pos = r->head % r->cap, first = n < r->cap - pos ? n : r->cap - pos;
-    // (a mirror slot is rewritten one full capacity later -- 30 s of audio -- long after its copy has left)
+    // A mirror slot is rewritten one full capacity later (30 s of audio), normally long after its copy has left; the stream is
+    // drained before an append could overwrite samples whose copy has not been waited for (small rings, bursts).
     hipError_t er = hipSuccess;
+    if (r->unsynced + n > r->cap) { if (hipStreamSynchronize(r->st) != hipSuccess) return SONIC_ERR_HIP; r->unsynced = 0; }
+    r->unsynced += n;
     if (first > 0) { memcpy(r->host + pos, pcm, (size_t)first * 2); er = hipMemcpyAsync(r->buf + pos, r->host + pos, (size_t)first * 2, hipMemcpyHostToDevice, r->st); }
     if (er == hipSuccess && n > first) { memcpy(r->host, pcm + first, (size_t)(n - first) * 2); er = hipMemcpyAsync(r->buf, r->host, (size_t)(n - first) * 2, hipMemcpyHostToDevice, r->st); }
     if (er == hipSuccess && n > 0) { er = hipEventRecord(r->app_ev, r->st); r->app_pending = true; }

@@ -150,6 +150,23 @@ def test_audio_stream_facade_equals_transcribe():
     m.close()
 
 
+def test_small_ring_bursts(eng):
+    """a ring barely larger than one window, fed in bursts that lap it several times between decodes: the pinned mirror must not be
+    overwritten under a copy that has not left yet"""
+    cap = 20000
+    ring = eng.ring_create(cap)
+    raw = wire(41, 16000 * 8, 0.7)
+    for i in range(0, len(raw), 7000):                        # 7000-sample appends: the ring is lapped every three of them
+        ring.append(raw[i:i + 7000])
+    n = 18000
+    start = len(raw) - n
+    prompt = prompt_for(eng.dims, n)
+    ids_h, lg_h = eng.transcribe_batch(host_windows(raw[start:], eng.dims), [prompt], [3], want_logits=True)
+    ids_r, lg_r = eng.transcribe_batch([ring.slice(start, n)], [prompt], [3], want_logits=True)
+    assert np.array_equal(ids_h[0], ids_r[0]) and np.array_equal(lg_h.view(np.uint32), lg_r.view(np.uint32))
+    ring.close()
+
+
 def test_rings_die_with_their_engine():
     """sonic_destroy frees the rings that are still alive (C-level contract in include/sonic_hip.h); the Python wrappers close the
     rings first, and closing a stream after its model is a no-op."""
