@@ -1239,7 +1239,18 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
     const long cap = (long)d.n_frames * 160;
     RingStageArgs ra{};
     int max_n = 0; bool any_ring = false;
+    // every ring of the batch stays locked from the range check until the staging kernels have run (this function ends with a stream
+    // synchronise): an append in between could overwrite the oldest samples of a window that starts at the tail of its ring
     std::vector<sonic_ring*> used;
+    if (rings)
+        for (int w = 0; w < W; ++w)
+            if (rings[w] && std::find(used.begin(), used.end(), rings[w]) == used.end()) {
+                if (rings[w]->e != e) return fail(e, SONIC_ERR_INVALID, "window %d: ring belongs to another engine", w);
+                used.push_back(rings[w]);
+            }
+    std::vector<std::unique_lock<std::mutex>> held;
+    held.reserve(used.size());
+    for (sonic_ring* rg : used) held.emplace_back(rg->mu);
     for (int r = 0, w = 0; r < R; ++r) {
         const int w1 = req_win ? req_win[r + 1] : r + 1;
         if (w1 <= w) return fail(e, SONIC_ERR_INVALID, "request %d has no window", r);
@@ -1247,9 +1258,7 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
             ra.req_of[w] = r;
             sonic_ring* rg = rings ? rings[w] : nullptr;
             if (rg) {
-                if (rg->e != e) return fail(e, SONIC_ERR_INVALID, "window %d: ring belongs to another engine", w);
                 const int64_t n = ring_n[w], st = ring_start[w];
-                std::lock_guard<std::mutex> lk(rg->mu);
                 if (n < 0 || n > cap || st < 0 || st + n > rg->head || st < rg->head - rg->cap)
                     return fail(e, SONIC_ERR_INVALID, "window %d: samples [%lld, %lld) are not in the ring (holds [%lld, %lld))", w, (long long)st, (long long)(st + n),
                                 (long long)(rg->head > rg->cap ? rg->head - rg->cap : 0), (long long)rg->head);
@@ -1258,7 +1267,6 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
                 e->n_samples_h[w] = (int)n;
                 if ((int)n > max_n) max_n = (int)n;
                 any_ring = true;
-                if (std::find(used.begin(), used.end(), rg) == used.end()) used.push_back(rg);
             } else {
                 if (!host_pcm || !host_off) return fail(e, SONIC_ERR_INVALID, "window %d: neither ring nor host samples", w);
                 const int64_t n = host_off[w + 1] - host_off[w];
@@ -1272,10 +1280,7 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
         ra.peak = e->ring_peak; ra.pcm = e->pcm; ra.win_cap = cap;
         launch_fill_i32(e->ring_peak, 0, e->Bm, e->st);
         launch_ring_stage(ra, W, max_n, e->st);
-        for (sonic_ring* rg : used) {       // appends to these rings order behind the staging kernels
-            std::lock_guard<std::mutex> lk(rg->mu);
-            (void)hipEventRecord(rg->read_ev, e->st); rg->read_pending = true;
-        }
+        for (sonic_ring* rg : used) { (void)hipEventRecord(rg->read_ev, e->st); rg->read_pending = true; }   // (appends also order behind them on the device)
     }
     HIPC(e, hipMemcpyAsync(e->n_samples_d, e->n_samples_h.data(), (size_t)W * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipStreamSynchronize(e->st));
