@@ -108,7 +108,8 @@ struct GemmI8 {
     const float* scb;                 // [N] row absmax of the weights
     const bf16_t* x16; long ldx16;    // unquantised activations (fp16 storage) for the outlier columns
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group
-    const int* row_group; int group_div;                 // group of row m = row_group ? row_group[m / group_div] : m / group_div
+    const int* row_group; int group_div;                 // group of row m = row_group ? row_group[(m + row_off) / group_div] : (m + row_off) / group_div
+    int row_off;                                         // index of this launch's row 0 in the quantised matrix (a launch over a row range)
 };
 
 struct GemmArgs {

@@ -232,8 +232,18 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
             if ((main_tiles + cus - 1) / cus < (full + cus - 1) / cus) {
                 GemmArgs m = a; m.M = Mm;
                 launch_gemm256(m, epi, s);
-                GemmArgs t = a; t.M = tail; t.A = a.A + (long)Mm * a.lda; t.C = a.C + (long)Mm * a.ldc;
+                GemmArgs t = a; t.M = tail; t.C = a.C + (long)Mm * a.ldc;
                 if (a.R) t.R = a.R + (long)Mm * a.ldr;
+                if (a.q.sca) {
+                    // int8 GEMM: A is int8 (1 byte per element) and the per-row quantisation data travels with the rows - scales,
+                    // unquantised activations of the outlier columns, and the row -> group (request) index.  (Leaving them at row 0
+                    // gave the tail rows the scales and outlier lists of the FIRST rows of the batch: the last request of some batch
+                    // compositions differed from its solo result, found by tools/find_batch_dependence.py.)
+                    t.A = (const bf16_t*)((const int8_t*)a.A + (long)Mm * a.lda);
+                    t.q.sca = a.q.sca + Mm; t.q.x16 = a.q.x16 + (long)Mm * a.q.ldx16; t.q.row_off = a.q.row_off + Mm;
+                } else {
+                    t.A = a.A + (long)Mm * a.lda;
+                }
                 launch_gemm128(t, epi, s);
                 return;
             }

@@ -94,7 +94,7 @@ __device__ __forceinline__ I8Row i8_row(const GemmArgs& a, int m) {
     I8Row r{0.f, 0, 0};
     if constexpr (KD::I8) {
         r.sa = a.q.sca[m];
-        r.g = a.q.row_group ? a.q.row_group[m / a.q.group_div] : m / a.q.group_div;
+        r.g = a.q.row_group ? a.q.row_group[(m + a.q.row_off) / a.q.group_div] : (m + a.q.row_off) / a.q.group_div;
         r.cnt = a.q.oc_cnt[r.g];
     }
     return r;

@@ -15,3 +15,13 @@ def test_randomised_concurrency_soak(mode):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "6", "6", mode], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "errors: 0" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["native", "int8"])
+def test_no_batch_composition_changes_a_result_full_dimensions(mode):
+    """tools/find_batch_dependence.py at full model dimensions: random batches of 2-6 requests (0.1-40 s, one or two windows, mixed
+    budgets) against each request's solo transcript.  This is the search that found the int8 GEMM's ragged-tail rows reading the
+    quantisation data of the batch's first rows (the last request of some compositions differed)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "find_batch_dependence.py"), mode, "60"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 differing batches" in r.stdout
