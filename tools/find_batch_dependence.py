@@ -14,7 +14,7 @@ cases = []
 for i in range(16):
     n = int(16000 * rng.choice([0.1, 0.3, 1.28, 2.0, 5.0, 7.7, 12.0, 20.0, 31.0, 40.0]))
     raw = (synth.synth_pcm(1000 + i, n).astype(np.float64) * rng.uniform(0.05, 1.0)).round().astype(np.int16)
-    cases.append({"wav": frontend.pcm_bytes_to_float(raw.tobytes()), "n": n, "max_new": rng.choice([1, 3, 8, 15, 24, 40])})
+    cases.append({"wav": frontend.pcm_bytes_to_float(raw.tobytes()), "n": n, "max_new": rng.choice([1, 3, 8, 15, 24, 40, 90, 150])})
 for c in cases:
     c["want"] = m.transcribe(c["wav"], 16000, max_new_tokens=c["max_new"])
     c["wins"] = len(frontend.split_windows(c["n"], spec.FULL))
