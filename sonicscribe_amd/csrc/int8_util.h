@@ -41,7 +41,7 @@ __device__ __forceinline__ f32x4 deq4(const DeqInfo& q, const float* P, int ks, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float wdq = rT<f16_t>(__fmul_rn(__fmul_rn(deq_w(q, col + j, k), sb[j]), INT8_DEQ_W));
-                a2[j] = __fadd_rn(a2[j], __fmul_rn(xv, wdq));      // (no FMA contraction: the oracle rounds product and sum separately)
+                a2[j] = __fmaf_rn(xv, wdq, a2[j]);      // the oracle rounds product and sum separately; the product of two fp16 values is exact in fp32, so one FMA gives the same bits
             }
         }
 #pragma unroll
@@ -68,7 +68,7 @@ __device__ __forceinline__ float deq1(const DeqInfo& q, const float* P, int ks, 
         float a2 = 0.f;
         for (int i = 0; i < n; ++i) {
             const int k = q.oc_list[(long)g * q.oc_ld + i];
-            a2 = __fadd_rn(a2, __fmul_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn(deq_w(q, col, k), sb), INT8_DEQ_W))));
+            a2 = __fmaf_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn(deq_w(q, col, k), sb), INT8_DEQ_W)), a2);   // (exact product: see deq4)
         }
         v = rT<f16_t>(__fadd_rn(v, a2));
     }
@@ -82,7 +82,7 @@ __device__ __forceinline__ float i8_add_outliers(const GemmI8& q, const int8_t* 
     float a2 = 0.f;
     for (int i = 0; i < cnt; ++i) {
         const int k = q.oc_list[(long)g * q.oc_ld + i];
-        a2 = __fadd_rn(a2, __fmul_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn((float)wr[k], sb), INT8_DEQ_W))));
+        a2 = __fmaf_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn((float)wr[k], sb), INT8_DEQ_W)), a2);         // (exact product: see deq4)
     }
     return rT<f16_t>(__fadd_rn(v, a2));
 }
