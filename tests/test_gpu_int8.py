@@ -141,6 +141,42 @@ def test_int8_transcribe_vs_oracle(eng8, orc):
     assert np.array_equal(g[0], ee[0]) and np.array_equal(g[1], ee[1]) and np.array_equal(s0[0], g[1])
 
 
+def test_int8_multi_window_request_vs_oracle(orc):
+    """A 65 s request (three 30 s windows behind one prompt) in INT8 mode, batched with a short one: HF runs the windows of a request
+    as one encoder batch, so LLM.int8 finds its outlier columns over ALL rows of the request (engine: group = request via the
+    window -> request map) -- against the multi-window oracle, teacher-forced."""
+    from sonicscribe_amd import frontend
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    d = spec.TINY
+    eng8 = Engine(d, 0, MODE_INT8, max_batch=8, max_ctx=1024)
+    eng8.load_synthetic(SEED)
+    om = orc.Model(d, synth.synth_state_dict(d, SEED, 2), mode=orc.MODE_INT8)
+    n_long, n_short = 65 * 16000, 3 * 16000
+    pcm_l = frontend.normalise_to_int16(synth.synth_pcm(21, n_long).astype(np.float32) / 32768.0)
+    pcm_s = frontend.normalise_to_int16(synth.synth_pcm(22, n_short).astype(np.float32) / 32768.0)
+    wins = [pcm_l[s0:e0] for s0, e0 in frontend.split_windows(n_long, d)]
+    assert len(wins) == 3
+    n_audio, _ = frontend.request_audio_tokens(n_long, d)
+    prompt_l = [1, 17, 23, 5] + [d.audio_token_id] * n_audio + [7, 301, 302, 303, 9, 11]
+    prompt_s = _prompt(n_short, d)
+    n_new = 5
+    force = np.random.default_rng(9).integers(2, 900, (2, n_new)).astype(np.int32)
+    eng8.set_forced_ids(force)
+    try:
+        ids, logits = eng8.transcribe_batch([pcm_s] + wins, [prompt_s, prompt_l], [n_new, n_new], req_win=[0, 1, 4], want_logits=True)
+    finally:
+        eng8.set_forced_ids(None)
+    fm = [orc.logmel(w) for w in wins]
+    ref = om.transcribe(np.stack([f for f, _ in fm]), [int(m.sum()) for _, m in fm], prompt_l, n_new, force_ids=force[1])
+    worst = float(np.abs(logits[:, 1] - ref["step_logits"]).max())
+    f0, m0 = orc.logmel(pcm_s)
+    ref_s = om.transcribe(f0, int(m0.sum()), prompt_s, n_new, force_ids=force[0])
+    worst = max(worst, float(np.abs(logits[:, 0] - ref_s["step_logits"]).max()))
+    print(f"int8 multi-window: max|dlogit| vs oracle {worst:.4f}")
+    eng8.close()
+    assert worst <= 0.1
+
+
 def test_int8_fullwidth_layer_vs_oracle(orc):
     """Full-width layers (encoder 1280 / 5120, decoder 2048 / 6144 GQA 16:4) at depth 1 + 1, vocabulary 1024, two 20 s segments:
     the 256x256 int8 GEMM at M = 3000 with every epilogue, the int8 decode-step kernels at their full-size tilings (K slices of 1024,
