@@ -56,6 +56,26 @@ def test_ring_equals_host_path(eng, seconds, scale):
     ring.close()
 
 
+def test_ring_equals_host_path_int8_mode():
+    """the same in INT8 mode (fp16 hand-off of the log-mel features, LLM.int8 linears): staging is mode-independent, the results must
+    again be the same bits"""
+    from dataclasses import replace
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    e = Engine(replace(spec.TINY, eos_ids=()), 0, MODE_INT8, max_batch=4, max_ctx=1024)
+    e.load_synthetic(11)
+    n = 7 * 16000 + 321
+    raw = wire(13, n, 0.21)
+    ring = e.ring_create(30 * 16000)
+    data = raw.tobytes()
+    for i in range(0, len(data), CHUNK):
+        ring.append(data[i:i + CHUNK])
+    prompt = prompt_for(e.dims, n)
+    ids_h, lg_h = e.transcribe_batch(host_windows(raw, e.dims), [prompt], [5], want_logits=True)
+    ids_r, lg_r = e.transcribe_batch([ring.slice(0, n)], [prompt], [5], want_logits=True)
+    assert np.array_equal(ids_h[0], ids_r[0]) and np.array_equal(lg_h.view(np.uint32), lg_r.view(np.uint32))
+    e.close()
+
+
 def test_ring_wraps_and_rejects_what_it_lost(eng):
     cap = 3 * 16000
     ring = eng.ring_create(cap)
