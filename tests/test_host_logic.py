@@ -127,3 +127,26 @@ def test_shard_segments():
         a, b = shard_range(10, r, 3)
         cover += list(range(a, b))
     assert cover == list(range(10))
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/sonic_hip.h is the drop-in boundary: it must compile as C99 (no C++-isms outside the extern "C" guard) and a C program
+    that names every entry point must link against the built library (no compute: there is no GPU here)."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "sonic_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(sonic_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    src = tmp_path / "abi.c"
+    body = "\n".join(f"    p[{i}] = (fn){n};" for i, n in enumerate(names))
+    src.write_text('#include "sonic_hip.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n    fn p[%d];\n%s\n'
+                   '    printf("%%d entry points, %%d non-null\\n", %d, (int)(p[0] != 0));\n    return 0;\n}\n' % (len(names), body, len(names)))
+    lib_dir = os.path.join(root, "sonicscribe_amd", "csrc")
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", lib_dir, "-lsonic_hip", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
