@@ -14,6 +14,8 @@ The JSON line also carries
                 token step): algorithmic bytes per token step / its average duration, measured with HIP events on the engine's stream
                 around the decode loop of every timed step
   encoder_gemms / encoder_fc1_gemm / mel_frontend   the MFMA- and HBM-side figures SURVEY.md 8d names
+  two_batches_in_flight   NOT the headline: throughput with a second, independent batch of 32 on the same GPU at the same time (N=1 only;
+                shows how much of the decode loop's loss is latency; --no-two-chains skips it, use that under a profiler)
   cpu_baseline  the reference's DEVICE=cpu arithmetic (transformers GlmAsrForConditionalGeneration.generate, bf16, B=1, full depth,
                 150 tokens, asr.py thread rule) timed on the host cores, rank 0 at N=1 only
 
@@ -236,6 +238,7 @@ def main():
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--mode", default="native", choices=["native", "int8"], help="native = bf16 (BASELINE config 2); int8 = the repo's quantised option (config 4, use --batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-chains", action="store_true", help="skip the extra object `two_batches_in_flight` (two independent batches on the GPU at once; never the headline)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="engine tuning knob for experiments (sonic_set_option)")
     ap.add_argument("--streaming", action="store_true", help="BASELINE config 5: real-time session simulation (partial / final latency), one process")
     ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
@@ -375,6 +378,28 @@ def main():
             gm = tg["gemm_ms"] / tg["gemm_launches"]; fl = tg["gemm_flops"] / tg["gemm_launches"]
             out["encoder_fc1_gemm"] = {"bound": "mfma", "achieved": fl / (gm * 1e-3) / 1e12, "peak": peak_mm, "unit": "TFLOP/s",
                                        "frac": fl / (gm * 1e-3) / 1e12 / peak_mm, "avg_launch_ms": gm, "flops_per_launch": fl, "launches_timed": tg["gemm_launches"]}
+        if n_gpus == 1 and not a.no_two_chains and a.dims == "full":
+            # Not the headline (BASELINE's config is one batch of 32 at a time): how much of the decode loop's loss is latency that a
+            # second, independent batch in flight on the same GPU fills.  A second engine with its own staged batch; both step K times
+            # from two threads (ctypes releases the GIL).  DESIGN.md section 4.
+            import threading
+            try:
+                eng2 = Engine(dims, local_rank, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
+                eng2.load_synthetic(20260128)
+                eng2.stage_pcm([synth.synth_pcm(1000 + i, n_samples) for i in range(B)])
+                eng2.run_staged([prompt] * B, [a.max_new] * B)
+                def _steps(en):
+                    for _ in range(a.steps):
+                        en.rerun_staged()
+                th = [threading.Thread(target=_steps, args=(en,)) for en in (eng, eng2)]
+                t2 = time.perf_counter()
+                [t.start() for t in th]; [t.join() for t in th]
+                d2 = time.perf_counter() - t2
+                out["two_batches_in_flight"] = {"value": 2 * B * a.steps / d2, "unit": "20s-segments/sec", "ms_per_step_pair": d2 / a.steps * 1e3,
+                                                "note": "two engines on this GPU, each with its own batch of %d, stepping concurrently; not the headline" % B}
+                eng2.close()
+            except Exception as ex:
+                out["two_batches_in_flight"] = {"value": None, "note": f"not measured: {ex!r}"}
         if n_gpus == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_reference_baseline()
