@@ -1,5 +1,5 @@
 """Deterministic search for a batch composition whose per-request result differs from the request's solo result (full dimensions).
-  python tools/find_batch_dependence.py [mode] [trials]"""
+  python tools/find_batch_dependence.py [mode] [trials] [max_batch]"""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +8,8 @@ from sonicscribe_amd.asr import ASRModel
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "int8"
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-m = ASRModel.from_synthetic(spec.FULL, device="cuda:0", mode=mode, max_batch=8, max_ctx=1024)
+MB = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+m = ASRModel.from_synthetic(spec.FULL, device="cuda:0", mode=mode, max_batch=MB, max_ctx=1024)
 rng = random.Random(1234)
 cases = []
 for i in range(16):
@@ -20,12 +21,12 @@ for c in cases:
     c["wins"] = len(frontend.split_windows(c["n"], spec.FULL))
 bad = 0
 for t in range(trials):
-    k = rng.randint(2, 6)
+    k = rng.randint(2, max(6, MB - 2))
     pick = []
     w = 0
     for _ in range(k):
         c = rng.choice(range(len(cases)))
-        if w + cases[c]["wins"] <= 8:
+        if w + cases[c]["wins"] <= MB:
             pick.append(c); w += cases[c]["wins"]
     if len(pick) < 2:
         continue
