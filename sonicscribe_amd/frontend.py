@@ -46,21 +46,21 @@ def normalise_to_int16(wav: np.ndarray) -> np.ndarray:
 
 
 def format_hotwords_prompt(hotwords: Optional[Sequence[str]], max_hotwords: int = 10) -> str:
-    """asr.py:303-333.  The reference de-duplicates through ``set()`` (arbitrary order across
-    processes); this restatement keeps first-seen order of the *cleaned* hotwords, which is one
-    of the orders the reference can produce."""
+    """asr.py:303-333.  The reference de-duplicates the RAW strings through ``set()`` (asr.py:318-322) and only then strips and
+    lower-cases them, so ``["Alpha", "alpha "]`` yields two entries, ``"alpha", "alpha"``; only exact repeats of a raw string
+    collapse.  ``set()`` iterates in an order that changes from process to process (string hash randomisation); this restatement
+    keeps the first-seen order of the raw strings, which is one of the orders the reference can produce."""
     if not hotwords:
         return ""
-    seen = []
+    raw = []
     for hw in hotwords:
-        if hw and isinstance(hw, str) and hw.strip():
-            c = hw.strip().lower()
-            if c not in seen:
-                seen.append(c)
-    if not seen:
+        if hw not in raw:            # set(hotwords): exact duplicates of the raw value only
+            raw.append(hw)
+    cleaned = [hw.strip().lower() for hw in raw if hw and isinstance(hw, str) and hw.strip()]
+    if not cleaned:
         return ""
-    seen = seen[:max_hotwords]
-    return ". Pay special attention to these important terms: " + ", ".join(f'"{h}"' for h in seen)
+    cleaned = cleaned[:max_hotwords]
+    return ". Pay special attention to these important terms: " + ", ".join(f'"{h}"' for h in cleaned)
 
 
 def build_instruction(hotwords: Optional[Sequence[str]]) -> str:

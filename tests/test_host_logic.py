@@ -27,8 +27,9 @@ def test_param_count_matches_survey():
 def test_hotwords_prompt():
     assert frontend.format_hotwords_prompt([]) == ""
     assert frontend.format_hotwords_prompt(["  ", None, 3]) == ""
-    s = frontend.format_hotwords_prompt(["Brand", "brand ", "Model X"])
-    assert s == '. Pay special attention to these important terms: "brand", "model x"'
+    s = frontend.format_hotwords_prompt(["Brand", "brand ", "Model X", "Brand"])      # set() drops exact repeats of the RAW string only (asr.py:318-322)
+    assert s == '. Pay special attention to these important terms: "brand", "brand", "model x"'
+    assert frontend.format_hotwords_prompt(["Alpha", "alpha "]) == '. Pay special attention to these important terms: "alpha", "alpha"'
     many = [f"w{i}" for i in range(20)]
     assert frontend.format_hotwords_prompt(many).count('"') == 20      # capped at 10 hotwords
     assert frontend.build_instruction(None) == "Please transcribe this audio into text"
