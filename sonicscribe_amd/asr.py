@@ -71,6 +71,24 @@ class HFPrompt:
         return self.processor.batch_decode([list(map(int, ids))], skip_special_tokens=True)[0]
 
 
+def _text_future(inner: "Future", decode) -> "Future[str]":
+    """Future of the transcript behind a dispatcher future of token ids.  Cancelling it (a session that went away) cancels the queued
+    request as well, so it never reaches the device."""
+    out: "Future[str]" = Future()
+
+    def done(f):
+        if out.done():
+            return
+        try:
+            out.set_result(decode(f.result()).strip())
+        except BaseException as ex:
+            if not out.done():
+                out.set_exception(ex)
+    inner.add_done_callback(done)
+    out.add_done_callback(lambda f: inner.cancel() if f.cancelled() else None)
+    return out
+
+
 class AudioStream:
     """Device-resident counterpart of the reference's per-connection chunk store.
 
@@ -81,12 +99,17 @@ class AudioStream:
     int16 -> float -> peak-normalise -> PCM_16 steps run on the device (csrc/ingest.hip), bit-identical with the host path.
     """
 
-    def __init__(self, model: "ASRModel", session: str, replica: int, buffer_seconds: float):
+    def __init__(self, model: "ASRModel", session: str, replica: int, buffer_seconds: float, margin_seconds: float = 10.0):
         self.model, self.session, self.replica = model, session, replica
-        self.ring = model.models[replica].ring_create(int(buffer_seconds * model.target_sr))
+        # A decode names a sample range and the range is only read when the replica reaches the request, so the ring is LARGER than the
+        # buffer the session sees: chunks stay addressable for `buffer_seconds` (the reference's MAX_AUDIO_BUFFER_SECONDS, config.py:25),
+        # and a queued request survives `margin_seconds` of further appends before the ring overwrites its oldest samples (the
+        # reference concatenates on the host at call time and cannot lose audio that way).
+        self.visible = int(buffer_seconds * model.target_sr)
+        self.ring = model.models[replica].ring_create(int((buffer_seconds + margin_seconds) * model.target_sr))
         self._chunks: Dict[int, tuple] = {}       # chunk id -> (first sample index, samples)
         self.next_chunk_id = 0
-        self._oldest = 0                          # smallest chunk id still in the ring
+        self._oldest = 0                          # smallest chunk id still in the buffer
 
     def add_audio_chunk(self, audio_data: bytes) -> int:
         """audio_manager.py:21-33: store one wire chunk, return its chunk id."""
@@ -94,36 +117,40 @@ class AudioStream:
         cid = self.next_chunk_id
         self.next_chunk_id += 1
         self._chunks[cid] = (first, len(audio_data) // 2)
-        floor = first + len(audio_data) // 2 - self.ring.capacity     # chunks that have left the ring (audio_manager.py:35-59 drops them by age)
+        floor = first + len(audio_data) // 2 - self.visible           # chunks older than the buffer (audio_manager.py:35-59 drops them by age)
         while self._oldest < cid and self._chunks[self._oldest][0] < floor:
             del self._chunks[self._oldest]
             self._oldest += 1
         return cid
 
-    def submit_chunks(self, start_chunk_id: int, end_chunk_id: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> "Future[str]":
-        """Transcribe chunks start..end inclusive (audio_manager.py:76-79 get_chunks_by_range + :115-123 concatenation)."""
-        ids = [c for c in range(start_chunk_id, end_chunk_id + 1) if c in self._chunks]
+    @property
+    def oldest_chunk_id(self) -> int:
+        return self._oldest
+
+    def chunk_range_samples(self, start_chunk_id: int, end_chunk_id: int):
+        """(first sample index, sample count) of chunks start..end inclusive, restricted to what the buffer still holds
+        (audio_manager.py:76-79: ids that left the buffer are skipped)."""
+        ids = [c for c in range(max(start_chunk_id, self._oldest), end_chunk_id + 1) if c in self._chunks]
         if not ids:
             raise ValueError(f"no audio left in the buffer for chunks {start_chunk_id}..{end_chunk_id}")
         for a, b in zip(ids, ids[1:]):
             if b != a + 1:
                 raise ValueError("chunk range is not contiguous in the buffer")
-        first = self._chunks[ids[0]][0]
-        n = sum(self._chunks[c][1] for c in ids)
+        return self._chunks[ids[0]][0], sum(self._chunks[c][1] for c in ids)
+
+    def submit_samples(self, first: int, n: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> "Future[str]":
+        """Transcribe ring samples [first, first + n) (the >30 s split of connection_manager.py:206-214 cuts at byte offsets, not chunks)."""
         m = self.model
         windows = [self.ring.slice(first + s, e - s) for s, e in frontend.split_windows(n, m.dims)]
         n_audio, _ = frontend.request_audio_tokens(n, m.dims)
         prompt = m.prompt.build(frontend.build_instruction(hotwords), n_audio)
         inner = m._dispatcher.submit(windows, prompt, int(max_new_tokens), replica=self.replica)
-        out: "Future[str]" = Future()
+        return _text_future(inner, m.prompt.decode)
 
-        def done(f):
-            try:
-                out.set_result(m.prompt.decode(f.result()).strip())
-            except BaseException as ex:
-                out.set_exception(ex)
-        inner.add_done_callback(done)
-        return out
+    def submit_chunks(self, start_chunk_id: int, end_chunk_id: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> "Future[str]":
+        """Transcribe chunks start..end inclusive (audio_manager.py:76-79 get_chunks_by_range + :115-123 concatenation)."""
+        first, n = self.chunk_range_samples(start_chunk_id, end_chunk_id)
+        return self.submit_samples(first, n, max_new_tokens, hotwords)
 
     async def transcribe_chunks(self, start_chunk_id: int, end_chunk_id: int, max_new_tokens: int = 128, hotwords: Optional[List[str]] = None) -> str:
         return await asyncio.wrap_future(self.submit_chunks(start_chunk_id, end_chunk_id, max_new_tokens, hotwords))
@@ -222,22 +249,15 @@ class ASRModel:
         pcm, windows, n_audio = self._prepare(audio_tensor, sampling_rate)
         prompt = self.prompt.build(frontend.build_instruction(hotwords), n_audio)
         inner = self._dispatcher.submit(windows, prompt, int(max_new_tokens), session=session)
-        out: "Future[str]" = Future()
+        return _text_future(inner, self.prompt.decode)
 
-        def done(f):
-            try:
-                out.set_result(self.prompt.decode(f.result()).strip())
-            except BaseException as ex:
-                out.set_exception(ex)
-        inner.add_done_callback(done)
-        return out
-
-    def open_stream(self, session: str, buffer_seconds: float = 30.0) -> AudioStream:
+    def open_stream(self, session: str, buffer_seconds: float = 30.0, margin_seconds: float = 10.0) -> AudioStream:
         """A streaming session whose audio stays on the device (config.py:25 MAX_AUDIO_BUFFER_SECONDS = 30): chunks are appended to a
-        ring on the session's GPU, partial / final decodes name chunk ranges (AudioStream)."""
+        ring on the session's GPU, partial / final decodes name chunk ranges (AudioStream).  The ring holds `margin_seconds` more than
+        the buffer, so a max-length final that waits in the queue is not overwritten by the chunks that keep arriving."""
         if not hasattr(self, "model"):
             raise RuntimeError("ASR model has been released")
-        return AudioStream(self, session, self._dispatcher.home(session), buffer_seconds)
+        return AudioStream(self, session, self._dispatcher.home(session), buffer_seconds, margin_seconds)
 
     async def transcribe_async(self, audio_tensor, sampling_rate: int = 16000, max_new_tokens: int = 128,
                                hotwords: Optional[List[str]] = None, session: Optional[str] = None) -> str:

@@ -73,23 +73,36 @@ class _Replica:
         with self.cv:
             while not self.q and not self.stop:
                 self.cv.wait()
+            # a caller may have cancelled a queued request (a disconnected session): it leaves the queue here and never reaches the device
+            self.q = [r for r in self.q if not r.future.cancelled()]
             if not self.q:
                 return []
             cap = self.engine.max_batch
             head = self.q[0]
             if len(head.windows) > cap:          # a single request larger than a device batch
                 self.q.pop(0)
-                head.future.set_exception(ValueError(f"audio spans {len(head.windows)} windows, engine max_batch is {cap}"))
+                if head.future.set_running_or_notify_cancel():
+                    head.future.set_exception(ValueError(f"audio spans {len(head.windows)} windows, engine max_batch is {cap}"))
                 return []
             batch, used, rest = [], 0, []
             for r in self.q:                     # oldest first; same step class as the head; whatever fits
                 if r.cls == head.cls and used + len(r.windows) <= cap:
-                    batch.append(r); used += len(r.windows)
+                    if r.future.set_running_or_notify_cancel():      # RUNNING: cancel() now returns False, set_result cannot raise
+                        batch.append(r); used += len(r.windows)
                 else:
                     rest.append(r)
             self.q = rest
             self.busy_windows = used
             return batch
+
+    @staticmethod
+    def _finish(r: Request, result=None, error: Optional[BaseException] = None):
+        if r.future.done():
+            return
+        if error is not None:
+            r.future.set_exception(error)
+        else:
+            r.future.set_result(result)
 
     def _run(self, batch: List[Request]):
         segs, req_win = [], [0]
@@ -98,28 +111,39 @@ class _Replica:
             req_win.append(len(segs))
         try:
             ids, _ = self.engine.transcribe_batch(segs, [r.prompt for r in batch], [r.max_new for r in batch], req_win=req_win)
-            for r, i in zip(batch, ids):
-                r.future.set_result(i)
         except BaseException as ex:              # a per-request validation error must not poison its neighbours: retry one by one
             if len(batch) == 1:
-                batch[0].future.set_exception(ex)
+                self._finish(batch[0], error=ex)
                 return
             for r in batch:
                 try:
-                    ids, _ = self.engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
-                    r.future.set_result(ids[0])
+                    one, _ = self.engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
                 except BaseException as ex2:
-                    r.future.set_exception(ex2)
+                    self._finish(r, error=ex2)
+                else:
+                    self._finish(r, one[0])
+            return
+        for r, i in zip(batch, ids):             # futures complete outside the engine's try block: a callback's error is not an engine error
+            self._finish(r, i)
 
     def _loop(self):
         while True:
-            batch = self._take()
-            if batch:
-                self.batches += 1                # (counted before the futures complete: a waiter may read it right after its result)
-                self._run(batch)
+            batch: List[Request] = []
+            try:
+                batch = self._take()
+                if batch:
+                    self.batches += 1            # (counted before the futures complete: a waiter may read it right after its result)
+                    self._run(batch)
+            except BaseException as ex:          # the worker must not die silently: its queue would hang forever
+                for r in batch:
+                    try:
+                        self._finish(r, error=ex)
+                    except BaseException:
+                        pass
+            finally:
                 with self.cv:
                     self.busy_windows = 0
-            elif self.stop and not self.q:
+            if not batch and self.stop and not self.q:
                 return
 
     def close(self):

@@ -172,3 +172,40 @@ def test_pinned_replica_and_session_home():
     [f.result(timeout=10) for f in futs]
     assert sum(b[0] for b in engines[2].batches) == 6 and not engines[0].batches and not engines[1].batches
     d.close()
+
+
+def test_cancelled_requests_never_reach_the_engine_and_the_worker_survives():
+    """A caller may cancel the future it was handed (a session that disconnected).  The request leaves the queue, its neighbours still
+    complete, a cancel that races the batch start is refused, and the replica thread keeps serving afterwards."""
+    e = StubEngine(max_batch=4)
+    e.gate = threading.Event()
+    d = Dispatcher([e])
+    first = d.submit([seg(1)], [1], 150)
+    time.sleep(0.05)                                   # first is RUNNING on the "device"
+    assert not first.cancel()                          # running requests cannot be cancelled
+    queued = [d.submit([seg(i)], [1], 150) for i in range(2, 6)]
+    assert queued[1].cancel() and queued[2].cancel()   # still pending: cancelled in the queue
+    e.gate.set()
+    assert int(first.result(timeout=5)[0]) == 16
+    assert int(queued[0].result(timeout=5)[0]) == 32 and int(queued[3].result(timeout=5)[0]) == 80
+    assert sum(b[0] for b in e.batches) == 3           # the two cancelled requests never reached the engine
+    later = d.submit([seg(7)], [1], 150)               # the worker thread is alive
+    assert int(later.result(timeout=5)[0]) == 112
+    d.close()
+
+
+def test_text_future_propagates_cancellation_to_the_queued_request():
+    from sonicscribe_amd.asr import _text_future
+    e = StubEngine(max_batch=1)
+    e.gate = threading.Event()
+    d = Dispatcher([e])
+    d.submit([seg(1)], [1], 15)
+    time.sleep(0.05)
+    inner = d.submit([seg(2)], [1], 15)
+    outer = _text_future(inner, lambda ids: " ".join(map(str, ids)))
+    assert outer.cancel() and inner.cancelled()
+    e.gate.set()
+    ok = _text_future(d.submit([seg(3)], [1, 2], 15), lambda ids: " ".join(str(int(i)) for i in ids))
+    assert ok.result(timeout=5) == "48 2 15"
+    assert len(e.batches) == 2
+    d.close()
