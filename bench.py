@@ -42,12 +42,14 @@ MAX_NEW = 150           # min(50 + 5*20, 200), transcription_manager.py:37
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def _cpu_reference_worker(threads: int, n_timed: int, budget_s: float):
+def _cpu_reference_worker(threads: int, n_timed: int, budget_s: float, wait_go: bool = False):
     """Runs in a subprocess (so a slow host cannot stall the bench): times the reference's DEVICE=cpu arithmetic -- third-party torch +
     transformers, exactly what backend/asr.py drives (processor features -> model.generate(do_sample=False), asr.py:393-422) -- on one
     synthetic 20 s segment at FULL depth (32 encoder + 28 decoder layers, vocabulary 59264), B=1, bf16, greedy, 150 new tokens.
-    One warm-up pass (8 tokens: oneDNN primitive creation, page faults), then up to `n_timed` full passes while the budget lasts;
-    the reported figure is their median.  Nothing is extrapolated."""
+    Two warm-up passes (8 tokens each: oneDNN primitive creation, page faults), then up to `n_timed` full passes while the budget lasts;
+    the reported figure is their median.  Nothing is extrapolated.  With wait_go the model is built at once but the timing starts only
+    when the parent writes a line to stdin: the worker is spawned before the parent touches the GPU and must not load the host while
+    the GPU legs are being timed."""
     import torch
     from sonicscribe_amd import spec, synth
     torch.set_num_threads(threads)
@@ -88,54 +90,103 @@ def _cpu_reference_worker(threads: int, n_timed: int, budget_s: float):
         return time.perf_counter() - t0
 
     build_s = time.perf_counter() - t_start
-    warm = run(8)
+    if wait_go:
+        print("READY", flush=True)
+        sys.stdin.readline()
+    t_go = time.perf_counter()
+    warm = [run(8), run(8)]
     runs = []
     for _ in range(n_timed):
-        if runs and (time.perf_counter() - t_start) + 1.15 * max(runs) > budget_s:
+        if runs and (time.perf_counter() - t_go) + 1.15 * max(runs) > budget_s:
             break
         runs.append(run(MAX_NEW))
     print(json.dumps({"threads": threads, "runs_s": runs, "median_s": float(np.median(runs)), "warmup_8tok_s": warm, "build_s": build_s}), flush=True)
 
 
-def cpu_reference_baseline(timeout_s: float = 170.0):
-    """cpu_baseline of the bench line: the reference CPU path at full depth, with the thread count asr.py would pick on this host
-    (all cores, or cores - 2 above 4: asr.py:96-101) and, next to it, capped at 64 threads (a B=1 model rarely scales past that)."""
-    import multiprocessing
-    import subprocess
-    cores = multiprocessing.cpu_count()
-    rule = max(1, cores - 2) if cores > 4 else cores
-    # `value` is timed with min(rule, 64) threads: a B=1 model does not scale past that (on a 256-thread host the 254-thread
-    # rule is several times SLOWER), so this is the figure most favourable to the reference.  The literal asr.py rule runs second
-    # with what is left of the budget and is reported next to it (null when it cannot finish one warm-up + one timed pass).
-    main_th = min(rule, 64)
-    variants = [(main_th, timeout_s)] + ([(rule, 120.0)] if rule != main_th else [])
-    res = {}
-    for th, tmo in variants:
+class CpuBaseline:
+    """cpu_baseline of the bench line: the reference CPU path at full depth.  start() spawns the worker (a child process: model build
+    only) BEFORE the parent initialises the GPU; collect() lets it time 2 warm-ups + up to 5 full passes and reads the result.
+    Threads: min(asr.py's rule, 64) - a B=1 model does not scale past that (asr.py:96-101 would take all cores minus two: on a
+    256-thread host that is several times SLOWER and did not finish one pass in 120 s in round 2; noted, not run)."""
+
+    def __init__(self, budget_s: float = 235.0, n_timed: int = 5):
+        import multiprocessing
+        self.cores = multiprocessing.cpu_count()
+        self.rule = max(1, self.cores - 2) if self.cores > 4 else self.cores
+        self.threads = min(self.rule, 64)
+        self.budget_s, self.n_timed, self.proc = budget_s, n_timed, None
+
+    def start(self):
+        import subprocess
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-threads", str(self.threads),
+                                      "--cpu-timed", str(self.n_timed), "--cpu-budget", str(self.budget_s - 15.0), "--cpu-wait-go"],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def collect(self):
+        import subprocess
+        res = {}
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-threads", str(th),
-                                  "--cpu-budget", str(tmo - 20.0)], capture_output=True, text=True, timeout=tmo)
-            line = next((l for l in reversed(out.stdout.strip().splitlines()) if l.startswith("{")), None)
-            res[th] = json.loads(line) if line else {"error": out.stderr[-300:]}
+            self.proc.stdin.write("go\n"); self.proc.stdin.flush()
+            out, err = self.proc.communicate(timeout=self.budget_s + 60.0)
+            line = next((l for l in reversed(out.strip().splitlines()) if l.startswith("{")), None)
+            res = json.loads(line) if line else {"error": err[-300:]}
         except subprocess.TimeoutExpired:
-            res[th] = {"error": f"did not finish one warm-up + one timed full-depth pass within {tmo:.0f} s"}
-    main_r = res[main_th]
-    ok = "median_s" in main_r
-    desc = (f"1 synthetic 20 s segment, B=1, bf16, FULL depth (32+28 layers, vocab 59264), {MAX_NEW} greedy tokens through torch-CPU + transformers "
-            f"generate() = the reference's DEVICE=cpu arithmetic (asr.py:393-422); 1 warm-up (8 tokens) then the median of the timed full passes; "
-            f"{cores} host CPUs visible; ")
-    for th, _ in variants:
-        r = res[th]
-        tag = "asr.py:96-101 thread rule" if th == rule else "capped at 64"
-        desc += (f"{th} threads ({tag}): " + (f"runs {[round(x, 2) for x in r['runs_s']]} s, median {r['median_s']:.2f} s/segment (RTF {r['median_s'] / SEG_SECONDS:.2f}); "
-                                              if "median_s" in r else f"no result ({r.get('error', '?')}); "))
-    out = {"value": (1.0 / main_r["median_s"]) if ok else None, "unit": "20s-segments/sec", "cores": main_th, "kind": "reference", "sample": desc + "random weights"}
-    if rule != main_th:
-        out["value_asr_thread_rule"] = (1.0 / res[rule]["median_s"]) if "median_s" in res[rule] else None
-        out["asr_thread_rule_threads"] = rule
-    return out
+            self.proc.kill()
+            res = {"error": f"did not finish within {self.budget_s + 60:.0f} s"}
+        except Exception as ex:
+            res = {"error": repr(ex)}
+        ok = "median_s" in res
+        desc = (f"1 synthetic 20 s segment, B=1, bf16, FULL depth (32+28 layers, vocab 59264), {MAX_NEW} greedy tokens through torch-CPU + transformers "
+                f"generate() = the reference's DEVICE=cpu arithmetic (asr.py:393-422); worker spawned before the GPU was initialised, timed after the GPU legs; "
+                f"2 warm-ups (8 tokens) then the median of the timed full passes; {self.cores} host CPUs visible; {self.threads} threads (capped at 64; asr.py:96-101 "
+                f"would use {self.rule}, which is slower on this host): ")
+        desc += (f"runs {[round(x, 2) for x in res['runs_s']]} s, median {res['median_s']:.2f} s/segment (RTF {res['median_s'] / SEG_SECONDS:.2f}); " if ok
+                 else f"no result ({res.get('error', '?')}); ")
+        return {"value": (1.0 / res["median_s"]) if ok else None, "unit": "20s-segments/sec", "cores": self.threads, "kind": "reference",
+                "passes": len(res.get("runs_s", [])), "sample": desc + "random weights"}
+
+
+def extra_batch_run(dims, device_index: int, mode: str, B: int, max_new: int, steps: int = 2):
+    """An extra object of the N=1 line: one engine of `mode` at batch B, 1 warm-up + `steps` timed steps, PCM staged before the clock."""
+    from sonicscribe_amd import spec, synth
+    from sonicscribe_amd.engine import MODE_INT8, MODE_NATIVE, Engine
+    e = Engine(dims, device_index, MODE_INT8 if mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
+    try:
+        e.load_synthetic(20260128)
+        n_samples = SEG_SECONDS * 16000
+        prompt = [1, 17, 23, 5] + [dims.audio_token_id] * spec.audio_token_count(spec.valid_frames(n_samples)) + [7, 301, 302, 303, 9, 11]
+        e.stage_pcm([synth.synth_pcm(i, n_samples) for i in range(B)])
+        e.run_staged([prompt] * B, [max_new] * B)
+        stage = {"mel_ms": 0.0, "encoder_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.rerun_staged()
+            t = e.timings()
+            for k in stage:
+                stage[k] += t[k]
+        dt = time.perf_counter() - t0
+        d_ = dims
+        qd, kvd = d_.dec_heads * d_.dec_head_dim, d_.dec_kv_heads * d_.dec_head_dim
+        wb = 1 if mode == "int8" else 2
+        w_bytes = wb * d_.dec_layers * (d_.dec_d * (qd + 2 * kvd) + qd * d_.dec_d + 3 * d_.dec_d * d_.dec_ff) + 2 * d_.vocab * d_.dec_d
+        n_dec = max(1, max_new - 1)
+        kv_bytes = B * d_.dec_layers * 2 * kvd * 2 * (len(prompt) + (n_dec + 1) / 2.0)
+        dec_ms = stage["decode_ms"] / steps / n_dec
+        gbs = (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9
+        return {"value": B * steps / dt, "unit": "20s-segments/sec", "ms_per_step": dt / steps * 1e3, "batch": B, "mode": mode, "steps": steps,
+                "dtype": "int8" if mode == "int8" else "bf16", "stages_ms_per_step": {k: v / steps for k, v in stage.items()},
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "avg_launch_ms": dec_ms,
+                             "bytes_per_launch": w_bytes + kv_bytes, "kernel": "decode token step"},
+                "weights_mb": e.weight_bytes() / 2 ** 20}
+    finally:
+        e.close()
 
 
 def run_streaming(a):
+    print(json.dumps(streaming_measure(a)), flush=True)
+
+
+def streaming_measure(a):
     """BASELINE config 5's call pattern against one process: S concurrent sessions, each speaking for 20 s (64 ms chunks), a partial
     decode of the last 20 chunks (1.28 s, 15 tokens: audio_manager.py:106-114, transcription_manager.py:19-28) every second while
     speaking (connection_manager.py:89-92, config.py:40) and a final decode of the whole 20 s segment (150 tokens,
@@ -225,7 +276,7 @@ def run_streaming(a):
                                "step-class buckets, session -> replica)" + ("; every 64 ms wire chunk appended to the session's device ring as it "
                                "arrives (AudioStream.add_audio_chunk), decodes name chunk ranges" if ring else ""), "sessions": S, "replicas": n_rep},
     }
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
@@ -249,9 +300,14 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-timed", type=int, default=3, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=150.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-wait-go", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the multi-rank run (nccl == RCCL; gloo for boxes "
+                    "with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="ranks use device LOCAL_RANK mod device count (exercise the N-rank path on fewer GPUs; not a scaling measurement)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra objects int8_b64 / streaming / pcie_inclusive of the N=1 line")
     a = ap.parse_args()
     if a.cpu_baseline_worker:
-        _cpu_reference_worker(a.cpu_threads, a.cpu_timed, a.cpu_budget)
+        _cpu_reference_worker(a.cpu_threads, a.cpu_timed, a.cpu_budget, a.cpu_wait_go)
         return
     if a.streaming:
         run_streaming(a)
@@ -260,13 +316,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = world if world > 1 else 1
+    cpu = None
+    if n_gpus == 1 and rank == 0 and not a.no_cpu_baseline:
+        cpu = CpuBaseline()
+        cpu.start()                                      # a child process, spawned before this process initialises the GPU; it idles until collect()
     import torch
     dist = None
+    device_index = local_rank % max(1, torch.cuda.device_count()) if a.share_gpu else local_rank
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run (also at world size 1)
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
-    n_gpus = world if world > 1 else 1
+        torch.cuda.set_device(device_index)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")               # ranks sharing a GPU: RCCL cannot put two ranks on one device
 
     from sonicscribe_amd import spec, synth
     from sonicscribe_amd.engine import Engine
@@ -276,13 +340,14 @@ def main():
     dims = replace(base, eos_ids=())       # random weights: never stop early, every row does the full 150 steps
     B = a.batch
     from sonicscribe_amd.engine import MODE_INT8, MODE_NATIVE
-    eng = Engine(dims, local_rank, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
+    eng = Engine(dims, device_index, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
     eng.load_synthetic(20260128)
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
 
     lo, hi = shard_range(n_gpus * B, rank, n_gpus)           # shard g gets segments g*B .. g*B+B-1
+    print(f"[bench] rank {rank}/{n_gpus} device {device_index} backend {a.dist_backend if dist is not None else 'none'} segments [{lo}, {hi})", file=sys.stderr, flush=True)
     n_samples = SEG_SECONDS * 16000
     segs = [synth.synth_pcm(i, n_samples) for i in range(lo, hi)]
     n_audio = spec.audio_token_count(spec.valid_frames(n_samples))
@@ -309,7 +374,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if a.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ids = eng.fetch_tokens(len(segs), a.max_new)
@@ -342,8 +407,10 @@ def main():
             "dtype": "int8" if a.mode == "int8" else "bf16", "data": "synthetic",
             "rtf": 1.0 / (SEG_SECONDS * value),
             "config": {"workload": f"batch of {B} synthetic {SEG_SECONDS} s 16 kHz segments per GPU, GLM-ASR-Nano dims ({a.dims}), {a.mode}, "
-                                   f"log-mel + encoder + prefill + {a.max_new} greedy tokens, portable-PRNG weights",
-                       "segments_per_gpu": B, "max_new_tokens": a.max_new, "parallelism": f"replica x{n_gpus} (segments sharded, no collective)"},
+                                   f"log-mel + encoder + prefill + {a.max_new} greedy tokens, portable-PRNG weights; int16 PCM HBM-resident before the "
+                                   f"timed region, token ids fetched to the host after the clock stops (see pcie_inclusive for the host-to-host rate)",
+                       "segments_per_gpu": B, "max_new_tokens": a.max_new, "parallelism": f"replica x{n_gpus} (segments sharded, no collective)",
+                       "shard_of_rank0": [lo, hi], "dist_backend": (a.dist_backend if dist is not None else None), "share_gpu": bool(a.share_gpu)},
             "stages_ms_per_step": {k: stage[k] / a.steps for k in ("mel_ms", "encoder_ms", "prefill_ms", "decode_ms")},
             # The time-dominant part of a step is the greedy decode loop (~2/3 of it): every token step streams the decoder's weights,
             # the tied lm_head and each sequence's KV cache exactly once -- HBM-bound.  One "launch" here is one token step (one hipGraph
@@ -355,12 +422,15 @@ def main():
                          "bytes_per_launch": w_bytes + kv_bytes, "avg_launch_ms": dec_ms, "launches_timed": n_dec * a.steps,
                          "algorithmic_bytes": {"weights": w_bytes, "kv_cache_avg": kv_bytes}},
         }
-        try:
-            with open(os.path.join(ROOT, "profiles", "round2_pmc_decode.json")) as f:
-                pm = json.load(f)
-            out["roofline"]["traffic_from_profile"] = {k: pm[k] for k in ("hbm_bytes_per_token_step", "fetch_bytes_x2", "write_bytes", "note", "source") if k in pm}
-        except Exception:
-            pass
+        for prof in ("round3_pmc_decode.json", "round2_pmc_decode.json"):     # newest committed PMC passes; labelled with their own commit
+            try:
+                with open(os.path.join(ROOT, "profiles", prof)) as f:
+                    pm = json.load(f)
+                out["roofline"]["traffic_from_profile"] = {k: pm[k] for k in ("hbm_bytes_per_token_step", "fetch_bytes_x2", "write_bytes", "note", "source", "commit") if k in pm}
+                out["roofline"]["traffic_from_profile"]["file"] = "profiles/" + prof
+                break
+            except Exception:
+                pass
         # the other rooflines SURVEY.md 8d names:
         #   mel front-end vs HBM: 1.408 MB of algorithmic bytes per 20 s segment (int16 PCM in, bf16 features out), timed region
         #   encoder GEMMs vs MFMA: all encoder-layer GEMM launches (QKV, o, fc1, fc2) with HIP events around each, from the extra step
@@ -378,13 +448,23 @@ def main():
             gm = tg["gemm_ms"] / tg["gemm_launches"]; fl = tg["gemm_flops"] / tg["gemm_launches"]
             out["encoder_fc1_gemm"] = {"bound": "mfma", "achieved": fl / (gm * 1e-3) / 1e12, "peak": peak_mm, "unit": "TFLOP/s",
                                        "frac": fl / (gm * 1e-3) / 1e12 / peak_mm, "avg_launch_ms": gm, "flops_per_launch": fl, "launches_timed": tg["gemm_launches"]}
+        extras = n_gpus == 1 and a.dims == "full" and a.mode == "native" and B == BATCH and not a.no_extras
+        if extras:
+            # host-to-host rate of the same batch through the one-call boundary (sonic_transcribe_batch: H2D of the int16 PCM, the device
+            # work, D2H of the ids) - never the headline `value`
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                eng.transcribe_batch(segs, [prompt] * len(segs), [a.max_new] * len(segs))
+            d1 = time.perf_counter() - t1
+            out["pcie_inclusive"] = {"value": B * a.steps / d1, "unit": "20s-segments/sec", "ms_per_step": d1 / a.steps * 1e3,
+                                     "note": "sonic_transcribe_batch host buffers in, host ids out (32 x 640 kB of PCM over PCIe per step); not the headline"}
         if n_gpus == 1 and not a.no_two_chains and a.dims == "full":
             # Not the headline (BASELINE's config is one batch of 32 at a time): how much of the decode loop's loss is latency that a
             # second, independent batch in flight on the same GPU fills.  A second engine with its own staged batch; both step K times
             # from two threads (ctypes releases the GIL).  DESIGN.md section 4.
             import threading
             try:
-                eng2 = Engine(dims, local_rank, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
+                eng2 = Engine(dims, device_index, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
                 eng2.load_synthetic(20260128)
                 eng2.stage_pcm([synth.synth_pcm(1000 + i, n_samples) for i in range(B)])
                 eng2.run_staged([prompt] * B, [a.max_new] * B)
@@ -400,13 +480,31 @@ def main():
                 eng2.close()
             except Exception as ex:
                 out["two_batches_in_flight"] = {"value": None, "note": f"not measured: {ex!r}"}
-        if n_gpus == 1 and not a.no_cpu_baseline:
+        if extras:
+            eng.close(); eng = None
+            # BASELINE config 4 (the repo's INT8 option, batch 64) and the bf16 batch-64 figure it has to beat, same process, same box
             try:
-                out["cpu_baseline"] = cpu_reference_baseline()
+                out["int8_b64"] = extra_batch_run(dims, device_index, "int8", 64, a.max_new, steps=2)
+                out["bf16_b64"] = extra_batch_run(dims, device_index, "native", 64, a.max_new, steps=2)
+            except Exception as ex:
+                out["int8_b64"] = {"value": None, "note": f"not measured: {ex!r}"}
+            # BASELINE config 5's call pattern at its per-GPU share (128 sessions / 8 GPUs = 16), real-time schedule, device-resident ingest
+            try:
+                sa = argparse.Namespace(dims="full", sessions=16, gpus=1, replicas_per_gpu=1, mode="native", batch=BATCH, ingest="ring")
+                st = streaming_measure(sa)
+                out["streaming"] = {k: st[k] for k in ("sessions", "partial_latency_ms", "final_latency_ms", "value", "unit", "wall_s", "ingest", "device_batches_per_replica")}
+                out["streaming"]["note"] = ("BASELINE config 5 call pattern: 16 sessions (128 / 8 GPUs) x (64 ms chunks into device rings, 1 s partials of 1.28 s / 15 "
+                                            "tokens, one 20 s final / 150 tokens), real-time schedule through ASRModel.submit(); latency = submit -> transcript")
+            except Exception as ex:
+                out["streaming"] = {"value": None, "note": f"not measured: {ex!r}"}
+        if cpu is not None:
+            try:
+                out["cpu_baseline"] = cpu.collect()
             except Exception as ex:   # transformers missing on the box: report that rather than a wrong number
                 out["cpu_baseline"] = {"value": None, "unit": "20s-segments/sec", "cores": 0, "kind": "reference", "sample": f"unavailable: {ex!r}"}
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -20,6 +20,13 @@
  *   sonic_logmel               WhisperFeatureExtractor.__call__ as invoked from asr.py:393
  *                              (HF:feature_extraction_whisper.py:193-346)
  *   sonic_encode               GlmAsrModel.get_audio_features             HF:modeling_glmasr.py:380-408
+ *   sonic_prefill / sonic_decode_step
+ *                              the two halves of model.generate: the prompt forward (logits_to_keep = 1,
+ *                              HF:generation/utils.py:2612-2616) and iterations of the greedy loop (:2876-2943)
+ *   sonic_device_info          torch.version.cuda / torch.cuda.get_device_name() / get_device_properties(0).total_memory
+ *                              in ASRModel.get_model_info                   asr.py:501-506
+ *   sonic_memory_info          torch.cuda.memory_allocated() / memory_reserved() in the debug dict  asr.py:453-457
+ *   sonic_release_pool         torch.cuda.empty_cache() after `del asr_model.model`  backend/main.py:84-90
  *   sonic_destroy              `del asr_model.model`                      backend/main.py:84-86
  *   sonic_last_error           the exception text re-raised at            asr.py:469-481
  */
@@ -76,6 +83,15 @@ int sonic_device_count(void);
 int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out);
 void sonic_destroy(sonic_engine* e);
 const char* sonic_last_error(sonic_engine* e); /* e may be NULL: error of the last failed sonic_create on this thread */
+/* name (NUL-terminated, truncated to name_cap), total / currently free device memory, hipRuntimeGetVersion(); any output may be NULL */
+int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_bytes, int64_t* free_bytes, int32_t* hip_runtime_version);
+/* allocated: bytes of this engine's live device allocations; reserved: allocated + the uncached blocks destroyed engines left in the
+ * process-wide pool of this engine's device (sonic_destroy parks them, the next engine that needs the same size takes them) */
+int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes);
+/* frees the pooled uncached blocks of device_id (< 0: every device) after a device synchronise and a system-scope cache write-back +
+ * invalidate; returns the bytes freed, 0 while an engine is still alive on the device.  sonic_destroy calls it for its device when it
+ * destroys the last engine there, so a model reload with other sizes does not keep the old KV cache / weight copies. */
+int64_t sonic_release_pool(int device_id);
 
 /* ---- weights (names: GlmAsrForConditionalGeneration.state_dict() keys, see sonicscribe_amd/spec.py) ---- */
 int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
@@ -107,6 +123,13 @@ int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets,
 int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                      const int32_t* max_new, int want_step_logits);
 int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+/* stage entry points: sonic_run_staged = sonic_prefill + sonic_decode_step(max(max_new) - 1).  sonic_prefill runs log-mel, encoder,
+ * projector, decoder prefill and emits the first token of every request; sonic_decode_step runs up to n_steps further greedy steps
+ * (*steps_done_out of them: fewer once the largest budget is reached or every row stopped) and reports the rows still running.
+ * sonic_fetch_tokens may be called after either. */
+int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                  const int32_t* max_new, int want_step_logits);
+int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32_t* steps_done_out);
 /* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as
  * 2048-byte chunks in a host dict (backend/audio_manager.py:21-33, fed from backend/main.py:813-842) and concatenates on the host for
  * every partial / final decode (audio_manager.py:99-123).  A decode names sample ranges of rings instead of handing over host buffers;

@@ -27,7 +27,7 @@ import numpy as np
 
 from . import frontend
 from .dispatch import Dispatcher
-from .engine import Engine, MODE_INT8, MODE_NATIVE, SonicError, device_count
+from .engine import Engine, MODE_INT8, MODE_NATIVE, SonicError, device_count, device_info
 from .spec import FULL, ModelDims
 
 
@@ -275,9 +275,10 @@ class ASRModel:
             elapsed = time.time() - t0
             if return_debug_info:
                 n = audio_tensor.shape[-1] if hasattr(audio_tensor, "shape") else len(audio_tensor)
+                alloc, reserved = self.model.memory_info()           # asr.py:453-457: allocator state, not the weight size
                 return {"transcript": transcript, "processing_time": elapsed, "audio_length_sec": n / sampling_rate,
                         "mode": self.mode, "device": str(self.device),
-                        "gpu_memory_allocated_mb": self.model.weight_bytes() / 1024 ** 2, "gpu_memory_reserved_mb": self.model.weight_bytes() / 1024 ** 2}
+                        "gpu_memory_allocated_mb": alloc / 1024 ** 2, "gpu_memory_reserved_mb": reserved / 1024 ** 2}
             return transcript
         except RuntimeError as e:
             if "out of memory" in str(e).lower():
@@ -306,9 +307,17 @@ class ASRModel:
         return [self.prompt.decode(i).strip() for i in ids]
 
     def get_model_info(self) -> Dict[str, Any]:
-        return {"mode": self.mode, "device": str(self.device), "model_dtype": "torch." + self.model_dtype, "target_sampling_rate": self.target_sr,
-                "checkpoint_dir": str(self.checkpoint_dir), "is_glm_asr": self.is_glm_asr, "engine": "sonicscribe_amd/gfx950",
-                "gpu_name": "AMD Instinct MI355X", "replicas": len(self.__dict__.get("models", [])), "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0}
+        """asr.py:490-513: the reference's keys for a GPU device (`cuda_version` carries the HIP runtime version: torch.version.cuda is
+        the toolkit the reference's torch was built with), plus `engine`, `replicas`, `weights_mb`."""
+        info = {"mode": self.mode, "device": str(self.device), "model_dtype": "torch." + self.model_dtype, "target_sampling_rate": self.target_sr,
+                "checkpoint_dir": str(self.checkpoint_dir), "is_glm_asr": self.is_glm_asr}
+        di = device_info(self.device_index)
+        v = di["hip_runtime_version"]
+        info.update({"cuda_version": f"HIP {v // 10000000}.{(v // 100000) % 100}.{v % 100000}", "gpu_name": di["name"],
+                     "gpu_memory_total_mb": di["total_bytes"] / 1024 ** 2})
+        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])),
+                     "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0})
+        return info
 
     def close(self):
         c = self.__dict__.pop("_dispatcher", None)

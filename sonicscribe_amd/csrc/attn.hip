@@ -248,6 +248,7 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 
 // ------------------------------------------------------------------------------------------------
 
+// Round-2 form of the decode attention (P.V on the VALU), kept for A/B runs (option "decode_attn_v1").
 // HD = 128, group size G = Hq/Hkv <= 4.  One block (8 waves) per (sequence, kv head).
 //  0. the first 16-key slice of K and V of every wave is requested before anything else (addresses do not depend on kv_len:
 //     rows are clamped to the cache and masked later), so its HBM latency overlaps the prologue;
@@ -261,7 +262,7 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 //  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
 // Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
 template <typename T>
-__global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
+__global__ __launch_bounds__(512) void decode_attn_v1_kernel(DecodeAttnArgs a) {
     typedef typename ET<T>::v8 V8;
     constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
     __shared__ float s_acc[NW][GMAX][HD];
@@ -433,6 +434,211 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     KT(a, 4);
 }
 
+// 16x16x16 MFMA on the engine's 16-bit element type (the P.V product of the decode attention: 16 keys per step)
+template <typename T> struct PV16;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+template <> struct PV16<bf16_t> {
+    static __device__ __forceinline__ f32x4 mfma(u32x2_t a, u32x2_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct PV16<f16_t> {
+    static __device__ __forceinline__ f32x4 mfma(u32x2_t a, u32x2_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+    }
+};
+
+// HD = 128, group size G = Hq/Hkv <= 4.  One block (8 waves) per (sequence, kv head).
+//  0. the first 16-key slice of K and V of every wave is requested before anything else (addresses do not depend on kv_len:
+//     rows are clamped to the cache and masked later), so its HBM latency overlaps the prologue;
+//  1. prologue (fused RoPE + KV append, modeling_llama.py:121-143,261-262): sums the QKV skinny-GEMM slabs of this
+//     (sequence, kv head), rounds to bf16, applies rotate-half RoPE at the token's position, writes the new K / V rows
+//     into the cache and keeps q (4 heads), k, v in LDS;
+//  2. single pass over the cached keys, 16 keys per wave-iteration (next slice prefetched into registers), BOTH products on the
+//     matrix pipe:
+//       S^T[key][head] = K.q^T   4 x v_mfma_f32_16x16x32 (a K row piece per lane IS the A fragment; the q heads sit on 4 of the 16 B
+//                                columns).  D layout: lane (r, g) holds head r, keys 4g .. 4g+3;
+//       O[head][hd]   += P.V     8 x v_mfma_f32_16x16x16: the A fragment of lane (r, g) is P[head r][keys 4g .. 4g+3] - exactly the
+//                                probabilities that lane just computed, no exchange; the B fragment of tile t is V[keys 4g .. 4g+3][hd
+//                                8r + t]: every lane loads the 16-byte piece r of its four key rows (full 256-byte rows per instruction,
+//                                as before) and tile t takes element t of each piece (two v_perm_b32 per tile), i.e. tile t covers
+//                                the head-dim columns {8n + t}.
+//     Round 2 did P.V on the VALU (128 FMAs + 32 converts per lane and slice, probabilities handed over through LDS): the key loop was
+//     VALU-bound at 0.9 us per slice (in-kernel timeline, profiles/round2_decode_timeline.txt).
+//  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
+// Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
+template <typename T>
+__global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
+    typedef typename ET<T>::v8 V8;
+    constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
+    __shared__ __attribute__((aligned(16))) float s_acc[NW][GMAX][HD];
+    __shared__ float s_m[NW][GMAX], s_l[NW][GMAX];
+    __shared__ __attribute__((aligned(16))) T s_q[GMAX + 2][HD];   // q heads (unscaled), then k, v of the new token (all T values)
+    const int G = a.Hq / a.Hkv;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;                        // S: head column r, keys 4g..4g+3;  K rows: key r, dim chunk g;  V: piece r of keys 4g..4g+3
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    T* Kc = (T*)a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    T* Vc = (T*)a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
+    const int cm1 = a.ctx_max - 1;
+
+    KT(a, 0);
+    V8 kf[4], vv[4], kfn[4], vvn[4];
+    auto load = [&](int k0, V8 (&kd)[4], V8 (&vd)[4]) {
+        const int kr = min(k0 + r, cm1);
+#pragma unroll
+        for (int hs = 0; hs < 4; ++hs) kd[hs] = *(const V8*)(Kc + (long)kr * HD + hs * 32 + g * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vd[j] = *(const V8*)(Vc + (long)min(k0 + 4 * g + j, cm1) * HD + r * 8);
+    };
+    load(wid * 16, kf, vv);
+
+    int n;                                   // keys visible, the new token included at position n-1
+    if (a.P) {
+        // QKV slab sum of this (segment, kv head): issued before kv_len is needed, so the two latencies overlap
+        const int N = (a.Hq + 2 * a.Hkv) * HD;
+        const int w = tid, vi = w / HALF, i = w % HALF;      // vector (q heads.., k, v), index in the first half; (G + 2) * 64 <= 384 threads
+        const bool act = w < (G + 2) * HALF;
+        float x1 = 0.f, x2 = 0.f;
+        if (act) {
+            const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
+            if (a.dq.sca) {
+                // int8 mode: int32 slabs of the quantised q/k/v projections -> fp16 module outputs (LLM.int8 dequant + outliers)
+                x1 = deq1(a.dq, a.P, a.ksplit, a.mpad, b, col, N); x2 = deq1(a.dq, a.P, a.ksplit, a.mpad, b, col + HALF, N);
+            } else {
+                // all slab loads in flight at once (a rolled loop would serialise one L2 round trip per slab); fixed summation order
+                float v1[8], v2[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const float* p = a.P + ((long)(ks < a.ksplit ? ks : 0) * a.mpad + b) * N + col;
+                    v1[ks] = p[0]; v2[ks] = p[HALF];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    if (ks < a.ksplit) { x1 += v1[ks]; x2 += v2[ks]; }
+            }
+        }
+        n = min(max(a.kv_len[b], 1), a.ctx_max);      // (clamped: the cache / RoPE table rows of this block end at ctx_max)
+        if (act) {
+            const int pos = n - 1;
+            x1 = rT<T>(x1); x2 = rT<T>(x2);
+            float o1 = x1, o2 = x2;
+            if (vi <= G) {
+                const float c = a.cs[(long)pos * HD + i], sn = a.cs[(long)pos * HD + HALF + i];
+                o1 = rT<T>(rT<T>(x1 * c) + rT<T>(-x2 * sn));
+                o2 = rT<T>(rT<T>(x2 * c) + rT<T>(x1 * sn));
+            }
+            const int row = vi < G ? vi : (vi == G ? GMAX : GMAX + 1);
+            const T b1 = (T)o1, b2 = (T)o2;
+            s_q[row][i] = b1; s_q[row][HALF + i] = b2;
+            if (vi == G) { Kc[(long)pos * HD + i] = b1; Kc[(long)pos * HD + HALF + i] = b2; }
+            if (vi == G + 1) { Vc[(long)pos * HD + i] = b1; Vc[(long)pos * HD + HALF + i] = b2; }
+        }
+        __syncthreads();
+    } else {
+        n = min(max(a.kv_len[b], 1), a.ctx_max);
+    }
+    KT(a, 1);
+    // q as the MFMA B operand: column r = head (zero beyond the group), k = head-dim
+    V8 qf[4];
+#pragma unroll
+    for (int hs = 0; hs < 4; ++hs) {
+        const V8 t = a.P ? *(const V8*)&s_q[r < G ? r : 0][hs * 32 + g * 8]
+                         : *(const V8*)((const T*)a.Q + (long)b * a.Hq * HD + (kvh * G + (r < G ? r : 0)) * HD + hs * 32 + g * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[hs][j] = r < G ? t[j] : (T)0.f;
+    }
+    float m_r = -1e30f, lsum = 0.f;          // running max / partial row sum of head r over this lane's keys
+    f32x4 acc[8];                            // O tiles: acc[t][j] = head 4g + j (real heads: g == 0), head-dim column 8r + t
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int k0, const V8 (&kd)[4], const V8 (&vd)[4], int limit) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hs = 0; hs < 4; ++hs) st = ET<T>::mfma(kd[hs], qf[hs], st);
+        float sc[4], mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = (k0 + g * 4 + j) < limit ? st[j] * a.scale : -1e30f; mx = fmaxf(mx, sc[j]); }
+        mx = rows_max(mx);                                   // over the four key quarters: the slice maximum of head r, in every lane of column r
+        const float mn = fmaxf(m_r, mx);
+        const float alpha = __expf(m_r - mn);
+        m_r = mn;
+        float ps = 0.f, pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float pv = ((k0 + g * 4 + j) < limit && r < G) ? __expf(sc[j] - mn) : 0.f; ps += pv; pr[j] = pv; }
+        lsum = lsum * alpha + ps;
+        u32x2_t pa;                                          // A fragment: P[head r][keys 4g..4g+3], rounded to T
+        {
+            typename ET<T>::v4 p4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p4[j] = (T)pr[j];
+            pa = __builtin_bit_cast(u32x2_t, p4);
+        }
+        // rescale the accumulators: row j of a tile is head j, whose factor sits in lane j (column j, first key quarter)
+        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), 0));
+        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), 1));
+        const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), 2));
+        const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), 3));
+        const unsigned* w0 = (const unsigned*)&vd[0]; const unsigned* w1 = (const unsigned*)&vd[1];
+        const unsigned* w2 = (const unsigned*)&vd[2]; const unsigned* w3 = (const unsigned*)&vd[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // tiles 2i (low halves of dword i of the four pieces) and 2i + 1 (high halves): B fragment = element t of keys 4g..4g+3
+            u32x2_t blo, bhi;
+            blo[0] = __builtin_amdgcn_perm(w1[i], w0[i], 0x05040100u); blo[1] = __builtin_amdgcn_perm(w3[i], w2[i], 0x05040100u);
+            bhi[0] = __builtin_amdgcn_perm(w1[i], w0[i], 0x07060302u); bhi[1] = __builtin_amdgcn_perm(w3[i], w2[i], 0x07060302u);
+            f32x4 c0 = acc[2 * i], c1 = acc[2 * i + 1];
+            c0[0] *= a0; c0[1] *= a1; c0[2] *= a2; c0[3] *= a3;
+            c1[0] *= a0; c1[1] *= a1; c1[2] *= a2; c1[3] *= a3;
+            acc[2 * i] = PV16<T>::mfma(pa, blo, c0);
+            acc[2 * i + 1] = PV16<T>::mfma(pa, bhi, c1);
+        }
+    };
+    const int nc = a.P ? n - 1 : n;          // keys read from the cache
+    for (int k0 = wid * 16; k0 < nc; k0 += NW * 16) {
+        const bool more = k0 + NW * 16 < nc;
+        if (more) load(k0 + NW * 16, kfn, vvn);
+        step(k0, kf, vv, nc);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { kf[u] = kfn[u]; vv[u] = vvn[u]; }
+        }
+    }
+    if (a.P && wid == NW - 1) {              // the token being decoded: its k / v are still in LDS (slice key 0 only); the last wave has
+                                             // the fewest cached slices (slices go round-robin from wave 0), so it takes the extra step
+#pragma unroll
+        for (int hs = 0; hs < 4; ++hs) kf[hs] = *(const V8*)&s_q[GMAX][hs * 32 + g * 8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] = *(const V8*)&s_q[GMAX + 1][r * 8];
+        step(0, kf, vv, 1);
+    }
+    KT(a, 2);
+    // merge: per wave the row sums over the 4 key quarters (the outputs are already summed over the keys by the MFMA); then the 8 waves
+    lsum = rows_sum(lsum);
+    if (g == 0 && r < 4) { s_l[wid][r] = lsum; s_m[wid][r] = m_r; }
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)&s_acc[wid][j][8 * r] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+            *(f32x4*)&s_acc[wid][j][8 * r + 4] = (f32x4){acc[4][j], acc[5][j], acc[6][j], acc[7][j]};
+        }
+    }
+    __syncthreads();
+    KT(a, 3);
+    for (int idx = tid; idx < G * HD; idx += 512) {
+        const int h = idx / HD, e = idx % HD;
+        float M = -1e30f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][h]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][h] - M); num += f * s_acc[w][h][e]; den += f * s_l[w][h]; }
+        ((T*)a.O)[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = (T)(num / den);
+    }
+    KT(a, 4);
+}
+
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {
+    if (g_opts.decode_attn_v1) { DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_v1_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a)); return; }
     DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a));
 }

@@ -59,6 +59,7 @@ struct LaunchOpts {
     int gemm_force128 = 0;     // route every GEMM to the 128x128 kernel
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
+    int decode_attn_v1 = 0;    // decode attention with P.V on the VALU (round 2), for A/B runs
 };
 extern thread_local LaunchOpts g_opts;
 

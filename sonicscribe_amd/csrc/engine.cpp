@@ -46,8 +46,8 @@ struct sonic_engine {
     std::string err;
     std::vector<void*> allocs;
     std::vector<std::pair<void*, size_t>> uc_allocs;     // uncached blocks: returned to the process-wide pool, never to hipFree
-    int64_t weight_bytes = 0;
-    bool finalized = false;
+    int64_t weight_bytes = 0, alloc_bytes = 0;      // alloc_bytes: every live device allocation of this engine (sonic_memory_info)
+    bool finalized = false, registered = false;
 
     std::map<std::string, DevTensor> raw;
     // packed weights
@@ -90,7 +90,7 @@ struct sonic_engine {
     float* dump = nullptr; size_t dump_cap = 0; int dump_steps = 0;
     bf16_t* taps = nullptr; int taps_on = 0; int last_ntok = 0;   // debug: prefill hidden states after embedding + each layer
     int* n_active_h = nullptr;  // pinned
-    int R = 0, max_steps = 0, greedy_calls = 0;
+    int R = 0, max_steps = 0, greedy_calls = 0, steps_run = 0; bool run_logits = false;   // state of the staged batch between the stage entry points
     int* force_d = nullptr; int force_ld = 0, force_R = 0;   // teacher forcing for the next runs (sonic_set_forced_ids)
     std::vector<int> last_qlen, last_maxnew;
     std::map<int, hipGraphExec_t> graphs;
@@ -154,7 +154,7 @@ template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool
     void* q = nullptr;
     const size_t bytes = ((n ? n : 1) * sizeof(Tt) + 3) / 4 * 4;
     HIPC(e, hipMalloc(&q, bytes));
-    e->allocs.push_back(q);
+    e->allocs.push_back(q); e->alloc_bytes += (int64_t)bytes;
     if (zero) zero_fill(e, q, bytes);
     *p = (Tt*)q;
     return SONIC_OK;
@@ -172,6 +172,13 @@ template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool
 // A production process creates its engines once, so it never recycled; the pool makes the test processes safe as well.
 static std::mutex g_uc_mu;
 static std::multimap<std::pair<int, size_t>, void*> g_uc_pool;
+static std::map<int, int> g_live_engines;                      // engines alive per device (under g_uc_mu)
+static int64_t uc_pooled_bytes(int dev) {
+    std::lock_guard<std::mutex> lk(g_uc_mu);
+    int64_t b = 0;
+    for (auto& it : g_uc_pool) if (it.first.first == dev) b += (int64_t)it.first.second;
+    return b;
+}
 static void* uc_take(int dev, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_uc_mu);
     auto it = g_uc_pool.find({dev, bytes});
@@ -179,13 +186,46 @@ static void* uc_take(int dev, size_t bytes) {
     void* p = it->second; g_uc_pool.erase(it); return p;
 }
 static void uc_give(int dev, size_t bytes, void* p) { std::lock_guard<std::mutex> lk(g_uc_mu); g_uc_pool.insert({{dev, bytes}, p}); }
+// System-scope release + acquire on every CU: writes back and invalidates the vector caches and every XCD's L2, so no cache holds a line
+// (clean or dirty) of memory that is about to change owner and cacheability.
+__global__ void cache_flush_kernel() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, ""); }
+// Frees the pooled uncached blocks of a device (dev < 0: all).  Only while no engine lives there: the blocks of a live engine are not in
+// the pool, but a purge in the middle of another engine's run would put a device synchronise into it.
+extern "C" int64_t sonic_release_pool(int device_id) {
+    std::vector<std::pair<int, void*>> blocks;
+    int64_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_uc_mu);
+        for (auto it = g_uc_pool.begin(); it != g_uc_pool.end();) {
+            const int dev = it->first.first;
+            if ((device_id < 0 || dev == device_id) && g_live_engines[dev] <= 0) { blocks.push_back({dev, it->second}); bytes += (int64_t)it->first.second; it = g_uc_pool.erase(it); }
+            else ++it;
+        }
+    }
+    if (blocks.empty()) return 0;
+    int cur = 0; (void)hipGetDevice(&cur);
+    int last = -1;
+    for (auto& b : blocks) {
+        if (b.first != last) {
+            (void)hipSetDevice(b.first);
+            (void)hipDeviceSynchronize();
+            hipLaunchKernelGGL(cache_flush_kernel, dim3(4096), dim3(64), 0, 0);
+            (void)hipDeviceSynchronize();
+            last = b.first;
+        }
+        (void)hipFree(b.second);
+    }
+    (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    return bytes;
+}
 template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
     const size_t bytes = ((n ? n : 1) * sizeof(Tt) + 3) / 4 * 4;
     void* q = getenv("SONIC_NO_UC") ? nullptr : uc_take(e->device, bytes);
     if (!q) {
         if (getenv("SONIC_NO_UC") || hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return dalloc(e, p, n, zero); }
     }
-    e->uc_allocs.push_back({q, bytes});
+    e->uc_allocs.push_back({q, bytes}); e->alloc_bytes += (int64_t)bytes;
     if (zero) zero_fill(e, q, bytes);
     *p = (Tt*)q;
     return SONIC_OK;
@@ -193,7 +233,9 @@ template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, b
 template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) { return dalloc_uc(e, p, n, true); }
 #define TRY(x) do { int _s = (x); if (_s != SONIC_OK) return _s; } while (0)
 // every locked C-ABI entry: serialise on the engine, select its device, and hand its experiment knobs to the launchers
-#define ENTER(e) std::lock_guard<std::mutex> lk((e)->mu); HIPC(e, hipSetDevice((e)->device)); g_opts = (e)->opts
+// (hipGetLastError first: the slot is per thread and sticky, so a failure some earlier call of this thread ignored would otherwise
+// surface at this call's closing hipGetLastError check)
+#define ENTER(e) std::lock_guard<std::mutex> lk((e)->mu); (void)hipGetLastError(); HIPC(e, hipSetDevice((e)->device)); g_opts = (e)->opts
 
 static inline float bf16_round_host(float x) {
     uint32_t u; memcpy(&u, &x, 4);
@@ -452,6 +494,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
 #undef A
     e->n_samples_h.assign(Bm, 0);
     if (hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; return bail(SONIC_ERR_HIP); }
+    { std::lock_guard<std::mutex> lk(g_uc_mu); g_live_engines[device_id] += 1; e->registered = true; }
     *out = e;
     return SONIC_OK;
 }
@@ -466,6 +509,8 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& u : e->uc_allocs) uc_give(e->device, u.second, u.first);
+    bool last_on_device = false;
+    if (e->registered) { std::lock_guard<std::mutex> lk(g_uc_mu); last_on_device = --g_live_engines[e->device] <= 0; }
     if (e->dump) (void)hipFree(e->dump);
     if (e->force_d) (void)hipFree(e->force_d);
     if (e->taps) (void)hipFree(e->taps);
@@ -474,7 +519,12 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
     if (e->st) (void)hipStreamDestroy(e->st);
+    const int dev = e->device;
     delete e;
+    // The last engine of a device hands its uncached blocks back (`del asr_model.model` + torch.cuda.empty_cache(), main.py:84-90): a model
+    // reload with other sizes must not keep the old KV cache and weight copies.  While another engine lives on the device the blocks stay
+    // pooled for reuse.  SONIC_KEEP_POOL=1 keeps round 2's behaviour (never hipFree an uncached block).
+    if (last_on_device && !getenv("SONIC_KEEP_POOL")) (void)sonic_release_pool(dev);
 }
 
 extern "C" int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n) {
@@ -495,6 +545,35 @@ extern "C" int sonic_synchronize(sonic_engine* e) {
     return SONIC_OK;
 }
 
+// what ASRModel.get_model_info() reads from torch.cuda (asr.py:501-506: version, device name, total memory) ...
+extern "C" int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_bytes, int64_t* free_bytes, int32_t* hip_runtime_version) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { (void)hipGetLastError(); return fail(nullptr, SONIC_ERR_INVALID, "device %d not available", device_id); }
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device_id) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, SONIC_ERR_HIP, "hipGetDeviceProperties failed"); }
+    if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s", pr.name); }
+    if (total_bytes) *total_bytes = (int64_t)pr.totalGlobalMem;
+    if (free_bytes) {
+        size_t fr = 0, tot = 0; int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (hipSetDevice(device_id) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
+        (void)hipSetDevice(cur);
+        *free_bytes = (int64_t)fr;
+    }
+    if (hip_runtime_version) { int v = 0; if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; } *hip_runtime_version = v; }
+    return SONIC_OK;
+}
+// ... and what the debug dict of transcribe() reads from the caching allocator (asr.py:453-457): allocated = bytes in this engine's live
+// device allocations (weights, activations, KV cache, rings excluded), reserved = allocated + the uncached blocks parked in the process-wide
+// pool of its device (held by the process, handed to the next engine that asks for the same size)
+extern "C" int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (allocated_bytes) *allocated_bytes = e->alloc_bytes;
+    if (reserved_bytes) *reserved_bytes = e->alloc_bytes + uc_pooled_bytes(e->device);
+    return SONIC_OK;
+}
+
 // ------------------------------------------------------------------------------------------ weights
 static int raw_alloc(sonic_engine* e, const std::string& name, const std::vector<int64_t>& shape, DevTensor** out) {
     DevTensor& t = e->raw[name];
@@ -502,7 +581,7 @@ static int raw_alloc(sonic_engine* e, const std::string& name, const std::vector
         t.shape = shape; t.n = numel(shape);
         void* q = nullptr;
         HIPC(e, hipMalloc(&q, t.n * sizeof(bf16_t)));
-        t.p = (bf16_t*)q;
+        t.p = (bf16_t*)q; e->alloc_bytes += (int64_t)(t.n * sizeof(bf16_t));
     } else if (t.shape != shape) return fail(e, SONIC_ERR_INVALID, "tensor %s loaded twice with different shapes", name.c_str());
     *out = &t;
     return SONIC_OK;
@@ -575,7 +654,7 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
     }
     HIPC(e, hipStreamSynchronize(e->st));
     for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w16) { e->allocs.erase(it); break; }
-    (void)hipFree(*w16); *w16 = nullptr;
+    (void)hipFree(*w16); *w16 = nullptr; e->alloc_bytes -= (int64_t)N * K * 2;
     return SONIC_OK;
 }
 // concatenate row blocks of [rows_i][K] tensors
@@ -678,7 +757,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
     e->weight_bytes += (int64_t)d.vocab * d.dec_d * 2;
     TRY(to_f32(e, lm + "norm.weight", &e->dec_nw));
     HIPC(e, hipStreamSynchronize(e->st));
-    for (auto& kv : e->raw) if (kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; }
+    for (auto& kv : e->raw) if (kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; e->alloc_bytes -= (int64_t)kv.second.n * 2; }
     e->raw.clear();
     e->finalized = true;
     return SONIC_OK;
@@ -1040,8 +1119,9 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     return SONIC_OK;
 }
 
-static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
-                   const int32_t* max_new, bool want_logits) {
+// log-mel -> encoder -> projector -> prefill -> first greedy token (generation/utils.py:2612-2616, 2876-2943 for the first step)
+static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                              const int32_t* max_new, bool want_logits) {
     const sonic_dims& d = e->d;
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
     if (e->W < 1) return fail(e, SONIC_ERR_INVALID, "no PCM staged");
@@ -1060,6 +1140,7 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
         }
         e->dump_steps = hp.max_steps;
     } else e->dump_steps = 0;
+    e->run_logits = want_logits;
 
     (void)hipEventRecord(e->ev[0], e->st);
     TRY(run_mel(e, e->W, false));
@@ -1077,11 +1158,20 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     TRY(run_prefill(e, R, hp));
     launch_greedy(greedy_args(e, R, want_logits), e->st);
     (void)hipEventRecord(e->ev[3], e->st);
+    e->steps_run = 0;
+    e->greedy_calls = 1;
+    return SONIC_OK;
+}
 
-    // ---- decode loop: hipGraph replay of one captured step
+// up to n_steps further token steps of the staged batch: hipGraph replay of one captured step (eager under teacher forcing / when the
+// step logits are wanted).  Stops early once every row hit EOS / its budget (checked every 16 steps, as the free-running loop always did).
+static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
+    const int R = e->R, left = e->max_steps - 1 - e->steps_run;
+    if (n_steps > left) n_steps = left;
+    const bool want_logits = e->run_logits;
     const bool use_graph = !want_logits && !e->opt_no_graph && !e->force_d;
     hipGraphExec_t gx = nullptr;
-    if (use_graph && hp.max_steps > 1) {
+    if (use_graph && n_steps > 0) {
         auto it = e->graphs.find(R);
         if (it == e->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -1093,16 +1183,27 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
             e->graphs[R] = gx;
         } else gx = it->second;
     }
-    int steps_done = 0;
-    for (int s = 1; s < hp.max_steps; ++s) {
+    int done = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const int s = e->steps_run + 1;                  // index of the token this step produces (token 0 came out of prefill)
         if (gx) HIPC(e, hipGraphLaunch(gx, e->st)); else decode_step(e, R, want_logits);
-        ++steps_done;
-        if ((s & 15) == 0 && s + 1 < hp.max_steps) {   // ragged termination: stop once every row hit EOS / its budget
+        ++done; ++e->steps_run; ++e->greedy_calls;
+        if ((s & 15) == 0 && s + 1 < e->max_steps) {   // ragged termination: stop once every row hit EOS / its budget
             HIPC(e, hipMemcpyAsync(e->n_active_h, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
             HIPC(e, hipStreamSynchronize(e->st));
-            if (*e->n_active_h <= 0) break;
+            if (*e->n_active_h <= 0) { e->steps_run = e->max_steps - 1; break; }
         }
     }
+    if (done_out) *done_out = done;
+    return SONIC_OK;
+}
+
+static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                   const int32_t* max_new, bool want_logits) {
+    const sonic_dims& d = e->d;
+    TRY(run_to_first_token(e, req_win, R, prompt_ids, prompt_off, max_new, want_logits));
+    int steps_done = 0;
+    TRY(run_decode_steps(e, e->max_steps - 1, &steps_done));
     (void)hipEventRecord(e->ev[4], e->st);
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
@@ -1122,7 +1223,6 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
         t.enc_gemm_flops += 2.0 * MT * C * (3 * C) + 2.0 * MT * C * C + 4.0 * MT * F * C;      // QKV, o, fc1, fc2
     }
     t.decode_steps = steps_done;
-    e->greedy_calls = 1 + steps_done;
     return SONIC_OK;
 }
 
@@ -1212,7 +1312,17 @@ extern "C" int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, i
     std::lock_guard<std::mutex> lk(r->mu);
     if (n > r->cap) return SONIC_ERR_INVALID;
     if (hipSetDevice(r->e->device) != hipSuccess) return SONIC_ERR_HIP;
-    if (r->read_pending) { (void)hipStreamWaitEvent(r->st, r->read_ev, 0); r->read_pending = false; }   // do not overwrite what a staging kernel still reads
+    if (r->read_pending) {                                                                                 // do not overwrite what a staging kernel still reads
+        // The runtime refuses this wait ("dependency created on uncaptured work in another stream") while the engine's thread is
+        // capturing its decode graph on the stream the event was recorded on, although the record itself preceded the capture.  The
+        // staging kernels are microseconds long: wait for the event on the host then, and leave no sticky error behind for this
+        // thread's next call (found by tests/test_gpu_sessions.py: the stale error failed an unrelated engine call later on).
+        if (hipStreamWaitEvent(r->st, r->read_ev, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipEventSynchronize(r->read_ev) != hipSuccess) { (void)hipGetLastError(); return SONIC_ERR_HIP; }
+        }
+        r->read_pending = false;
+    }
     const int64_t pos = r->head % r->cap, first = n < r->cap - pos ? n : r->cap - pos;
     // A mirror slot is rewritten one full capacity later (30 s of audio), normally long after its copy has left; the stream is
     // drained before an append could overwrite samples whose copy has not been waited for (small rings, bursts).
@@ -1262,7 +1372,10 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
                 if (n < 0 || n > cap || st < 0 || st + n > rg->head || st < rg->head - rg->cap)
                     return fail(e, SONIC_ERR_INVALID, "window %d: samples [%lld, %lld) are not in the ring (holds [%lld, %lld))", w, (long long)st, (long long)(st + n),
                                 (long long)(rg->head > rg->cap ? rg->head - rg->cap : 0), (long long)rg->head);
-                if (rg->app_pending) (void)hipStreamWaitEvent(e->st, rg->app_ev, 0);      // the appended samples are (or will be) in HBM first
+                if (rg->app_pending && hipStreamWaitEvent(e->st, rg->app_ev, 0) != hipSuccess) {   // the appended samples are (or will be) in HBM first
+                    (void)hipGetLastError();
+                    HIPC(e, hipEventSynchronize(rg->app_ev));
+                }
                 ra.ring[w] = rg->buf; ra.ring_cap[w] = rg->cap; ra.start[w] = st % rg->cap; ra.n[w] = (int)n;
                 e->n_samples_h[w] = (int)n;
                 if ((int)n > max_n) max_n = (int)n;
@@ -1315,6 +1428,33 @@ extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, 
     if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
     ENTER(e);
     return run_all(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0);
+}
+
+// Stage entry points: the two halves of sonic_run_staged.  sonic_prefill = log-mel, encoder, projector, decoder prefill
+// and the first greedy token of every request (generate()'s first forward, HF:generation/utils.py:2612-2616); sonic_decode_step = up to
+// n_steps further iterations of the greedy loop (:2876-2943); *n_active_out = rows that are neither at EOS nor at their budget,
+// *steps_done_out = steps actually run (fewer than asked once the largest budget is reached).  sonic_fetch_tokens reads the result at any point.
+extern "C" int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                             const int32_t* max_new, int want_step_logits) {
+    if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
+    ENTER(e);
+    TRY(run_to_first_token(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0));
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    return SONIC_OK;
+}
+extern "C" int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32_t* steps_done_out) {
+    if (!e || n_steps < 0) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (e->R < 1 || e->greedy_calls < 1) return fail(e, SONIC_ERR_INVALID, "sonic_decode_step needs a batch that went through sonic_prefill");
+    int done = 0;
+    TRY(run_decode_steps(e, n_steps, &done));
+    HIPC(e, hipMemcpyAsync(e->n_active_h, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, hipGetLastError());
+    if (n_active_out) *n_active_out = *e->n_active_h;
+    if (steps_done_out) *steps_done_out = done;
+    return SONIC_OK;
 }
 
 static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits) {
@@ -1670,6 +1810,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
+    if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch

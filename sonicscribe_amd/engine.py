@@ -28,6 +28,7 @@ EXPORTS = [
     "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_debug_ktrace", "sonic_test_skinny_gu",
     "sonic_set_forced_ids", "sonic_test_greedy", "sonic_test_linear_int8",
     "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
+    "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info", "sonic_release_pool",
 ]
 
 
@@ -118,6 +119,12 @@ def load_library():
     lib.sonic_debug_ktrace.argtypes = [vp, C.c_void_p, C.c_int64]
     lib.sonic_debug_read.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int64]
     lib.sonic_test_skinny_gu.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.sonic_prefill.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
+    lib.sonic_decode_step.argtypes = [vp, C.c_int, ip, ip]
+    lib.sonic_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, i64p, i64p, ip]
+    lib.sonic_memory_info.argtypes = [vp, i64p, i64p]
+    lib.sonic_release_pool.argtypes = [C.c_int]
+    lib.sonic_release_pool.restype = C.c_int64
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.sonic_test_linear_int8.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -359,6 +366,25 @@ class Engine:
         self._run_cache = (ids, poffs, mn, rw)
         self._check(self.lib.sonic_run_staged(self.h, _p(rw), len(prompts), _p(ids), _p(poffs), _p(mn), int(want_logits)))
 
+    def prefill(self, prompts: Sequence[Sequence[int]], max_new: Sequence[int], req_win: Optional[Sequence[int]] = None, want_logits: bool = False):
+        """Stage entry point: everything up to and including the first greedy token of the staged batch (sonic_prefill)."""
+        ids, poffs = self._pack_prompts(prompts)
+        mn = np.ascontiguousarray(max_new, dtype=np.int32)
+        rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+        self._check(self.lib.sonic_prefill(self.h, _p(rw), len(prompts), _p(ids), _p(poffs), _p(mn), int(want_logits)))
+
+    def decode_step(self, n_steps: int = 1):
+        """Stage entry point: up to n_steps further greedy steps; returns (rows still active, steps actually run)."""
+        na, done = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.sonic_decode_step(self.h, int(n_steps), C.byref(na), C.byref(done)))
+        return int(na.value), int(done.value)
+
+    def memory_info(self):
+        """(allocated, reserved) bytes: the engine's live device allocations / plus the uncached blocks pooled for its device."""
+        a, r = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.sonic_memory_info(self.h, C.byref(a), C.byref(r)))
+        return int(a.value), int(r.value)
+
     def rerun_staged(self):
         """Repeat the last run_staged call without re-packing (benchmark inner loop)."""
         ids, poffs, mn, rw = self._run_cache
@@ -492,6 +518,22 @@ Engine.debug_read = _debug_read
 Engine.debug_ktrace = _debug_ktrace
 Engine.bench_skinny = _bench_skinny
 Engine.set_option = _set_option
+
+
+def device_info(device_id: int = 0) -> dict:
+    """name / total and free memory / HIP runtime version of a device (what asr.py:501-506 reads from torch.cuda)."""
+    lib = load_library()
+    name = C.create_string_buffer(256)
+    tot, fr, ver = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    if lib.sonic_device_info(int(device_id), name, 256, C.byref(tot), C.byref(fr), C.byref(ver)) != 0:
+        raise RuntimeError((lib.sonic_last_error(None) or b"").decode())
+    return {"name": name.value.decode(), "total_bytes": int(tot.value), "free_bytes": int(fr.value), "hip_runtime_version": int(ver.value)}
+
+
+def release_pool(device_id: int = -1) -> int:
+    """Hand the uncached blocks parked by destroyed engines back to the driver (all devices when device_id < 0); returns the bytes freed.
+    Refused (returns 0) while an engine is alive on the device."""
+    return int(load_library().sonic_release_pool(int(device_id)))
 
 
 def device_count() -> int:

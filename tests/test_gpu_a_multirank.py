@@ -1,0 +1,35 @@
+"""The real N-rank bench path on a one-GPU box (the 8-GPU scaling run itself is the driver's): bench.py under
+`python -m torch.distributed.run --nproc-per-node 2`, gloo for the barrier / max-reduce (RCCL cannot put two ranks on one device),
+both ranks on device 0 (--share-gpu).  Checks what the driver's SCALE run relies on: one JSON line from rank 0, n_gpus = 2, value =
+the segments of BOTH ranks over the max-rank time, and every rank working on its own shard (sharder.shard_range).  This file sorts
+first on purpose: the launcher process has not touched the GPU when it starts the child processes."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from sonicscribe_amd.sharder import shard_range
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_one_gpu_through_torchrun():
+    B, steps = 4, 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
+           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]                   # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["config"]["share_gpu"] is True
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - 2 * B) < 1e-6 * 2 * B      # whole-job segments / max-over-ranks time
+    shards = {int(m.group(1)): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"\[bench\] rank (\d)/2 device 0 backend gloo segments \[(\d+), (\d+)\)", r.stderr)}
+    assert shards == {0: shard_range(2 * B, 0, 2), 1: shard_range(2 * B, 1, 2)}, r.stderr[-1000:]
+    assert shards[0][1] <= shards[1][0]                         # disjoint

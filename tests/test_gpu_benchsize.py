@@ -387,3 +387,66 @@ def test_long_requests_vs_oracle(orc, seconds):
     if (srt[:, -1] - srt[:, -2]).min() > 8 * 2.0 ** -6:
         assert np.array_equal(ids[0], ref["new_ids"])
     e.close()
+
+
+def test_deep_context_full_depth_vs_oracle(orc):
+    """The bench decodes 150 tokens (context 260 -> 410); the full-depth test above stops after 3.  Here the B = 32 x 20 s batch runs all
+    150 steps under teacher forcing (varying ids per row) and one row is checked against the bf16 oracle at full depth at every step:
+    the later KV slices of the decode attention (contexts past 384 = a fourth 128-key round), token positions / kv_len up to step 149,
+    and the embedding gather of 149 different forced ids.  Bound as above: 8 bf16 ulp of 2^-6; measured values are printed."""
+    from sonicscribe_amd.engine import Engine
+    d = replace(spec.FULL, eos_ids=())
+    B, n_new, n_samples, row = 32, 150, 320000, 5
+    e = Engine(d, 0, max_batch=B, max_ctx=512)
+    e.load_synthetic(SEED)
+    segs = [synth.synth_pcm(200 + i, n_samples) for i in range(B)]
+    prompt = tiny_prompt(n_samples, d)
+    rng = np.random.default_rng(77)
+    force = rng.integers(2, d.vocab, size=(B, n_new)).astype(np.int32)
+    force[force == d.audio_token_id] = 17
+    e.set_forced_ids(force)
+    ids, logits = e.transcribe_batch(segs, [prompt] * B, [n_new] * B, want_logits=True)
+    e.set_forced_ids(None)
+    e.close()
+    assert all(np.array_equal(ids[r], force[r]) for r in range(B)) and np.isfinite(logits).all()
+    om = orc.Model(d, _full_state(orc, d, SEED), bf16=True)
+    feats, mask = orc.logmel(segs[row])
+    ref = om.transcribe(feats, int(mask.sum()), prompt, n_new, force_ids=force[row])
+    dl = np.abs(logits[:, row] - ref["step_logits"]).max(axis=1)
+    tol = 8 * 2.0 ** -6
+    print("deep context, full depth: max|dlogit| per step at 0/1/16/17/64/128/149:", [round(float(dl[s]), 4) for s in (0, 1, 16, 17, 64, 128, 149)],
+          f"worst {dl.max():.4f} at step {int(dl.argmax())}")
+    assert dl.max() <= tol, (float(dl.max()), int(dl.argmax()))
+    for s in (1, 16, 17, 64, 149):
+        srt = np.sort(ref["step_logits"][s])
+        if srt[-1] - srt[-2] > 2 * tol:
+            assert int(np.argmax(logits[s, row])) == int(np.argmax(ref["step_logits"][s])), s
+
+
+def test_stage_entry_points_and_memory_info(eng):
+    """sonic_prefill + sonic_decode_step (SURVEY 8b stage entry points) = sonic_run_staged, token for token; the memory / device queries
+    behind get_model_info() and the debug dict (asr.py:453-457, 501-506)."""
+    from sonicscribe_amd.engine import device_info
+    d = spec.TINY
+    segs = [synth.synth_pcm(70 + i, 48000 + 16000 * i) for i in range(3)]
+    prompts = [tiny_prompt(len(s), d) for s in segs]
+    budgets = [9, 20, 5]
+    want, _ = eng.transcribe_batch(segs, prompts, budgets)
+    eng.stage_pcm(segs)
+    eng.prefill(prompts, budgets)
+    first = eng.fetch_tokens(3, 32)
+    assert [len(x) for x in first] == [1, 1, 1] and all(first[r][0] == want[r][0] for r in range(3))
+    total = 0
+    while True:
+        n_active, done = eng.decode_step(4)
+        total += done
+        if done == 0:
+            break
+    got = eng.fetch_tokens(3, 32)
+    assert total == max(len(w) for w in want) - 1 or total == max(budgets) - 1
+    assert all(np.array_equal(got[r], want[r]) for r in range(3))
+    alloc, reserved = eng.memory_info()
+    assert reserved >= alloc > eng.weight_bytes() > 0
+    di = device_info(0)
+    assert di["total_bytes"] > 2 ** 36 and di["free_bytes"] > 0 and di["hip_runtime_version"] > 0 and len(di["name"]) > 0
+

@@ -17,7 +17,7 @@ from sonicscribe_amd import spec, synth, weights      # noqa: E402
 
 
 def test_live_hf_generate_vs_engine_through_hf_checkpoint(tmp_path):
-    from oracle import gen_golden as G                  # the container-side generator: only its model / feature helpers are used
+    from tests import hf_helpers as G                   # model / feature helpers over transformers (shared with oracle/gen_golden.py)
     from sonicscribe_amd.engine import Engine
     d = spec.TINY
     model, _cfg = G.build_tiny(torch.bfloat16)          # GlmAsrForConditionalGeneration with the portable-PRNG weights, bf16
@@ -79,7 +79,7 @@ def test_facade_on_a_complete_checkpoint_directory_vs_live_reference_sequence(tm
     reference's own sequence run live: peak-normalise + PCM_16 round trip (asr.py:247-276), chat-template prompt with the audio
     placeholder expanded by the processor (:375-399), generate(do_sample=False) (:411-422), batch_decode(skip_special_tokens)[0].strip()
     (:425-429).  Transcripts must be equal strings, with and without hotwords, for one- and two-window audio."""
-    from oracle import gen_golden as G
+    from tests import hf_helpers as G
     from sonicscribe_amd import frontend
     from sonicscribe_amd.asr import ASRModel, HFPrompt
     d = spec.TINY

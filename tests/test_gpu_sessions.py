@@ -54,10 +54,11 @@ def test_128_sessions_gate_to_ring_decodes():
         want = m.transcribe(frontend.pcm_bytes_to_float(wire[s][a:a + n].tobytes()), 16000, max_new_tokens=max_new)
         assert e["future"].result(timeout=120) == want, (e["type"], s)
         checked += 1
-    # the utterance lies inside the final's range
+    # the final covers the utterance from the window in which the gate first saw speech (the reference's segment starts at that
+    # window's first chunk, vad_processor_manager.py:127-129: up to one 640 ms window of the onset can precede it) to its end
     for e in finals:
         s = int(e["session"].split("-")[1])
-        assert e["first_sample"] <= lead[s] * CHUNK and e["first_sample"] + e["n_samples"] >= (lead[s] + n_speech[s]) * CHUNK
+        assert e["first_sample"] <= (lead[s] + 10) * CHUNK and e["first_sample"] + e["n_samples"] >= (lead[s] + n_speech[s]) * CHUNK
     batches = m._dispatcher.replicas[0].batches
     assert batches < len(finals) + len(partials) + checked                     # requests of a tick shared device batches
     g.close(); m.close()

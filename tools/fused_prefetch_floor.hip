@@ -4,7 +4,11 @@
 //   op B (gate/up):  50.3 MB of weights, every block also reads the 128 KB activation image op A published
 // Variant 0: two kernels per pair (stream order).  Variant 1: one kernel, 256 blocks (one per CU), B's 24 x 16-byte loads per lane
 // issued first, then A's loads; A consumed and published; XCD-style hierarchical grid barrier (group = blockIdx & 7, bounded spin);
-// the activation image read behind an agent-scope acquire; B consumed.  A chain of 28 pairs in one hipGraph, like the engine's step.
+// the activation image read behind an agent-scope acquire; B consumed.  (vmcnt retires in order, so the drain of A's stores in front of
+// the barrier also waits for every B load: no overlap.)  Variant 3: the form that CAN overlap on gfx9 - 9 waves per block, waves 0-7
+// do A, drain their own stores, THEN request B (in-order vmcnt: the store drain must not sit behind B's loads), a ninth wave that never
+// has a load in flight arrives at the grid barrier, polls it and runs the acquire (a polling wave's loads would queue behind its own
+// B requests).  A chain of 28 pairs in one hipGraph, like the engine's step.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/fpf tools/fused_prefetch_floor.hip && /tmp/fpf
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -85,6 +89,59 @@ template <int UA, int XA, int UB, int XB> __global__ __launch_bounds__(512) void
     if (b[0] == 0x5a17c0de) sink[0] = 1;
 }
 
+// control-wave form: waves 0..7 work, wave 8 synchronises
+__device__ __forceinline__ void grid_barrier_ctrl(Bar* b, unsigned& g, bool ctrl) {
+    __builtin_amdgcn_s_barrier();                     // every working wave has drained its own stores (it waited vmcnt before requesting B)
+    if (ctrl) {
+        if ((threadIdx.x & 63) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned grp = blockIdx.x & 7, per = gridDim.x >> 3;
+            if (__hip_atomic_fetch_add(&b->cnt[grp][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == per - 1) {
+                __hip_atomic_store(&b->cnt[grp][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7) {
+                    __hip_atomic_store(&b->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&b->gen[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            int spins = 0;
+            while (ld_sc1(&b->gen[0]) == g) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { __hip_atomic_store(&b->err[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    g += 1;
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int UA, int XA, int UB, int XB> __global__ __launch_bounds__(576) void fused_ctrl_kernel(const v4i* wa, const v4i* xa, const v4i* wb, int* mid, int* out, Bar* bar, int* sink) {
+    const bool ctrl = threadIdx.x >= 512;
+    unsigned g = 0;
+    if (ctrl) g = ld_sc1(&bar->gen[0]);
+    v4i bv[UB];
+    if (!ctrl) {
+        v4i av[UA], xv[XA];
+        issue<XA>(xa + threadIdx.x, xv);
+        issue<UA>(wa + (long)blockIdx.x * UA * 512 + threadIdx.x, av);
+        const v4i a = fold<UA>(av) ^ fold<XA>(xv);
+        mid[blockIdx.x * 512 + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left (nothing else of its is in flight yet)
+        issue<UB>(wb + (long)blockIdx.x * UB * 512 + threadIdx.x, bv);
+    }
+    grid_barrier_ctrl(bar, g, ctrl);
+    if (!ctrl) {
+        v4i x2[XB];
+#pragma unroll
+        for (int u = 0; u < XB; ++u) x2[u] = ((const v4i*)mid)[u * 512 + threadIdx.x];
+        const v4i b = fold<UB>(bv) ^ fold<XB>(x2);
+        out[blockIdx.x * 512 + threadIdx.x] = b[0] ^ b[1] ^ b[2] ^ b[3];
+        if (b[0] == 0x5a17c0de) sink[0] = 1;
+    }
+}
+
 int main() {
     const int L = 28, NB = 256;
     constexpr int UA = 4, XA = 8, UB = 24, XB = 16;           // per lane: A 64 B of weights (32 KB / block) + 64 KB image; B 384 B (192 KB / block) + 128 KB image
@@ -102,7 +159,7 @@ int main() {
     CK(hipStreamSynchronize(s));
     printf("op A %.1f MB + op B %.1f MB per pair, %d pairs per graph\n", wa_b / 1e6, wb_b / 1e6, L);
     for (int round = 0; round < 2; ++round)
-        for (int variant = 0; variant < 3; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             hipGraph_t g; hipGraphExec_t gx;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             for (int l = 0; l < L; ++l) {
@@ -111,8 +168,10 @@ int main() {
                     hipLaunchKernelGGL((op_kernel<UB, XB>), dim3(NB), dim3(512), 0, s, WB[l], (const v4i*)mid, out, sink);
                 } else if (variant == 1) {
                     hipLaunchKernelGGL((fused_kernel<UA, XA, UB, XB>), dim3(NB), dim3(512), 0, s, WA[l], xin, WB[l], mid, out, bar, sink);
-                } else {
+                } else if (variant == 2) {
                     hipLaunchKernelGGL((op_kernel<UB, XB>), dim3(NB), dim3(512), 0, s, WB[l], (const v4i*)mid, out, sink);       // op B alone
+                } else {
+                    hipLaunchKernelGGL((fused_ctrl_kernel<UA, XA, UB, XB>), dim3(NB), dim3(576), 0, s, WA[l], xin, WB[l], mid, out, bar, sink);
                 }
             }
             CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&gx, g, nullptr, nullptr, 0));
@@ -125,7 +184,7 @@ int main() {
             CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             unsigned err = 0; CK(hipMemcpy(&err, &bar->err[0], 4, hipMemcpyDeviceToHost));
-            printf("%-44s %7.2f us per pair%s\n", variant == 0 ? "two launches (A, then B)" : variant == 1 ? "one launch (B requested, A, barrier, B)" : "op B alone (one launch)",
+            printf("%-54s %7.2f us per pair%s\n", variant == 0 ? "two launches (A, then B)" : variant == 1 ? "one launch (B requested, A, barrier, B)" : variant == 2 ? "op B alone (one launch)" : "one launch, control wave (A, B requested, barrier, B)",
                    ms * 1e3 / R / L, err ? "  [BARRIER TIMEOUT]" : "");
             CK(hipGraphExecDestroy(gx)); CK(hipGraphDestroy(g));
         }
