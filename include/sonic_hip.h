@@ -26,7 +26,7 @@
  *   sonic_device_info          torch.version.cuda / torch.cuda.get_device_name() / get_device_properties(0).total_memory
  *                              in ASRModel.get_model_info                   asr.py:501-506
  *   sonic_memory_info          torch.cuda.memory_allocated() / memory_reserved() in the debug dict  asr.py:453-457
- *   sonic_release_pool         torch.cuda.empty_cache() after `del asr_model.model`  backend/main.py:84-90
+ *   sonic_release_pool         (part of) torch.cuda.empty_cache() after `del asr_model.model`  backend/main.py:84-90
  *   sonic_destroy              `del asr_model.model`                      backend/main.py:84-86
  *   sonic_last_error           the exception text re-raised at            asr.py:469-481
  */
@@ -89,8 +89,10 @@ int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_by
  * process-wide pool of this engine's device (sonic_destroy parks them, the next engine that needs the same size takes them) */
 int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes);
 /* frees the pooled uncached blocks of device_id (< 0: every device) after a device synchronise and a system-scope cache write-back +
- * invalidate; returns the bytes freed, 0 while an engine is still alive on the device.  sonic_destroy calls it for its device when it
- * destroys the last engine there, so a model reload with other sizes does not keep the old KV cache / weight copies. */
+ * invalidate; returns the bytes freed, 0 while an engine is still alive on the device.  The pool only holds the per-step activation
+ * buffers (tens of MB per engine shape; weights and the KV cache are ordinary allocations that sonic_destroy frees), and it is NOT
+ * released automatically: on this stack, memory recycled from uncached to ordinary allocations came back with stale cache lines
+ * (DESIGN.md 4).  Call it only when the process will not allocate device memory again, or to measure. */
 int64_t sonic_release_pool(int device_id);
 
 /* ---- weights (names: GlmAsrForConditionalGeneration.state_dict() keys, see sonicscribe_amd/spec.py) ---- */

@@ -111,6 +111,10 @@ struct GemmI8 {
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group
     const int* row_group; int group_div;                 // group of row m = row_group ? row_group[(m + row_off) / group_div] : (m + row_off) / group_div
     int row_off;                                         // index of this launch's row 0 in the quantised matrix (a launch over a row range)
+    // Deferred outliers (EPI_BIAS_RESID only): rows whose group lists more than defer_thr outlier columns leave the GEMM as fp16(acc * s + b)
+    // in defer_out (same row pitch as C; no outlier sum, no residual) and launch_i8_outlier_side finishes them with a dense fp16 MFMA
+    // product over the gathered columns.  NULL: every list is walked in the epilogue (O(columns) scalar loads per output element).
+    bf16_t* defer_out; int defer_thr;
 };
 
 struct GemmArgs {

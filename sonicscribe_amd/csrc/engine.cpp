@@ -59,6 +59,7 @@ struct sonic_engine {
     // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
     int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
     int q_kmax = 0; bf16_t* qkv_rm = nullptr;
+    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 32;   // rows deferred to the outlier side product leave the GEMM here
     // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
@@ -231,6 +232,16 @@ template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, b
     return SONIC_OK;
 }
 template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) { return dalloc_uc(e, p, n, true); }
+// The big once-per-step streams (KV cache, fragment-tiled weight copies; GiB) are ORDINARY allocations since round 3: pooled uncached
+// blocks are never returned to the driver (see above), so a model reload with other sizes kept the old KV cache and weight copies -
+// and releasing the pool with the last engine brought the stale-line corruption straight back (tests/test_gpu_int8.py failed in the
+// first full-suite run with the release enabled, although tools/uc_recycle_repro.hip reproduces neither of the two mechanisms tried).
+// Uncached + pooled stays for the per-step activation buffers only (tens of MB per engine shape).  Cost measured with bench.py: the
+// uncached KV cache / weights were worth 2.4 ms of a 311 ms step in round 2.  SONIC_UC_BIG=1 restores them for A/B runs.
+template <typename Tt> static int dalloc_big(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
+    if (getenv("SONIC_UC_BIG")) return dalloc_uc(e, p, n, zero);
+    return dalloc(e, p, n, zero);
+}
 #define TRY(x) do { int _s = (x); if (_s != SONIC_OK) return _s; } while (0)
 // every locked C-ABI entry: serialise on the engine, select its device, and hand its experiment knobs to the launchers
 // (hipGetLastError first: the slot is per thread and sticky, so a failure some earlier call of this thread ignored would otherwise
@@ -453,7 +464,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->dx, tc * d.dec_d)); A(dalloc(e, &e->dhn, tc * d.dec_d)); A(dalloc(e, &e->dqkv, tc * e->qkvN));
     A(dalloc(e, &e->dq, tc * e->QD)); A(dalloc(e, &e->datt, tc * e->QD)); A(dalloc(e, &e->dact, tc * d.dec_ff));
     const size_t kvn = (size_t)d.dec_layers * Bm * d.dec_kv_heads * max_ctx * d.dec_head_dim;
-    A(dalloc_uc(e, &e->Kc, kvn)); A(dalloc_uc(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
+    A(dalloc_big(e, &e->Kc, kvn)); A(dalloc_big(e, &e->Vc, kvn)); A(dalloc(e, &e->Vts, (size_t)Bm * d.dec_kv_heads * d.dec_head_dim * max_ctx));
     long mx = 2L * d.dec_ff; if (e->qkvN > mx) mx = e->qkvN; if (d.dec_d > mx) mx = d.dec_d;
     e->slabN = mx;
     A(dalloc_act(e, &e->ssq, (size_t)256 * 64));
@@ -475,6 +486,8 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
         A(dalloc(e, &e->qa, qa_bytes + 4096)); A(dalloc(e, &e->q_sca, rows)); A(dalloc(e, &e->q_flags, (size_t)64 * kmax + 64));
         A(dalloc(e, &e->q_oc_cnt, 64)); A(dalloc(e, &e->q_oc_list, (size_t)64 * kmax)); A(dalloc(e, &e->win_req, 64));
         A(dalloc(e, &e->qkv_rm, Mp * 3 * C));
+        e->defer_cap = Mp * (size_t)C > tc * (size_t)d.dec_d ? Mp * (size_t)C : tc * (size_t)d.dec_d;
+        A(dalloc(e, &e->defer_tmp, e->defer_cap, false));
         A(dalloc_act(e, &e->hn_q, (size_t)64 * d.dec_d)); A(dalloc_act(e, &e->att_q, (size_t)64 * e->QD)); A(dalloc_act(e, &e->act_q, (size_t)64 * d.dec_ff));
         A(dalloc(e, &e->sca_hn, 64)); A(dalloc(e, &e->sca_att, 64)); A(dalloc(e, &e->sca_act, 64));
         A(dalloc(e, &e->oc_hn, 64)); A(dalloc(e, &e->oc_att, 64)); A(dalloc(e, &e->oc_act, 64));
@@ -521,10 +534,9 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->st) (void)hipStreamDestroy(e->st);
     const int dev = e->device;
     delete e;
-    // The last engine of a device hands its uncached blocks back (`del asr_model.model` + torch.cuda.empty_cache(), main.py:84-90): a model
-    // reload with other sizes must not keep the old KV cache and weight copies.  While another engine lives on the device the blocks stay
-    // pooled for reuse.  SONIC_KEEP_POOL=1 keeps round 2's behaviour (never hipFree an uncached block).
-    if (last_on_device && !getenv("SONIC_KEEP_POOL")) (void)sonic_release_pool(dev);
+    // The pooled (small, per-step activation) blocks are NOT released here: recycling uncached memory through hipFree corrupts later
+    // allocations on this stack (dalloc_big above).  SONIC_RELEASE_POOL=1 releases them with the last engine of a device, for experiments.
+    if (last_on_device && getenv("SONIC_RELEASE_POOL")) (void)sonic_release_pool(dev);
 }
 
 extern "C" int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n) {
@@ -648,7 +660,7 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
     launch_quant_weights(*w16, q->cb, q->scb, N, K, e->st);
     e->weight_bytes += (int64_t)N * K + (int64_t)N * 4 - (int64_t)N * K * 2;
     if (tiled) {
-        TRY(dalloc_uc(e, &q->cbt, (size_t)N * K, false));
+        TRY(dalloc_big(e, &q->cbt, (size_t)N * K, false));
         launch_tile_weights_i8(q->cb, q->cbt, N, K, e->st);
         e->weight_bytes += (int64_t)N * K;
     }
@@ -733,7 +745,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         e->weight_bytes += (int64_t)g->n * 4;
         TRY(keep_raw(e, p + "mlp.down_proj.weight", &L.wdown));
         auto tiled = [&](const bf16_t* w, bf16_t** out, int N, int K) -> int {
-            TRY(dalloc_uc(e, out, (size_t)N * K, false));
+            TRY(dalloc_big(e, out, (size_t)N * K, false));
             launch_tile_weights(w, *out, N, K, e->st);
             e->weight_bytes += (int64_t)N * K * 2;
             return SONIC_OK;
@@ -747,12 +759,12 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
         TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
         if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave)
-            TRY(dalloc_uc(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
+            TRY(dalloc_big(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
             launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
             e->weight_bytes += (int64_t)2 * d.dec_ff * d.dec_d * 2;
         }
     }
-    TRY(dalloc_uc(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
+    TRY(dalloc_big(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
     launch_tile_weights(e->embed, e->embed_t, d.vocab, d.dec_d, e->st);
     e->weight_bytes += (int64_t)d.vocab * d.dec_d * 2;
     TRY(to_f32(e, lm + "norm.weight", &e->dec_nw));
@@ -790,7 +802,12 @@ static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const b
     a.q.row_group = grp.gmap; a.q.group_div = grp.gdiv;
     const bool fuse = false && rope_cs && !g_opts.gemm_force128 && gemm256_eligible(a, epi);   // int8 kind: the fused form spills (gemm256.hip), RoPE stays its own pass
     if (fuse) { a.rope_cs = rope_cs; a.rope_T = rope_T; a.rope_ncols = rope_ncols; }
+    // residual-epilogue linears (o_proj, fc2, down_proj: their inputs are activation outputs, where long outlier lists occur): requests with
+    // more than `i8_defer_thr` outlier columns are finished by the dense side product instead of the epilogue's per-element list walk
+    const bool defer = epi == EPI_BIAS_RESID && e->defer_tmp && e->opt_i8_defer_thr >= 0 && (size_t)M * ldc <= e->defer_cap;
+    if (defer) { a.q.defer_out = e->defer_tmp; a.q.defer_thr = e->opt_i8_defer_thr; }
     launch_gemm(a, epi, e->st);
+    if (defer) launch_i8_outlier_side(a, e->st);
     return fuse;
 }
 
@@ -1810,6 +1827,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
+    if (!strcmp(key, "i8_defer_thr")) { e->opt_i8_defer_thr = value; return SONIC_OK; }   // int8: outlier lists longer than this go to the dense side product (-1: never)
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)

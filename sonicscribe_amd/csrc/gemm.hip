@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
                     const int seg = m / a.seg_T, t = m - seg * a.seg_T;
                     O4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv, I8Row{}, 0.f);   // (16-bit kinds only)
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (16-bit kinds only)
                     *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
                 }
             }
@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) l[j] = gemm_lin<KD>(a, acc[ni][mi][j], m, n + j, bv[j], rw, sb[j]);
             if (EPI == EPI_BIAS_RESID) {
+                if (rw.defer) {                                   // finished by launch_i8_outlier_side (outlier sum, then the residual)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)l[j];
+                    *(O4*)((OT*)a.q.defer_out + (long)blockIdx.z * a.strideC + (long)m * a.ldc + n) = o;
+                    continue;
+                }
                 const O4 rv = *(const O4*)(R + (long)m * a.ldr + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (OT)(l[j] + (float)rv[j]);

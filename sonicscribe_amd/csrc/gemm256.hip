@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int m = m0 + wr * 128 + mb * 16 + fg * 4 + j; m = m < a.M ? m : a.M - 1;
-                    o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc, bv, I8Row{}, 0.f);   // (V^T tiles exist for 16-bit kinds only)
+                    o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (V^T tiles exist for 16-bit kinds only)
                 }
                 *(O4*)(smem + nl * CLD + (wr * 128 + mb * 16 + fg * 4) * 2) = o;
             }
@@ -298,6 +298,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     I8Row rws[8];
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) { int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1; rws[mb] = i8_row<KD>(a, m); }
+    // deferred rows (their outlier columns and the residual are added by launch_i8_outlier_side): one flag byte per tile row behind the
+    // staged tile, read back by the row-wise store pass
+    constexpr bool DEFER = KD::I8 && EPI == EPI_BIAS_RESID;
+    if constexpr (DEFER) {
+        if (wc == 0 && fg == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) smem[LDS256_BYTES + wr * 128 + mb * 16 + fr] = rws[mb].defer ? 1 : 0;
+        }
+    }
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -455,6 +464,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int m = m0 + row, n = n0 + ch * 8;
         if (m < a.M && n < a.N) {
             O8 v = *(const O8*)(smem + row * CLD + ch * 16);
+            if constexpr (DEFER) {
+                if (smem[LDS256_BYTES + row]) { *(O8*)((OT*)a.q.defer_out + (long)blockIdx.z * a.strideC + (long)m * a.ldc + n) = v; continue; }
+            }
             if (EPI == EPI_BIAS_RESID) {
                 const O8 rv = *(const O8*)(R + (long)m * a.ldr + n);
 #pragma unroll
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 
 
 template <typename KD, int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = LDS256_BYTES + ((EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value) ? GELU_LUT_N * 2 : 0);
+    constexpr int LDS = LDS256_BYTES + ((EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value) ? GELU_LUT_N * 2 : 0) + ((KD::I8 && EPI == EPI_BIAS_RESID) ? 256 : 0);
     ensure_dyn_lds((const void*)gemm256_kernel<KD, EPI, STG>, LDS);
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
     hipLaunchKernelGGL((gemm256_kernel<KD, EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS, s, a);

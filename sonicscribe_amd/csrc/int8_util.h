@@ -88,14 +88,15 @@ __device__ __forceinline__ float i8_add_outliers(const GemmI8& q, const int8_t* 
 }
 
 // Per-row metadata of an int8 GEMM epilogue, loaded once per row a lane touches (not per element)
-struct I8Row { float sa; int g, cnt; };
+struct I8Row { float sa; int g, cnt; bool defer; };
 template <typename KD>
 __device__ __forceinline__ I8Row i8_row(const GemmArgs& a, int m) {
-    I8Row r{0.f, 0, 0};
+    I8Row r{0.f, 0, 0, false};
     if constexpr (KD::I8) {
         r.sa = a.q.sca[m];
         r.g = a.q.row_group ? a.q.row_group[(m + a.q.row_off) / a.q.group_div] : (m + a.q.row_off) / a.q.group_div;
         r.cnt = a.q.oc_cnt[r.g];
+        if (a.q.defer_out && r.cnt > a.q.defer_thr) { r.defer = true; r.cnt = 0; }     // the side kernel adds this row's outlier columns
     }
     return r;
 }

@@ -141,6 +141,8 @@ struct QuantActArgs {
     int8_t* q; float* sca; int* oc_cnt; int* oc_list; int oc_ld;
 };
 void launch_quant_act(const QuantActArgs& a, hipStream_t s);
+// finishes the rows an int8 GEMM deferred (GemmI8::defer_out): dense fp16 MFMA product over their gathered outlier columns + residual
+void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s);
 // decode flavour: every row is its own group; one block per row
 void launch_quant_rows(const bf16_t* X, long ld, int M, int K, const QuantOut& qo, hipStream_t s);
 void launch_tile_weights_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s);

@@ -111,6 +111,104 @@ void launch_quant_act(const QuantActArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(qa_lists_kernel, dim3(a.G), dim3(256), 0, s, a);
 }
 
+// ---------------------------------------------------------------- deferred outlier columns of an int8 GEMM (prefill / encoder, RESID epilogue)
+// bitsandbytes adds the outlier columns of a Linear8bitLt call as a dense fp16 matmul over the gathered columns
+// (MatMul8bitLt.forward: output.addmm(subA, subB)); the GEMM epilogues walk the list per output element instead, which is the right
+// trade for the handful of columns a real checkpoint has but costs O(columns) scattered loads per element: 1.1 ms per down_proj GEMM for
+// the ~360 columns synthetic SwiGLU activations produce (profiles/round2_int8_b64_kernel_summary.txt).  Rows whose group lists more
+// than defer_thr columns therefore leave the GEMM as v = fp16(acc * s + b) in `tmp`, and this kernel finishes them:
+//     out = fp16(fp16(v + sum_k x[m][k] * wdq[n][k]) + R[m][n]),  wdq = fp16(CB[n][k] * SCB[n] / 127)   (oracle/sonic_oracle.c linear_int8)
+// with the sum on the matrix pipe: v_mfma_f32_16x16x32_f16 over 32-column chunks of the group's ascending list, operands gathered into
+// LDS (products exact, fp32 accumulation in the MFMA's own order: the scalar epilogue sums in ascending k, so a deferred element can
+// differ from it by one fp16 ulp when v + sum lands on a rounding boundary; the order depends on the list only, never on the batch).
+// Block: 64 rows x 128 columns, 4 waves (each 64 x 32).  A tile that spans two groups handles them one after the other, rows of the other
+// group zeroed in the A image.
+struct OutlierSideArgs {
+    const f16_t* x16; long ldx;              // unquantised activations [M][K]
+    const int8_t* cb; const float* scb;      // weights [N][K] row-wise int8 + row absmax
+    const f16_t* tmp; const f16_t* R; long ldr; f16_t* C; long ldc;   // v in, residual in, out (tmp has C's pitch)
+    const int* oc_cnt; const int* oc_list; int oc_ld, thr;
+    const int* row_group; int group_div;
+    int M, N, K;
+};
+__global__ __launch_bounds__(256) void i8_outlier_side_kernel(OutlierSideArgs a) {
+    constexpr int XP = 80, RM = 64, RN = 128;                       // LDS row pitch in bytes (64 B of k + 16 B skew), tile rows / columns
+    __shared__ __attribute__((aligned(16))) char sx[RM * XP];
+    __shared__ __attribute__((aligned(16))) char sw[RN * XP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * RM, n0 = blockIdx.y * RN;
+    const int mlast = min(m0 + RM, a.M) - 1;
+    auto group_of = [&](int m) { return a.row_group ? a.row_group[m / a.group_div] : m / a.group_div; };
+    const int g_first = group_of(m0), g_last = group_of(mlast);     // group ids do not decrease with the row
+    for (int g = g_first; g <= g_last; ++g) {
+        const int cnt = a.oc_cnt[g];
+        if (cnt <= a.thr) continue;                                  // (block-uniform: the epilogue of the GEMM finished these rows)
+        const int* lst = a.oc_list + (long)g * a.oc_ld;
+        f32x4 acc[4][2];                                             // [m block][n block] of this wave's 64 x 32
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < cnt; k0 += 32) {
+            __syncthreads();
+            // gather: X chunk [64 rows][32 listed columns], W chunk [128 rows][32] dequantised to fp16 values
+            for (int i = tid; i < RM * 32; i += 256) {
+                const int r = i >> 5, c = i & 31, m = m0 + r;
+                f16_t v = (f16_t)0.f;
+                if (k0 + c < cnt && m < a.M && group_of(m) == g) v = a.x16[(long)m * a.ldx + lst[k0 + c]];
+                *(f16_t*)(sx + r * XP + c * 2) = v;
+            }
+            for (int i = tid; i < RN * 32; i += 256) {
+                const int r = i >> 5, c = i & 31, n = n0 + r;
+                f16_t v = (f16_t)0.f;
+                if (k0 + c < cnt && n < a.N) v = (f16_t)rT<f16_t>(__fmul_rn(__fmul_rn((float)a.cb[(long)n * a.K + lst[k0 + c]], a.scb[n]), INT8_DEQ_W));
+                *(f16_t*)(sw + r * XP + c * 2) = v;
+            }
+            __syncthreads();
+            f16x8 xf[4], wf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *(const f16x8*)(sx + (i * 16 + fr) * XP + fg * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *(const f16x8*)(sw + (wid * 32 + j * 16 + fr) * XP + fg * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        // D[n = n0 + wid*32 + j*16 + fg*4 + e][m = m0 + i*16 + fr]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i * 16 + fr;
+            if (m >= a.M || group_of(m) != g) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wid * 32 + j * 16 + fg * 4;
+                if (n >= a.N) continue;
+                const f16x4 v = *(const f16x4*)(a.tmp + (long)m * a.ldc + n);
+                f16x4 o;
+                if (a.R) {
+                    const f16x4 rv = *(const f16x4*)(a.R + (long)m * a.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16_t)(rT<f16_t>(__fadd_rn((float)v[e], acc[i][j][e])) + (float)rv[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16_t)__fadd_rn((float)v[e], acc[i][j][e]);
+                }
+                *(f16x4*)(a.C + (long)m * a.ldc + n) = o;
+            }
+        }
+    }
+}
+void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s) {
+    if (!g.q.defer_out || g.M <= 0) return;
+    OutlierSideArgs a{};
+    a.x16 = (const f16_t*)g.q.x16; a.ldx = g.q.ldx16; a.cb = (const int8_t*)g.W; a.scb = g.q.scb;
+    a.tmp = (const f16_t*)g.q.defer_out; a.R = (const f16_t*)g.R; a.ldr = g.ldr; a.C = (f16_t*)g.C; a.ldc = g.ldc;
+    a.oc_cnt = g.q.oc_cnt; a.oc_list = g.q.oc_list; a.oc_ld = g.q.oc_ld; a.thr = g.q.defer_thr;
+    a.row_group = g.q.row_group; a.group_div = g.q.group_div; a.M = g.M; a.N = g.N; a.K = g.K;
+    hipLaunchKernelGGL(i8_outlier_side_kernel, dim3((g.M + 63) / 64, (g.N + 127) / 128), dim3(256), 0, s, a);
+}
+
 // ---------------------------------------------------------------- int8 encoder: V columns of the row-major QKV matrix -> V^T [seg][C][vt_ld]
 // (the 16-bit path writes V^T from the QKV GEMM's epilogue; with the dequantisation on top that epilogue spills registers)
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* qkv, long ld, int col0, bf16_t* vt, int T, int C, int vt_ld, long vt_seg_stride) {

@@ -100,6 +100,39 @@ def test_linear8bit_epilogues(eng8, orc):
         assert np.abs(got - ref).max() <= 2.0 ** -9 * max(1.0, float(np.abs(ref).max()))
 
 
+def test_linear8bit_long_outlier_lists_go_to_the_dense_side_product(eng8, orc):
+    """Requests with more than 32 outlier columns (synthetic SwiGLU activations: ~360 of 6144) leave a residual-epilogue int8 GEMM without
+    their outlier sum; a dense fp16 MFMA product over the gathered columns finishes them (bitsandbytes does the same:
+    MatMul8bitLt.forward adds subA @ subB).  Two requests in one call, 260 rows each (a 64-row tile of the side kernel spans both):
+    request 0 with 70 outlier columns (deferred), request 1 with 5 (walked in the GEMM epilogue, exact).  The MFMA sums in its own order, the
+    oracle in ascending k: a deferred element may differ by one fp16 ulp when v + sum sits on a rounding boundary; with the deferral
+    switched off the result is bit-exact again."""
+    from sonicscribe_amd.engine import EPI_BIAS_RESID
+    rng = np.random.default_rng(99)
+    M, N, K, G = 520, 256, 512, 260
+    X = f16(rng.standard_normal((M, K))); W = f16(rng.standard_normal((N, K)) * 0.08); b = f16(rng.standard_normal(N) * 0.1)
+    R = f16(rng.standard_normal((M, N)))
+    cols0 = rng.choice(K, 70, replace=False)
+    X[rng.integers(0, G, 70), cols0] = f16(rng.choice([-1.0, 1.0], 70) * rng.uniform(6.0, 14.0, 70))
+    cols1 = rng.choice(K, 5, replace=False)
+    X[G + rng.integers(0, G, 5), cols1] = f16(rng.uniform(6.5, 9.0, 5))
+    ref = f16(_ref_linear(orc, X, W, b, G) + R)
+    got = eng8.test_linear_int8(X, W, b, resid=R, group_rows=G, epi=EPI_BIAS_RESID)
+    ulp = np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10), 2.0 ** -24)
+    diff = np.abs(got - ref)
+    assert (diff <= ulp).all(), float((diff / ulp).max())
+    assert np.array_equal(got[G:], ref[G:])                         # the short list stayed on the exact path
+    frac = float((diff[:G] > 0).mean())
+    print(f"deferred request: {frac * 100:.3f} % of the elements differ from the ascending-k sum (by one fp16 ulp)")
+    assert frac < 0.02
+    eng8.set_option("i8_defer_thr", -1)
+    try:
+        exact = eng8.test_linear_int8(X, W, b, resid=R, group_rows=G, epi=EPI_BIAS_RESID)
+    finally:
+        eng8.set_option("i8_defer_thr", 32)
+    assert np.array_equal(exact, ref)
+
+
 def _prompt(n_samples, d):
     return [1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(n_samples)) + [7, 301, 302, 303, 9, 11]
 
