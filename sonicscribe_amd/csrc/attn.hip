@@ -44,8 +44,11 @@ template <int HD> __device__ __forceinline__ int kswz(int row) {  // swizzle ter
     return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
 }
 
-template <typename T, int HD, bool CAUSAL>
+// VAR (A/B, option "flash_variant"): bit 0 = two LDS tile buffers, one barrier per key tile; bit 1 = accumulators rescaled only when a
+// running maximum of the wave moved
+template <typename T, int HD, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
+    constexpr bool DB = (VAR & 1) != 0, LAZY = (VAR & 2) != 0;
     typedef typename ET<T>::v8 V8;
     typedef typename ET<T>::v4 V4;
     constexpr int HS = HD / 32;        // hd k-steps for S^T
@@ -55,9 +58,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     constexpr int KT_BYTES = 64 * KROW;
     constexpr int VT_BYTES = HD * 128;
     constexpr int KV_PASSES = KT_BYTES / 4096;  // 256 threads x 16 B per pass
-    __shared__ __attribute__((aligned(16))) char smem[KT_BYTES + VT_BYTES];
-    char* sK = smem;
-    char* sV = smem + KT_BYTES;
+    // two K / V^T tile buffers: tile kt+1 is committed to the other buffer while tile kt is being read, one barrier per tile
+    __shared__ __attribute__((aligned(16))) char smem[(DB ? 2 : 1) * (KT_BYTES + VT_BYTES)];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -116,7 +118,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
             vreg[p] = *(const V8*)(Vt + (long)vr * a.vt_ld + key0 + vc * 8);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        char* sK = smem + buf * (KT_BYTES + VT_BYTES);
+        char* sV = sK + KT_BYTES;
 #pragma unroll
         for (int p = 0; p < KV_PASSES; ++p) {
             const int idx = p * 256 + tid;
@@ -127,12 +131,26 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
         }
     };
 
+    // Round 2 had one buffer and two barriers per tile (consumed -> commit -> visible).  With two buffers the registers that hold tile
+    // kt+1 are committed to the buffer tile kt-1 was read from (every wave passed the barrier that closed iteration kt-1), tile kt+2 is
+    // requested, tile kt is consumed, and ONE barrier closes the iteration.
     issue(0);
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        __syncthreads();          // previous tile fully consumed
-        commit();
+    if (DB) {
+        commit(0);
+        if (n_tiles > 1) issue(1);
         __syncthreads();
-        if (kt + 1 < n_tiles) issue(kt + 1);
+    }
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        if (DB) {
+            if (kt + 1 < n_tiles) { commit((kt + 1) & 1); if (kt + 2 < n_tiles) issue(kt + 2); }
+        } else {
+            __syncthreads();          // previous tile fully consumed
+            commit(0);
+            __syncthreads();
+            if (kt + 1 < n_tiles) issue(kt + 1);
+        }
+        const char* sK = smem + (DB ? (kt & 1) : 0) * (KT_BYTES + VT_BYTES);
+        const char* sV = sK + KT_BYTES;
         const int key0 = kt * 64;
 
         // ---- S^T = K . Q^T   (st[ks][sb][qb][j]: key = key0 + ks*32 + 8*fg + 4*sb + j, query = qb*16 + fr)
@@ -161,6 +179,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
         const bool edge = (key0 + 64 > kv_len) || (CAUSAL && (key0 + 63 > q0 + wid * 32 + qpos_off));
         V8 pf[2][2];
         const float cexp = a.scale * 1.44269504088896341f;
+        float alph[2];
         auto softmax = [&](auto masked) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
@@ -201,11 +220,18 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
                             pf[qb][ks][sb * 4 + j] = (T)p;
                         }
                 lrun[qb] = lrun[qb] * alpha + psum;
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) oacc[qb][hb] *= alpha;
+                alph[qb] = alpha;
             }
         };
         if (edge) softmax(std::true_type{}); else softmax(std::false_type{});
+        // the accumulators are rescaled only when some query of this wave moved its running maximum (alpha == 1 otherwise: after the first
+        // tiles that is the common case, and the 8 * HB multiplies are pure VALU time in a VALU-bound loop); one wave-uniform branch
+        if (!LAZY || __builtin_amdgcn_ballot_w64(alph[0] != 1.0f || alph[1] != 1.0f) != 0) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) oacc[qb][hb] *= alph[qb];
+        }
 
         // ---- O^T += V^T . P^T
 #pragma unroll
@@ -217,6 +243,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
                 oacc[0][hb] = ET<T>::mfma(vf, pf[0][ks], oacc[0][hb]);
                 oacc[1][hb] = ET<T>::mfma(vf, pf[1][ks], oacc[1][hb]);
             }
+        if (DB) __syncthreads();  // tile kt consumed by every wave; tile kt+1's commit visible
     }
 
     // ---- epilogue: O[query][h*HD + hb*16 + fg*4 + j] = O^T / l
@@ -236,14 +263,23 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     }
 }
 
-void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s) {
-    dim3 grid((max_q + 127) / 128, a.Hq, B), block(256);
+template <int VAR> static void launch_flash_v(const FlashArgs& a, int hd, bool causal, dim3 grid, hipStream_t s) {
+    dim3 block(256);
     DT_SWITCH(a.dt, T, {
-        if (hd == 64 && !causal) hipLaunchKernelGGL((flash_attn_kernel<T, 64, false>), grid, block, 0, s, a);
-        else if (hd == 64 && causal) hipLaunchKernelGGL((flash_attn_kernel<T, 64, true>), grid, block, 0, s, a);
-        else if (hd == 128 && causal) hipLaunchKernelGGL((flash_attn_kernel<T, 128, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((flash_attn_kernel<T, 128, false>), grid, block, 0, s, a);
+        if (hd == 64 && !causal) hipLaunchKernelGGL((flash_attn_kernel<T, 64, false, VAR>), grid, block, 0, s, a);
+        else if (hd == 64 && causal) hipLaunchKernelGGL((flash_attn_kernel<T, 64, true, VAR>), grid, block, 0, s, a);
+        else if (hd == 128 && causal) hipLaunchKernelGGL((flash_attn_kernel<T, 128, true, VAR>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((flash_attn_kernel<T, 128, false, VAR>), grid, block, 0, s, a);
     });
+}
+void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s) {
+    dim3 grid((max_q + 127) / 128, a.Hq, B);
+    switch (g_opts.flash_variant & 3) {
+        case 1: launch_flash_v<1>(a, hd, causal, grid, s); break;
+        case 2: launch_flash_v<2>(a, hd, causal, grid, s); break;
+        case 3: launch_flash_v<3>(a, hd, causal, grid, s); break;
+        default: launch_flash_v<0>(a, hd, causal, grid, s); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,6 +60,9 @@ struct LaunchOpts {
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
     int decode_attn_v1 = 0;    // decode attention with P.V on the VALU (round 2), for A/B runs
+    int flash_variant = 2;     // prefill / encoder attention: bit 0 two LDS buffers + one barrier per tile (no gain measured), bit 1 lazy accumulator rescale (-0.6 ms per batch; default)
+    int gemm256_persist = 0;   // 1: 16-bit 256x256 GEMM as one persistent launch (gemm256p.hip) - measured SLOWER than one block per tile (round 3), kept for A/B
+    int gemm256_gm = 8;        // 256x256 GEMM raster: M tiles per group (a group sweeps all N tiles before the next M rows)
 };
 extern thread_local LaunchOpts g_opts;
 
@@ -135,6 +138,7 @@ struct GemmArgs {
     // bf16 GELU by table (256x256 kernel, EPI_BIAS_GELU): GELU of a bf16 value is a function of 65536 inputs; the compact table
     // (GELU_LUT_N bf16 bit patterns: both signs x exponents 2^-14 .. 2^3 x 128 mantissas) is copied to LDS and indexed by the bits
     const unsigned short* gelu_lut;
+    int raster_gm;                   // 256x256 kernel: M tiles per raster group (0: default 8)
 };
 #define GELU_LUT_E0 113                     // biased exponent of 2^-14
 #define GELU_LUT_NE 18                      // exponents 2^-14 .. 2^3  (|x| < 16)

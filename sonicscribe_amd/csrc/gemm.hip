@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 
 bool gemm256_eligible(const GemmArgs& a, int epi);
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);
+void launch_gemm256p(const GemmArgs& a, int epi, int cus, hipStream_t s);
 thread_local LaunchOpts g_opts;
 
 static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s);
@@ -226,6 +227,11 @@ static int device_cus() {
     static int n = 0;
     if (!n) { int dev = 0; hipDeviceProp_t p; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     return n;
+}
+// the 256x256 tile: persistent kernel for the 16-bit kinds (gemm256p.hip), one launch per tile round otherwise (int8 kinds, batched conv stem)
+static void launch_tile256(const GemmArgs& a, int epi, hipStream_t s) {
+    if (!a.q.sca && a.batch <= 1 && g_opts.gemm256_persist) launch_gemm256p(a, epi, device_cus(), s);
+    else launch_gemm256(a, epi, s);
 }
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     if (!g_opts.gemm_force128 && gemm256_eligible(a, epi)) {
@@ -237,7 +243,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
             const long full = (long)((a.M + 255) / 256) * ntn, main_tiles = (long)(Mm / 256) * ntn;
             if ((main_tiles + cus - 1) / cus < (full + cus - 1) / cus) {
                 GemmArgs m = a; m.M = Mm;
-                launch_gemm256(m, epi, s);
+                launch_tile256(m, epi, s);
                 GemmArgs t = a; t.M = tail; t.C = a.C + (long)Mm * a.ldc;
                 if (a.R) t.R = a.R + (long)Mm * a.ldr;
                 if (a.q.sca) {
@@ -247,6 +253,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
                     // compositions differed from its solo result, found by tools/find_batch_dependence.py.)
                     t.A = (const bf16_t*)((const int8_t*)a.A + (long)Mm * a.lda);
                     t.q.sca = a.q.sca + Mm; t.q.x16 = a.q.x16 + (long)Mm * a.q.ldx16; t.q.row_off = a.q.row_off + Mm;
+                    if (a.q.defer_out) t.q.defer_out = a.q.defer_out + (long)Mm * a.ldc;
                 } else {
                     t.A = a.A + (long)Mm * a.lda;
                 }
@@ -254,7 +261,7 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
                 return;
             }
         }
-        launch_gemm256(a, epi, s);
+        launch_tile256(a, epi, s);
         return;
     }
     launch_gemm128(a, epi, s);

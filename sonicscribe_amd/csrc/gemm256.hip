@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     }
     int tm, tn;
     {
-        const int GM = 8, gsz = GM * tilesN, g = id / gsz, first = g * GM;
+        const int GM = a.raster_gm > 0 ? a.raster_gm : 8, gsz = GM * tilesN, g = id / gsz, first = g * GM;
         const int gm = min(GM, tilesM - first), in = id - g * gsz;
         tm = first + in % gm;
         tn = in / gm;
@@ -484,7 +484,11 @@ template <typename KD, int EPI, bool STG> static void launch256v(const GemmArgs&
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
     hipLaunchKernelGGL((gemm256_kernel<KD, EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS, s, a);
 }
-template <int EPI> static void launch256(const GemmArgs& a, hipStream_t s) {
+template <int EPI> static void launch256(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    // raster group height: 8 M tiles per group; 2 when the matrix is at most 5 tiles wide (out_proj / fc2 of the encoder, N = 1280: +3-6 %
+    // at M = 48000, tools/ab_gemm_raster.py); the option overrides both
+    if (a.raster_gm <= 0) a.raster_gm = g_opts.gemm256_gm != 8 ? g_opts.gemm256_gm : ((a.N + T256 - 1) / T256 <= 5 ? 2 : 8);
     if (a.q.sca) { if constexpr (EPI != EPI_QKV_VT) launch256v<KI8, EPI, true>(a, s); }
     else if (a.dt == DT_F16) launch256v<KF16, EPI, true>(a, s);
     else if (g_opts.gemm256_stagger) launch256v<KBF16, EPI, true>(a, s);
