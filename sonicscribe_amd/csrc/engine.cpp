@@ -1303,7 +1303,6 @@ static void ring_free(sonic_ring* r) {
         std::lock_guard<std::mutex> lk(r->mu);
         (void)hipSetDevice(r->e->device);
         (void)hipStreamSynchronize(r->st);
-        if (r->read_pending) (void)hipEventSynchronize(r->read_ev);
         (void)hipFree(r->buf); (void)hipHostFree(r->host); (void)hipStreamDestroy(r->st); (void)hipEventDestroy(r->read_ev); (void)hipEventDestroy(r->app_ev);
     }
     delete r;
@@ -1328,28 +1327,33 @@ extern "C" int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, i
     if (!r || (!pcm && n > 0) || n < 0) return SONIC_ERR_INVALID;
     std::lock_guard<std::mutex> lk(r->mu);
     if (n > r->cap) return SONIC_ERR_INVALID;
-    if (hipSetDevice(r->e->device) != hipSuccess) return SONIC_ERR_HIP;
-    if (r->read_pending) {                                                                                 // do not overwrite what a staging kernel still reads
-        // The runtime refuses this wait ("dependency created on uncaptured work in another stream") while the engine's thread is
-        // capturing its decode graph on the stream the event was recorded on, although the record itself preceded the capture.  The
-        // staging kernels are microseconds long: wait for the event on the host then, and leave no sticky error behind for this
-        // thread's next call (found by tests/test_gpu_sessions.py: the stale error failed an unrelated engine call later on).
-        if (hipStreamWaitEvent(r->st, r->read_ev, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipEventSynchronize(r->read_ev) != hipSuccess) { (void)hipGetLastError(); return SONIC_ERR_HIP; }
-        }
-        r->read_pending = false;
-    }
+    // failures are reported through sonic_last_error(NULL) of the calling thread (appends do not take the engine lock, so they cannot
+    // write the engine's own error string)
+    auto hip_fail = [&](const char* what, hipError_t er) { (void)hipGetLastError(); return fail(nullptr, SONIC_ERR_HIP, "sonic_ring_append: %s failed: %s", what, hipGetErrorString(er)); };
+    hipError_t er = hipSetDevice(r->e->device);
+    if (er != hipSuccess) return hip_fail("hipSetDevice", er);
+    // No device-side ordering against the staging kernels is needed: a batch holds the locks of its rings from the range check until its
+    // staging kernels have COMPLETED (stage_mixed_locked ends with a stream synchronise), and this function runs under the ring's lock.
+    // (Rounds 2-3 also recorded an event behind the staging kernels and made the ring's stream wait for it here.  The runtime refuses
+    // both hipStreamWaitEvent and hipEventSynchronize on an event whose stream is capturing at that moment - the engine thread captures a
+    // decode graph for every new batch size - "operation not permitted on an event last recorded in a capturing stream": an append then
+    // failed, or left a sticky error that failed an unrelated call later.  Found by tests/test_gpu_sessions.py in full-suite runs.)
     const int64_t pos = r->head % r->cap, first = n < r->cap - pos ? n : r->cap - pos;
     // A mirror slot is rewritten one full capacity later (30 s of audio), normally long after its copy has left; the stream is
     // drained before an append could overwrite samples whose copy has not been waited for (small rings, bursts).
-    hipError_t er = hipSuccess;
-    if (r->unsynced + n > r->cap) { if (hipStreamSynchronize(r->st) != hipSuccess) return SONIC_ERR_HIP; r->unsynced = 0; }
+    if (r->unsynced + n > r->cap) { er = hipStreamSynchronize(r->st); if (er != hipSuccess) return hip_fail("hipStreamSynchronize", er); r->unsynced = 0; }
     r->unsynced += n;
-    if (first > 0) { memcpy(r->host + pos, pcm, (size_t)first * 2); er = hipMemcpyAsync(r->buf + pos, r->host + pos, (size_t)first * 2, hipMemcpyHostToDevice, r->st); }
-    if (er == hipSuccess && n > first) { memcpy(r->host, pcm + first, (size_t)(n - first) * 2); er = hipMemcpyAsync(r->buf, r->host, (size_t)(n - first) * 2, hipMemcpyHostToDevice, r->st); }
-    if (er == hipSuccess && n > 0) { er = hipEventRecord(r->app_ev, r->st); r->app_pending = true; }
-    if (er != hipSuccess) return SONIC_ERR_HIP;
+    if (first > 0) {
+        memcpy(r->host + pos, pcm, (size_t)first * 2);
+        er = hipMemcpyAsync(r->buf + pos, r->host + pos, (size_t)first * 2, hipMemcpyHostToDevice, r->st);
+        if (er != hipSuccess) return hip_fail("hipMemcpyAsync", er);
+    }
+    if (n > first) {
+        memcpy(r->host, pcm + first, (size_t)(n - first) * 2);
+        er = hipMemcpyAsync(r->buf, r->host, (size_t)(n - first) * 2, hipMemcpyHostToDevice, r->st);
+        if (er != hipSuccess) return hip_fail("hipMemcpyAsync (wrap)", er);
+    }
+    if (n > 0) { er = hipEventRecord(r->app_ev, r->st); if (er != hipSuccess) return hip_fail("hipEventRecord", er); r->app_pending = true; }
     if (first_index) *first_index = r->head;
     r->head += n;
     return SONIC_OK;
@@ -1410,7 +1414,6 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
         ra.peak = e->ring_peak; ra.pcm = e->pcm; ra.win_cap = cap;
         launch_fill_i32(e->ring_peak, 0, e->Bm, e->st);
         launch_ring_stage(ra, W, max_n, e->st);
-        for (sonic_ring* rg : used) { (void)hipEventRecord(rg->read_ev, e->st); rg->read_pending = true; }   // (appends also order behind them on the device)
     }
     HIPC(e, hipMemcpyAsync(e->n_samples_d, e->n_samples_h.data(), (size_t)W * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipStreamSynchronize(e->st));

@@ -171,7 +171,7 @@ class Ring:
         first = C.c_int64(0)
         rc = self.engine.lib.sonic_ring_append(self.h, _p(a) if a.size else None, a.size, C.byref(first))
         if rc != 0:
-            raise RuntimeError(f"sonic_ring_append failed with status {rc}")
+            raise RuntimeError(f"sonic_ring_append failed with status {rc}: " + (self.engine.lib.sonic_last_error(None) or b"").decode())
         return int(first.value)
 
     @property

@@ -30,7 +30,7 @@ def test_destroy_returns_weights_and_kv_cache():
     ids_a, _ = a.transcribe_batch(seg, [prompt], [6])
     a.close()
     free1 = device_info(0)["free_bytes"]
-    assert free1 > free0 - 2 ** 28, (free0, free1)                  # everything but the pooled activation buffers (< 256 MiB) is back
+    assert free1 > free0 - 2 ** 29, (free0, free1)                  # everything but the pooled activation buffers and the runtime's own state (< 512 MiB) is back
     b = Engine(d, 0, max_batch=8, max_ctx=512)                      # a reload with other sizes
     b.load_synthetic(1)
     alloc_b, res_b = b.memory_info()
@@ -38,4 +38,4 @@ def test_destroy_returns_weights_and_kv_cache():
     ids_b, _ = b.transcribe_batch(seg, [prompt], [6])
     assert np.array_equal(ids_a[0], ids_b[0])
     b.close()
-    assert device_info(0)["free_bytes"] > free0 - 2 ** 28
+    assert device_info(0)["free_bytes"] > free0 - 2 ** 29
