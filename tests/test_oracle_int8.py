@@ -59,7 +59,11 @@ def test_outlier_column_is_per_call():
     base = oracle.linear_int8(x, cb, scb)
     x2 = x.copy(); x2[3, 40] = 9.0
     y2 = oracle.linear_int8(x2, cb, scb)
-    assert np.array_equal(y2[:3], y2[:3]) and not np.array_equal(base[0], y2[0])            # row 0 changed although only row 3 holds the outlier
+    # rows 0..2 of the call WITH the outlier row equal the numpy statement of the whole 8-row call (column 40 out of the int8 product for
+    # every row, added back in fp16), and differ from the call without the outlier although only row 3 holds it
+    assert np.array_equal(y2, numpy_linear8bit(x2, w, None)) and not np.array_equal(base[0], y2[0])
+    without_col = oracle.linear_int8(np.delete(x2, 40, axis=1), *oracle.quantize_rows(np.delete(w, 40, axis=1)))
+    assert np.abs(y2[:3] - without_col[:3] - f16(x2[:3, 40:41] * f16(cb[:, 40].astype(np.float32) * scb / 127.0)[None, :])).max() < 2e-2   # = int8 part without column 40 + its fp16 product
     alone = oracle.linear_int8(x2[:3], cb, scb)                                                # rows 0..2 as their own call: no outlier column
     assert np.array_equal(alone, base[:3])
 
