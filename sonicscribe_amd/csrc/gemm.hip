@@ -757,9 +757,13 @@ static int skinny_pick_kw(int K) {
         if (K % (256 * kw) == 0 && K / (256 * kw) <= 8) return kw;
     return 0;
 }
-// config: 1 = BIG (64 rows x 1024 k per block), 2 = SMALL (32 rows x 512 k), 0 = one-shot register kernel (small K)
+// config: 1 = BIG (64 rows x 1024 k per block), 3 = 64 rows x 768 k, 2 = SMALL (32 rows x 512 k), 0 = one-shot register kernel (small K)
 static int skinny_pick_cfg(int N, int K) {
     if (g_opts.skinny_variant >= 2) return 0;
+    // 768-deep slices where they put a block on more CUs than 1024-deep ones without exceeding one block per CU: down_proj of the full-size
+    // model (2048 x 6144) is 32 x 8 = 256 blocks instead of 32 x 6 = 192 - the weight stream is bound by how many CUs pull it
+    if (!g_opts.no_skinny768 && K % 768 == 0 && N % 64 == 0 && K / 768 <= 8 && (long)(N / 64) * (K / 768) <= 256 &&
+        (K % 1024 != 0 || (long)(N / 64) * (K / 768) > (long)(N / 64) * (K / 1024)) && (long)(N / 64) * (K / 768) >= 192) return 3;
     if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8 && (long)(N / 64) * (K / 1024) >= 192) return 1;
     if (K % 512 == 0 && N % 32 == 0 && K / 512 <= 8) return 2;
     if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8) return 1;
@@ -768,6 +772,7 @@ static int skinny_pick_cfg(int N, int K) {
 int skinny_pick_ksplit(int N, int K) {
     const int cfg = skinny_pick_cfg(N, K);
     if (cfg == 1) return K / 1024;
+    if (cfg == 3) return K / 768;
     if (cfg == 2) return K / 512;
     const int kw = skinny_pick_kw(K);
     return kw ? K / (256 * kw) : 0;
@@ -797,6 +802,7 @@ template <typename KD, int MB, int WN, int WK, int KSW> static void launch_xs_v(
 }
 template <typename KD, int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
     if (cfg == 1) launch_xs_v<KD, MB, 4, 2, 16>(a, a.K / 1024, s);
+    else if (cfg == 3) launch_xs_v<KD, MB, 4, 2, 12>(a, a.K / 768, s);
     else launch_xs_v<KD, MB, 2, 4, 4>(a, a.K / 512, s);
 }
 // int8 operands (Linear8bitLt decode step): one kernel family, 32 weight rows x (4 * KSW * 64) of K per block
