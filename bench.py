@@ -12,15 +12,21 @@ replica per GPU, no data-path collective): weak scaling, value = all ranks' segm
 The JSON line also carries
   roofline      the time-dominant part of a step, the greedy decode loop (HBM-bound: decoder weights + tied lm_head + KV cache once per
                 token step): algorithmic bytes per token step / its average duration, measured with HIP events on the engine's stream
-                around the decode loop of every timed step
+                around the decode loop of every timed step; traffic_from_profile = the committed PMC passes (profiles/, with their commit)
   encoder_gemms / encoder_fc1_gemm / mel_frontend   the MFMA- and HBM-side figures SURVEY.md 8d names
+  pcie_inclusive          the same batch through the one-call boundary (host PCM in, host ids out); never the headline
   two_batches_in_flight   NOT the headline: throughput with a second, independent batch of 32 on the same GPU at the same time (N=1 only;
                 shows how much of the decode loop's loss is latency; --no-two-chains skips it, use that under a profiler)
+  int8_b64 / bf16_b64     BASELINE config 4 (INT8 weight path, batch 64) and the bf16 figure at the same batch, same process, same box
+  streaming               BASELINE config 5's call pattern at its per-GPU share (16 sessions), real-time schedule: partial / final latency
   cpu_baseline  the reference's DEVICE=cpu arithmetic (transformers GlmAsrForConditionalGeneration.generate, bf16, B=1, full depth,
-                150 tokens, asr.py thread rule) timed on the host cores, rank 0 at N=1 only
+                150 tokens, 64 threads) timed on the host cores, rank 0 at N=1 only; the worker process is spawned before this process
+                initialises the GPU and stays idle until the GPU legs are done (2 warm-ups + 5 full passes then)
+(--no-extras skips int8_b64 / bf16_b64 / streaming / pcie_inclusive; a default run takes about five minutes, most of it the CPU passes.)
 
-  python bench.py --mode int8 --batch 64     BASELINE config 4 (the repo's INT8 option)
+  python bench.py --mode int8 --batch 64     BASELINE config 4 alone
   python bench.py --streaming                BASELINE config 5's call pattern (sessions x partial / final decodes through the coalescer)
+  torchrun ... bench.py --gpus N [--dist-backend gloo --share-gpu]    N ranks (gloo + shared device: the N-rank path on fewer GPUs)
 """
 from __future__ import annotations
 
