@@ -510,6 +510,8 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_acc[NW][GMAX][HD];
     __shared__ float s_m[NW][GMAX], s_l[NW][GMAX];
     __shared__ __attribute__((aligned(16))) T s_q[GMAX + 2][HD];   // q heads (unscaled), then k, v of the new token (all T values)
+    __shared__ int s_ok[OUTL_CAP];                                 // int8 mode: the row's outlier pairs (int8_util.h)
+    __shared__ float s_ox[OUTL_CAP];
     const int G = a.Hq / a.Hkv;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;                        // S: head column r, keys 4g..4g+3;  K rows: key r, dim chunk g;  V: piece r of keys 4g..4g+3
@@ -536,11 +538,17 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         const int w = tid, vi = w / HALF, i = w % HALF;      // vector (q heads.., k, v), index in the first half; (G + 2) * 64 <= 384 threads
         const bool act = w < (G + 2) * HALF;
         float x1 = 0.f, x2 = 0.f;
+        const int col = act ? (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i : 0;
+        if (a.dq.sca) {
+            // int8 mode: int32 slabs of the quantised q/k/v projections -> fp16 module outputs (LLM.int8 dequant + outliers); the
+            // row's outlier pairs are requested with the slabs and shared through LDS
+            const OutlStage os = outl_issue(a.dq, b);
+            const Slab1x2 sl = slab1x2_load(a.dq, a.P, a.ksplit, a.mpad, b, col, HALF, N);
+            outl_commit(a.dq, b, os, s_ok, s_ox);
+            if (act) slab1x2_finish(a.dq, a.P, a.ksplit, a.mpad, b, col, HALF, N, sl, os, s_ok, s_ox, x1, x2);
+        }
         if (act) {
-            const int col = (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i;
             if (a.dq.sca) {
-                // int8 mode: int32 slabs of the quantised q/k/v projections -> fp16 module outputs (LLM.int8 dequant + outliers)
-                x1 = deq1(a.dq, a.P, a.ksplit, a.mpad, b, col, N); x2 = deq1(a.dq, a.P, a.ksplit, a.mpad, b, col + HALF, N);
             } else {
                 // all slab loads in flight at once (a rolled loop would serialise one L2 round trip per slab); fixed summation order
                 float v1[8], v2[8];

@@ -24,9 +24,11 @@ __device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active,
         for (int j = 0; j < 8; ++j) { const float a = fabsf(y[j]); if (a < LLM_INT8_THRESHOLD) amax = fmaxf(amax, a); else ++cnt; }
     }
     amax = wave_max(amax);
-    int incl = cnt;                                   // inclusive scan of the outlier counts inside the wave
+    int incl = cnt;                                   // inclusive scan of the outlier counts inside the wave (only where the wave holds any)
+    if (__ballot(cnt > 0)) {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    }
     __syncthreads();                                  // scratch may still be in use by the caller
     if (lane == 63) s_i[wid] = incl;
     if (lane == 0) s_f[wid] = amax;
@@ -43,7 +45,11 @@ __device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active,
             const bool out = !(fabsf(y[j]) < LLM_INT8_THRESHOLD);
             int qv = (out || !(bm > 0.f)) ? 0 : (int)rintf(y[j] * scale);
             pk[j >> 2] |= (qv & 0xFF) << ((j & 3) * 8);
-            if (out) qo.oc_list[(long)row * qo.oc_ld + pos++] = c * 8 + j;
+            if (out) {
+                const long at = (long)row * qo.oc_ld + pos++;
+                qo.oc_list[at] = c * 8 + j;
+                if (qo.oc_val) qo.oc_val[at] = y[j];
+            }
         }
         *(int2*)(qo.q + (long)row * qo.ldq + c * 8) = make_int2(pk[0], pk[1]);
     }
@@ -133,19 +139,28 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
     typedef typename ET<T>::v8 V8;
     __shared__ float part[16];
     __shared__ int parti[17];
+    __shared__ int s_ok[OUTL_CAP];
+    __shared__ float s_ox[OUTL_CAP];
     const int row = blockIdx.x, c = threadIdx.x, lane = c & 63, wid = c >> 6;
     const int nv = d >> 3;
     float v[8];
     float s = 0.f;
-    if (c < nv) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        T* xr = x + (long)row * d + c * 8;
-        const V8 t = *(const V8*)xr;
-        if (dq.sca) {
-            const f32x4 a0 = deq4(dq, P, ksplit, mpad, row, c * 8, d), a1 = deq4(dq, P, ksplit, mpad, row, c * 8 + 4, d);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    T* xr = x + (long)row * d + (c < nv ? c : 0) * 8;
+    const V8 t = *(const V8*)xr;                      // (requested before the slabs: one round trip for both)
+    if (dq.sca) {
+        // int8: the row's outlier pairs and this thread's slabs are requested together, the pairs go through LDS (int8_util.h)
+        const OutlStage os = outl_issue(dq, row);
+        const int col[1] = {c < nv ? c * 8 : 0};
+        const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
+        outl_commit(dq, row, os, s_ok, s_ox);
+        float a[1][8];
+        slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] = a0[j]; acc[4 + j] = a1[j]; }
-        } else {
+        for (int j = 0; j < 8; ++j) acc[j] = a[0][j];
+    }
+    if (c < nv) {
+        if (!dq.sca) {
             // every slab load is issued before the first add (a rolled ksplit loop costs one L2 round trip per slab); the sum keeps its
             // fixed order ks = 0, 1, ...
             f32x4 a0[8], a1[8];
@@ -217,18 +232,23 @@ __global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 
 __global__ __launch_bounds__(1024) void swiglu_quant_kernel(const float* P, int ksplit, int mpad, int ff, f16_t* act, DeqInfo dq, QuantOut qo) {
     __shared__ float part[16];
     __shared__ int parti[17];
+    __shared__ int s_ok[OUTL_CAP];
+    __shared__ float s_ox[OUTL_CAP];
     const int row = blockIdx.x, c = threadIdx.x;
     const bool active = c * 8 < ff;
+    // act columns [8c, 8c + 8) = gate columns [base, base + 8) and up columns [base + 16, base + 24) of the interleaved projection
+    const int base = active ? (c >> 1) * 32 + (c & 1) * 8 : 0;
+    const int col[2] = {base, base + 16};
+    const OutlStage os = outl_issue(dq, row);
+    const Slab8<2, 2> sl = slab8_load<2, 2>(dq, P, ksplit, mpad, row, col, 2 * ff);
+    outl_commit(dq, row, os, s_ok, s_ox);
+    float gu[2][8];
+    slab8_finish<2, 2>(dq, P, ksplit, mpad, row, col, 2 * ff, sl, os, s_ok, s_ox, gu);
     float y[8];
     if (active) {
         f16x8 o;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c4 = c * 8 + h * 4, ng = (c4 >> 4) * 32 + (c4 & 15);
-            const f32x4 g = deq4(dq, P, ksplit, mpad, row, ng, 2 * ff), u = deq4(dq, P, ksplit, mpad, row, ng + 16, 2 * ff);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { o[h * 4 + j] = (f16_t)(rT<f16_t>(silu_f(g[j])) * u[j]); y[h * 4 + j] = (float)o[h * 4 + j]; }
-        }
+        for (int j = 0; j < 8; ++j) { o[j] = (f16_t)(rT<f16_t>(silu_f(gu[0][j])) * gu[1][j]); y[j] = (float)o[j]; }
         *(f16x8*)(act + (long)row * ff + c * 8) = o;
     }
     quant_emit_row(y, active, c, row, qo, part, parti);

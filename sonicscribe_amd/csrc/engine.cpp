@@ -63,6 +63,7 @@ struct sonic_engine {
     // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
+    float *ov_hn = nullptr, *ov_att = nullptr, *ov_act = nullptr;      // the outliers' values beside the lists
     std::map<std::string, bool> raw_f16;   // int8 mode: tensors already converted to fp16 at load
     bf16_t* embed = nullptr; bf16_t* embed_t = nullptr;
     std::vector<DecLayerW> dec;
@@ -492,6 +493,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
         A(dalloc(e, &e->sca_hn, 64)); A(dalloc(e, &e->sca_att, 64)); A(dalloc(e, &e->sca_act, 64));
         A(dalloc(e, &e->oc_hn, 64)); A(dalloc(e, &e->oc_att, 64)); A(dalloc(e, &e->oc_act, 64));
         A(dalloc(e, &e->ol_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ol_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ol_act, (size_t)64 * d.dec_ff));
+        A(dalloc(e, &e->ov_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ov_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ov_act, (size_t)64 * d.dec_ff));
     }
     A(dalloc(e, &e->src, tc)); A(dalloc(e, &e->tok_seq, tc)); A(dalloc(e, &e->tok_pos_pf, tc));
     A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
@@ -946,7 +948,7 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     g.norm_w = e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
     g.force_ids = e->force_d; g.force_ld = e->force_ld;
     g.dt = e->dt;
-    if (e->i8) g.qo = QuantOut{e->hn_q, d.dec_d, e->sca_hn, e->oc_hn, e->ol_hn, d.dec_d};     // layer 0's q/k/v input, quantised
+    if (e->i8) g.qo = QuantOut{e->hn_q, d.dec_d, e->sca_hn, e->oc_hn, e->ol_hn, d.dec_d, e->ov_hn};     // layer 0's q/k/v input, quantised
     return g;
 }
 
@@ -1002,12 +1004,12 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
 static void decode_step_i8(sonic_engine* e, int R, bool dump) {
     const sonic_dims& d = e->d;
     const int D = d.dec_d, FF = d.dec_ff, mpad = ((R + 15) / 16) * 16;
-    const QuantOut q_hn{e->hn_q, D, e->sca_hn, e->oc_hn, e->ol_hn, D};
-    const QuantOut q_att{e->att_q, e->QD, e->sca_att, e->oc_att, e->ol_att, e->QD};
-    const QuantOut q_act{e->act_q, FF, e->sca_act, e->oc_act, e->ol_act, FF};
+    const QuantOut q_hn{e->hn_q, D, e->sca_hn, e->oc_hn, e->ol_hn, D, e->ov_hn};
+    const QuantOut q_att{e->att_q, e->QD, e->sca_att, e->oc_att, e->ol_att, e->QD, e->ov_att};
+    const QuantOut q_act{e->act_q, FF, e->sca_act, e->oc_act, e->ol_act, FF, e->ov_act};
     auto deq = [&](const QuantOut& q, const QW& w, int K, const bf16_t* x16) {
         DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.cbt = w.cbt; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
-        dq.row_group = nullptr; dq.group_div = 1;
+        dq.row_group = nullptr; dq.group_div = 1; dq.oc_val = q.oc_val;
         return dq;
     };
     for (int l = 0; l < d.dec_layers; ++l) {
@@ -1830,6 +1832,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "no_skinny_i8_wide")) { e->opts.no_skinny_i8_wide = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
     if (!strcmp(key, "flash_variant")) { e->opts.flash_variant = value; return SONIC_OK; }
     if (!strcmp(key, "gemm256_persist")) { e->opts.gemm256_persist = value; return SONIC_OK; }
@@ -1864,6 +1867,9 @@ extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, fl
     else if (!strcmp(name, "datt")) { src = e->datt; cap = (size_t)e->tok_cap * e->QD; }
     else if (!strcmp(name, "dact")) { src = e->dact; cap = (size_t)e->tok_cap * d.dec_ff; }
     else if (!strcmp(name, "enc_x")) { src = e->ln; cap = (size_t)e->Bm * e->T * d.enc_d; }
+    else if (!strcmp(name, "shn")) { src = e->shn; cap = (size_t)64 * d.dec_d; }          // decode-step buffers as the last step left them
+    else if (!strcmp(name, "satt")) { src = e->satt; cap = (size_t)64 * e->QD; }
+    else if (!strcmp(name, "sact")) { src = e->sact; cap = (size_t)64 * d.dec_ff; }
     else return fail(e, SONIC_ERR_INVALID, "unknown buffer %s", name);
     if (n < 0 || (size_t)n > cap) return fail(e, SONIC_ERR_INVALID, "read of %lld elements exceeds buffer %s", (long long)n, name);
     TmpBuf tb(e->st);

@@ -351,18 +351,23 @@ __global__ __launch_bounds__(512) void skinny_readfloor_kernel(SkinnyArgs a) {
 // source address, conflict-free ds_read_b128 fragments) and read by all 8 waves; weights go straight to VGPRs from the
 // fragment-tiled copy (every wave load is one contiguous 1 KiB, each weight byte read once, nontemporal).  The WK
 // K-slices of a block are summed through LDS; K/BKk slabs are left for the consumer (2 for K = 2048 with BKk = 1024).
-template <typename KD, int MB, int WN, int WK, int KSW>
+// NT = 16-row weight tiles per wave (default 1).  The per-CU vector-memory pipe bounds these kernels (W bytes + the X image of every
+// block that lands on the CU), so at 48-64 activation rows - where the image of a 1024-deep slice is 64 KiB of int8 - a block should own as
+// many weight rows as keeps the grid at one block per CU: gate/up of the full-size model as 96 rows x 1024 (128 x 2 = 256 blocks, 96 KiB
+// of W per 64 KiB image) instead of 32 rows x 1024 (768 blocks, three images per CU).
+template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1>
 __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     typedef typename KD::elem ET_; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
     // element size; elements per 16-B chunk, per MFMA k-step, per 128-B LDS row, per 1-KiB weight tile
     constexpr int EB = sizeof(ET_), CE = 16 / EB, KS = 64 / EB, ROWE = 128 / EB, TILE_E = 1024 / EB;
     constexpr int BKk = WK * KSW * KS, NKB = BKk / ROWE, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048, PW = (NI + 7) / 8;
+    constexpr int NL = NT * KSW;                                     // weight loads of a wave
     static_assert(WN * WK == 8 && (WK * KSW) % 2 == 0, "8 waves, whole 128-byte K blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int wn = wid % WN, wk = wid / WN;
-    const int n0 = blockIdx.x * (WN * 16) + wn * 16;
+    const int n0 = blockIdx.x * (WN * NT * 16) + wn * NT * 16;
     const int kb = blockIdx.y * BKk;
     KT(a, 0);
     // X slice first (small, out of L2): it has to be complete in LDS - for all waves - before the first MFMA
@@ -383,41 +388,54 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     // then the weights (HBM, nontemporal): asm loads with hand-counted waits, so that k-step u is multiplied as soon as ITS fragment
     // has landed (vmcnt retires in order) instead of after the whole slice - the compiler's own bookkeeping falls back to vmcnt(0)
     // when LDS-DMA and register loads are in flight together
+    const long tile_stride = (long)(a.K / KS) * TILE_E;              // elements between the 16-row tiles n and n + 16 at one k-step
     const ET_* wp = (const ET_*)a.W + ((long)(n0 >> 4) * (a.K / KS) + ((kb + wk * (KSW * KS)) / KS)) * TILE_E + lane * CE;
-    Frag wf[KSW];
+    Frag wf[NT][KSW];
 #pragma unroll
-    for (int u = 0; u < KSW; ++u) {
-        if (u < 4) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp), "n"(u * 1024) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[u]) : "v"(wp + (u / 4) * 4 * TILE_E), "n"((u % 4) * 1024) : "memory");
-    }
-    Acc acc[MB];
+    for (int u = 0; u < KSW; ++u)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+        for (int t = 0; t < NT; ++t) {
+            const ET_* wpt = wp + t * tile_stride;
+            if (u < 4) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[t][u]) : "v"(wpt), "n"(u * 1024) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[t][u]) : "v"(wpt + (u / 4) * 4 * TILE_E), "n"((u % 4) * 1024) : "memory");
+        }
+    Acc acc[NT][MB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[mb][e] = 0;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][mb][e] = 0;
     KT(a, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KSW) : "memory");      // this wave's X pieces are in LDS
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");       // this wave's X pieces are in LDS
     __builtin_amdgcn_s_barrier();                                    // (raw barrier: __syncthreads would add a vmcnt(0) fence)
     KT(a, 2);
 #pragma unroll
     for (int u = 0; u < KSW; ++u) {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[u]) : "n"(KSW - 1 - u) : "memory");
         const int kg = wk * KSW + u, kblock = kg >> 1, half = kg & 1;
+        Frag xf[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int m = mb * 16 + r;
-            const Frag xf = *(const Frag*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
-            acc[mb] = KD::mfma(wf[u], xf, acc[mb]);
+            xf[mb] = *(const Frag*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[t][u]) : "n"(NL - 1 - (u * NT + t)) : "memory");
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[t][mb] = KD::mfma(wf[t][u], xf[mb], acc[t][mb]);
         }
     }
     KT(a, 3);
     __syncthreads();
     KT(a, 4);
-    Acc* red = (Acc*)smem;   // [WK][WN][MB][64]
+    Acc* red = (Acc*)smem;   // [WK][WN * NT][MB][64]
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) red[((wk * WN + wn) * MB + mb) * 64 + lane] = acc[mb];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) red[((wk * (WN * NT) + wn * NT + t) * MB + mb) * 64 + lane] = acc[t][mb];
     __syncthreads();
-    constexpr int BNR = WN * 16, mpad = MB * 16;
+    constexpr int BNR = WN * NT * 16, mpad = MB * 16;
     const int nb0 = blockIdx.x * BNR;
     for (int o = tid; o < BNR * mpad; o += 512) {
         const int m = o / BNR, nl = o % BNR, wn2 = nl >> 4, nloc = nl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3;
@@ -425,12 +443,12 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
         if constexpr (KD::I8) {
             int s = 0;
 #pragma unroll
-            for (int k = 0; k < WK; ++k) s += red[((k * WN + wn2) * MB + (m >> 4)) * 64 + ln][j];
-            ((int*)a.P)[dst] = s;                                    // exact int32 partial product; the consumer dequantises (deq4)
+            for (int k = 0; k < WK; ++k) s += red[((k * (WN * NT) + wn2) * MB + (m >> 4)) * 64 + ln][j];
+            ((int*)a.P)[dst] = s;                                    // exact int32 partial product; the consumer dequantises (int8_util.h)
         } else {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < WK; ++k) s += red[((k * WN + wn2) * MB + (m >> 4)) * 64 + ln][j];
+            for (int k = 0; k < WK; ++k) s += red[((k * (WN * NT) + wn2) * MB + (m >> 4)) * 64 + ln][j];
             a.P[dst] = s;
         }
     }
@@ -793,30 +811,53 @@ template <typename KD, int MB> static void launch_skinny_mb(const SkinnyArgs& a,
         default: launch_skinny_v<KD, MB, 1>(a, s); break;
     }
 }
-template <typename KD, int MB, int WN, int WK, int KSW> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
+template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
     constexpr int EB = sizeof(typename KD::elem), KS = 64 / EB, ROWE = 128 / EB;
     constexpr int NI = (WK * KSW * KS / ROWE) * MB * 2;
-    const size_t img = (size_t)NI * 1024, red = (size_t)8 * MB * 1024, lds = img > red ? img : red;
-    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW>, (int)lds);
-    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW>), dim3(a.N / (WN * 16), nkslices), dim3(512), lds, s, a);
+    const size_t img = (size_t)NI * 1024, red = (size_t)8 * NT * MB * 1024, lds = img > red ? img : red;
+    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW, NT>, (int)lds);
+    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW, NT>), dim3(a.N / (WN * NT * 16), nkslices), dim3(512), lds, s, a);
 }
 template <typename KD, int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
     if (cfg == 1) launch_xs_v<KD, MB, 4, 2, 16>(a, a.K / 1024, s);
     else if (cfg == 3) launch_xs_v<KD, MB, 4, 2, 12>(a, a.K / 768, s);
     else launch_xs_v<KD, MB, 2, 4, 4>(a, a.K / 512, s);
 }
-// int8 operands (Linear8bitLt decode step): one kernel family, 32 weight rows x (4 * KSW * 64) of K per block
-//   K % 1024 == 0: K slices of 1024 (full-size model: qkv 96 x 2, o 64 x 2, gate/up 384 x 2, down 64 x 6 blocks)
-//   else K % 256 == 0: K slices of 256 (tiny test configurations)
+// int8 operands (Linear8bitLt decode step): 32 * NT weight rows x (4 * KSW * 64) of K per block.  The slabs are exact int32 sums, so the
+// K split changes no bit of the result and is chosen per shape for one block per CU (full-size model, 256 CUs):
+//   cfg 1  96 rows x 1024   gate/up 128 x 2 = 256 blocks          (N % 96 == 0, K % 1024 == 0, >= 192 blocks)
+//   cfg 2  64 rows x  768   down     32 x 8 = 256 blocks          (N % 64 == 0, K % 768 == 0, <= 8 slices, >= 192 blocks)
+//   cfg 3  32 rows x  512   o_proj   64 x 4 = 256 blocks          (K % 512 == 0, <= 8 slices, 32 x 1024 would give < 192 blocks, this <= 320)
+//   cfg 0  32 rows x 1024   q/k/v    96 x 2 = 192 blocks          (K % 1024 == 0)
+//   cfg 4  32 rows x  256   tiny test configurations              (K % 256 == 0)
+static int skinny_i8_cfg(int N, int K) {
+    if (N % 32) return -1;
+    if (!g_opts.no_skinny_i8_wide) {
+        if (K % 1024 == 0 && N % 96 == 0 && (long)(N / 96) * (K / 1024) >= 192) return 1;
+        if (K % 768 == 0 && N % 64 == 0 && K / 768 <= 8 && (long)(N / 64) * (K / 768) >= 192 && (long)(N / 64) * (K / 768) <= 320) return 2;
+        if (K % 1024 == 0 && (long)(N / 32) * (K / 1024) < 192 && K / 512 <= 8 && (long)(N / 32) * (K / 512) <= 320) return 3;
+    }
+    if (K % 1024 == 0) return 0;
+    if (K % 256 == 0) return 4;
+    return -1;
+}
 int skinny_pick_ksplit_i8(int N, int K) {
-    if (N % 32) return 0;
-    if (K % 1024 == 0) return K / 1024;
-    if (K % 256 == 0) return K / 256;
-    return 0;
+    switch (skinny_i8_cfg(N, K)) {
+        case 0: case 1: return K / 1024;
+        case 2: return K / 768;
+        case 3: return K / 512;
+        case 4: return K / 256;
+        default: return 0;
+    }
 }
 template <int MB> static void launch_skinny_i8(const SkinnyArgs& a, hipStream_t s) {
-    if (a.K % 1024 == 0) launch_xs_v<KI8, MB, 2, 4, 4>(a, a.K / 1024, s);
-    else launch_xs_v<KI8, MB, 2, 4, 1>(a, a.K / 256, s);
+    switch (skinny_i8_cfg(a.N, a.K)) {
+        case 1: launch_xs_v<KI8, MB, 2, 4, 4, 3>(a, a.K / 1024, s); break;
+        case 2: launch_xs_v<KI8, MB, 2, 4, 3, 2>(a, a.K / 768, s); break;
+        case 3: launch_xs_v<KI8, MB, 2, 4, 2>(a, a.K / 512, s); break;
+        case 0: launch_xs_v<KI8, MB, 2, 4, 4>(a, a.K / 1024, s); break;
+        default: launch_xs_v<KI8, MB, 2, 4, 1>(a, a.K / 256, s); break;
+    }
 }
 template <typename KD> static void launch_skinny_16(const SkinnyArgs& a, hipStream_t s) {
     const int cfg = skinny_pick_cfg(a.N, a.K);

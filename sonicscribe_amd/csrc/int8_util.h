@@ -75,6 +75,192 @@ __device__ __forceinline__ float deq1(const DeqInfo& q, const float* P, int ks, 
     return v;
 }
 
+// ---- decode-step consumers, staged form (round 3) ------------------------------------------------------------------------------
+// deq4 / deq1 walk the row's outlier list once per call: count -> list entry -> x value -> weight bytes, three dependent global round
+// trips per outlier and per call (the SwiGLU consumer made four calls per thread).  Here a block that owns one row fetches the first
+// OUTL_CAP (k, x) pairs ONCE, speculatively and together with the slab loads (one round trip; the producer also stores the x values next
+// to the list, QuantOut.oc_val), parks them in LDS, and every thread then walks them with all weight bytes of two outliers in flight.
+// Same arithmetic, same order of the per-element sums: bit-identical with deq4 / deq1.
+#define OUTL_CAP 64
+struct OutlStage { int kk; float xv; int n, g, cap; };   // cap = pairs staged in LDS = min(OUTL_CAP, block size)
+// loads only; every thread of the block
+__device__ __forceinline__ OutlStage outl_issue(const DeqInfo& q, int row) {
+    OutlStage o;
+    o.g = q.row_group ? q.row_group[row / q.group_div] : row / q.group_div;
+    o.n = q.oc_cnt[o.g];
+    o.kk = 0; o.xv = 0.f;
+    o.cap = min(OUTL_CAP, (int)blockDim.x);
+    const int t = threadIdx.x;
+    if (t < OUTL_CAP) {
+        const long at = (long)o.g * q.oc_ld + min(t, q.oc_ld - 1);
+        o.kk = q.oc_list[at];                              // entries past the count are stale: clamped below, never used
+        if (q.oc_val) o.xv = q.oc_val[at];
+    }
+    return o;
+}
+// LDS + barrier; every thread of the block.  s_k / s_x: OUTL_CAP entries each.
+__device__ __forceinline__ void outl_commit(const DeqInfo& q, int row, const OutlStage& o, int* s_k, float* s_x) {
+    const int t = threadIdx.x;
+    if (t < OUTL_CAP) {
+        const int kk = min(max(o.kk, 0), q.K - 1);
+        s_k[t] = kk;
+        s_x[t] = q.oc_val ? o.xv : (float)((const f16_t*)q.x16)[(long)row * q.ldx16 + kk];
+    }
+    __syncthreads();
+}
+// outlier i of the row: from LDS, or (lists longer than OUTL_CAP) from memory
+__device__ __forceinline__ void outl_get(const DeqInfo& q, int row, const OutlStage& o, const int* s_k, const float* s_x, int i, int& k, float& xv) {
+    if (i < o.cap) { k = s_k[i]; xv = s_x[i]; }
+    else { k = q.oc_list[(long)o.g * q.oc_ld + i]; xv = (float)((const f16_t*)q.x16)[(long)row * q.ldx16 + k]; }
+}
+// byte address of W[n][k] (see deq_w); consecutive n inside a 16-row group are `deq_w_stride` bytes apart
+__device__ __forceinline__ const int8_t* deq_w_ptr(const DeqInfo& q, int n, int k) {
+    if (q.cbt) return q.cbt + ((long)(n >> 4) * (q.K >> 6) + (k >> 6)) * 1024 + ((((k & 63) >> 4) * 16) + (n & 15)) * 16 + (k & 15);
+    return q.cb + (long)n * q.K + k;
+}
+__device__ __forceinline__ long deq_w_stride(const DeqInfo& q) { return q.cbt ? 16 : q.K; }
+
+// NG groups of 8 consecutive output columns (col[g] % 8 == 0) of one row.  KU = slabs requested up front.
+template <int NG, int KU> struct Slab8 { i32x4 sl[KU][NG][2]; f32x4 sb[NG][2]; float sa; };
+template <int NG, int KU>
+__device__ __forceinline__ Slab8<NG, KU> slab8_load(const DeqInfo& q, const float* P, int ks, int mpad, int row, const int (&col)[NG], int N) {
+    Slab8<NG, KU> s;
+    const int* Pi = (const int*)P;
+#pragma unroll
+    for (int k = 0; k < KU; ++k)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int* p = Pi + ((long)(k < ks ? k : 0) * mpad + row) * N + col[g];
+            s.sl[k][g][0] = *(const i32x4*)p; s.sl[k][g][1] = *(const i32x4*)(p + 4);
+        }
+    s.sa = q.sca[row];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { s.sb[g][0] = *(const f32x4*)(q.scb + col[g]); s.sb[g][1] = *(const f32x4*)(q.scb + col[g] + 4); }
+    return s;
+}
+template <int NG, int KU>
+__device__ __forceinline__ void slab8_finish(const DeqInfo& q, const float* P, int ks, int mpad, int row, const int (&col)[NG], int N, const Slab8<NG, KU>& s,
+                                             const OutlStage& o, const int* s_k, const float* s_x, float (&v)[NG][8]) {
+    const int* Pi = (const int*)P;
+    i32x4 acc[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { acc[g][0] = (i32x4){0, 0, 0, 0}; acc[g][1] = (i32x4){0, 0, 0, 0}; }
+#pragma unroll
+    for (int k = 0; k < KU; ++k)
+        if (k < ks) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { acc[g][0] += s.sl[k][g][0]; acc[g][1] += s.sl[k][g][1]; }
+        }
+    for (int k = KU; k < ks; ++k)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int* p = Pi + ((long)k * mpad + row) * N + col[g];
+            acc[g][0] += *(const i32x4*)p; acc[g][1] += *(const i32x4*)(p + 4);
+        }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[g][j] = rT<f16_t>(fmaf((float)acc[g][j >> 2][j & 3], __fmul_rn(__fmul_rn(s.sa, s.sb[g][j >> 2][j & 3]), MM_DEQUANT_CONST), 0.0f));
+    if (o.n <= 0) return;
+    float a2[NG][8];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a2[g][j] = 0.f;
+    const long ws = deq_w_stride(q);
+    int i = 0;
+    for (; i + 1 < o.n; i += 2) {                      // two outliers' weight bytes in flight
+        int k0, k1; float x0, x1;
+        outl_get(q, row, o, s_k, s_x, i, k0, x0); outl_get(q, row, o, s_k, s_x, i + 1, k1, x1);
+        int8_t w0[NG][8], w1[NG][8];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int8_t* p0 = deq_w_ptr(q, col[g], k0); const int8_t* p1 = deq_w_ptr(q, col[g], k1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { w0[g][j] = p0[j * ws]; w1[g][j] = p1[j * ws]; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sb = s.sb[g][j >> 2][j & 3];
+                a2[g][j] = __fmaf_rn(x0, rT<f16_t>(__fmul_rn(__fmul_rn((float)w0[g][j], sb), INT8_DEQ_W)), a2[g][j]);
+                a2[g][j] = __fmaf_rn(x1, rT<f16_t>(__fmul_rn(__fmul_rn((float)w1[g][j], sb), INT8_DEQ_W)), a2[g][j]);
+            }
+    }
+    if (i < o.n) {
+        int k0; float x0;
+        outl_get(q, row, o, s_k, s_x, i, k0, x0);
+        int8_t w0[NG][8];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int8_t* p0 = deq_w_ptr(q, col[g], k0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w0[g][j] = p0[j * ws];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                a2[g][j] = __fmaf_rn(x0, rT<f16_t>(__fmul_rn(__fmul_rn((float)w0[g][j], s.sb[g][j >> 2][j & 3]), INT8_DEQ_W)), a2[g][j]);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[g][j] = rT<f16_t>(__fadd_rn(v[g][j], a2[g][j]));
+}
+
+// two single columns (col, col + dcol) of one row: the decode attention prologue
+struct Slab1x2 { int sl[8][2]; float sb[2]; float sa; };
+__device__ __forceinline__ Slab1x2 slab1x2_load(const DeqInfo& q, const float* P, int ks, int mpad, int row, int col, int dcol, int N) {
+    Slab1x2 s;
+    const int* Pi = (const int*)P;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int* p = Pi + ((long)(k < ks ? k : 0) * mpad + row) * N + col;
+        s.sl[k][0] = p[0]; s.sl[k][1] = p[dcol];
+    }
+    s.sa = q.sca[row]; s.sb[0] = q.scb[col]; s.sb[1] = q.scb[col + dcol];
+    return s;
+}
+__device__ __forceinline__ void slab1x2_finish(const DeqInfo& q, const float* P, int ks, int mpad, int row, int col, int dcol, int N, const Slab1x2& s,
+                                               const OutlStage& o, const int* s_k, const float* s_x, float& v0, float& v1) {
+    const int* Pi = (const int*)P;
+    int acc[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < ks) { acc[0] += s.sl[k][0]; acc[1] += s.sl[k][1]; }
+    for (int k = 8; k < ks; ++k) { const int* p = Pi + ((long)k * mpad + row) * N + col; acc[0] += p[0]; acc[1] += p[dcol]; }
+    float v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) v[c] = rT<f16_t>(fmaf((float)acc[c], __fmul_rn(__fmul_rn(s.sa, s.sb[c]), MM_DEQUANT_CONST), 0.0f));
+    if (o.n > 0) {
+        float a2[2] = {0.f, 0.f};
+        int i = 0;
+        for (; i + 3 < o.n; i += 4) {                  // four outliers' weight bytes in flight
+            int k[4]; float x[4]; int8_t w[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) outl_get(q, row, o, s_k, s_x, i + u, k[u], x[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { w[u][0] = *deq_w_ptr(q, col, k[u]); w[u][1] = *deq_w_ptr(q, col + dcol, k[u]); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) a2[c] = __fmaf_rn(x[u], rT<f16_t>(__fmul_rn(__fmul_rn((float)w[u][c], s.sb[c]), INT8_DEQ_W)), a2[c]);
+        }
+        for (; i < o.n; ++i) {
+            int k; float x;
+            outl_get(q, row, o, s_k, s_x, i, k, x);
+            const int8_t w0 = *deq_w_ptr(q, col, k), w1 = *deq_w_ptr(q, col + dcol, k);
+            a2[0] = __fmaf_rn(x, rT<f16_t>(__fmul_rn(__fmul_rn((float)w0, s.sb[0]), INT8_DEQ_W)), a2[0]);
+            a2[1] = __fmaf_rn(x, rT<f16_t>(__fmul_rn(__fmul_rn((float)w1, s.sb[1]), INT8_DEQ_W)), a2[1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) v[c] = rT<f16_t>(__fadd_rn(v[c], a2[c]));
+    }
+    v0 = v[0]; v1 = v[1];
+}
+
 // the rare part of an int8 GEMM epilogue (inlined: an out-of-line call made every instantiation spill around the call site):
 // v + sum over the outlier columns of the row's group of x[m][k] * fp16(CB[n][k] * SCB[n] / 127), rounded to fp16
 __device__ __forceinline__ float i8_add_outliers(const GemmI8& q, const int8_t* wr, float sb, int g, int cnt, long m, float v) {

@@ -15,6 +15,7 @@ struct DeqInfo {
     const bf16_t* x16; long ldx16;    // the GEMM's unquantised input (fp16 storage)
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
     const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div
+    const float* oc_val;              // optional (decode: one row = one group): x value of every list entry, same indexing as oc_list
 };
 // A producer that owns whole rows also emits them quantised for the next Linear8bitLt (decode step: one row = one reference call,
 // so the outlier "columns" are the row's own elements >= 6.0)
@@ -22,6 +23,7 @@ struct QuantOut {
     int8_t* q; long ldq;              // [M][K] int8; NULL = off
     float* sca;                       // [M]
     int* oc_cnt; int* oc_list; int oc_ld;
+    float* oc_val;                    // optional: the outliers' values, [M][oc_ld] beside oc_list
 };
 
 struct FlashArgs {
