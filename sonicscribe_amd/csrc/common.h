@@ -59,6 +59,7 @@ struct LaunchOpts {
     int gemm_force128 = 0;     // route every GEMM to the 128x128 kernel
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
     int no_skinny768 = 0;      // decode skinny GEMM: never the 768-deep K slices (A/B)
+    int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)
     int no_skinny_i8_wide = 0; // int8 decode skinny GEMM: always 32 rows x 1024 per block (A/B)
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
     int decode_attn_v1 = 0;    // decode attention with P.V on the VALU (round 2), for A/B runs

@@ -1832,6 +1832,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "gemm128_shallow")) { e->opts.gemm128_shallow = value; return SONIC_OK; }
     if (!strcmp(key, "no_skinny_i8_wide")) { e->opts.no_skinny_i8_wide = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
     if (!strcmp(key, "flash_variant")) { e->opts.flash_variant = value; return SONIC_OK; }

@@ -27,8 +27,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename KD, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
+// NS = stages of the operand ring.  2: one k-step in flight, two blocks per CU hide each other's load latency (large grids).  4: three k-steps in
+// flight with counted waits, one block per CU - for grids that do not fill the chip anyway (the <= 128 ragged rows a prefill GEMM cuts off its
+// 256x256 launch: 16 blocks whose k-step was one full L2 round trip, 0.54 us, with NS = 2).  Same k order per accumulator: same bits.
+// WM x WN = 16x16 MFMA tiles per wave (4 waves as 2 x 2): block tile (32 WM) x (32 WN).  4 x 4 = 128 x 128 is the general kernel; 1 x 2 =
+// 32 x 64 is for problems of a few hundred rows (the ragged tail rows, the streaming partials): such a GEMM is bound by how many CUs pull
+// operands (~65 GB/s each), and 16 tiles of 128 x 128 leave 240 CUs idle - 52 us for the 128 x 2048 x 6144 tail of a prefill down_proj.
+// Every output element still sums its k-blocks of 32 in ascending order on the same MFMA instruction: the tile shape changes no bit.
+template <typename KD, int EPI, int NS = 2, int WM = 4, int WN = 4>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) {
+    constexpr int TBM = 32 * WM, TBN = 32 * WN, TSTAGE = (TBM + TBN) * BK * 2;
+    static_assert(EPI != EPI_SWIGLU || WN % 2 == 0, "gate / up pairs of 16-column groups per wave");
     typedef typename KD::elem ET_; typedef typename KD::out OT; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
     typedef typename ET<OT>::v4 O4;
     constexpr int EB = sizeof(ET_), CE = 16 / EB, BKE = 128 / EB;   // bytes per element, elements per 16-B chunk / per 128-B tile row
@@ -37,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     const int wr = wid >> 1, wc = wid & 1;
 
     // ---- tile id: XCD-aware (blocks b, b+8, ... share an L2) + grouped raster (8 tile-rows per group)
-    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    const int tilesM = (a.M + TBM - 1) / TBM, tilesN = (a.N + TBN - 1) / TBN;
     const int nt = tilesM * tilesN;
     int id;
     {
@@ -51,73 +60,81 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         tm = first + in % gm;
         tn = in / gm;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * TBN;
     const ET_* A = (const ET_*)a.A + (long)blockIdx.z * a.strideA;
     OT* C = (OT*)a.C + (long)blockIdx.z * a.strideC;
     const OT* R = (EPI == EPI_BIAS_RESID) ? (const OT*)a.R + (long)blockIdx.z * a.strideR : nullptr;
 
     // ---- per-lane DMA source pointers (4 row groups of 8 rows per wave, per operand)
     const int lr = lane >> 3, lp = lane & 7, lc = lp ^ lr;  // LDS row-in-group, physical chunk, logical chunk
-    const ET_* srcA[4];
-    const ET_* srcW[4];
+    const ET_* srcA[WM];                                     // (WM / WN row groups of 8 rows per wave and operand)
+    const ET_* srcW[WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = wid * 4 + i;
-        int ra = m0 + g * 8 + lr; ra = ra < a.M ? ra : a.M - 1;
-        int rw = n0 + g * 8 + lr; rw = rw < a.N ? rw : a.N - 1;
+    for (int i = 0; i < WM; ++i) {
+        int ra = m0 + (wid * WM + i) * 8 + lr; ra = ra < a.M ? ra : a.M - 1;
         srcA[i] = A + (long)ra * a.lda + lc * CE;
+    }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        int rw = n0 + (wid * WN + i) * 8 + lr; rw = rw < a.N ? rw : a.N - 1;
         srcW[i] = (const ET_*)a.W + (long)rw * a.K + lc * CE;
     }
     auto stage_load = [&](int stage, int k0) {
-        char* sA = smem + stage * STAGE_BYTES;
-        char* sB = sA + BM * BK * 2;
+        char* sA = smem + stage * TSTAGE;
+        char* sB = sA + TBM * BK * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = wid * 4 + i;
-            glds16(srcA[i] + k0, sA + g * 1024);
-            glds16(srcW[i] + k0, sB + g * 1024);
-        }
+        for (int i = 0; i < WM; ++i) glds16(srcA[i] + k0, sA + (wid * WM + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) glds16(srcW[i] + k0, sB + (wid * WN + i) * 1024);
     };
 
-    Acc acc[4][4];  // [ni][mi]
+    Acc acc[WN][WM];  // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < WM; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
 
     const bool vtile = (EPI == EPI_QKV_VT) && (n0 >= a.n_split);
     const int fr = lane & 15, fg = lane >> 4;
     const int nk = a.K / BKE;
-    stage_load(0, 0);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) stage_load(p, min(p, nk - 1) * BKE);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int cur = kt % NS;
+        // stage kt has landed when at most NS - 2 later stage loads (WM + WN DMA instructions each) are still in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (WM + WN)) : "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage_load(cur ^ 1, (kt + 1) * BKE);
-        const char* sA = smem + cur * STAGE_BYTES;
-        const char* sB = sA + BM * BK * 2;
+        // the slot consumed in step kt - 1 is free for step kt + NS - 1 (past the end: the last block again, into a slot nobody reads - keeps
+        // the wait counts constant)
+        if (NS > 2 || kt + 1 < nk) stage_load((kt + NS - 1) % NS, min(kt + NS - 1, nk - 1) * BKE);
+        const char* sA = smem + cur * TSTAGE;
+        const char* sB = sA + TBM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            Frag xf[4], wf[4];
+            Frag xf[WM], wf[WN];
+            const int c = kk * 4 + fg;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rx = wr * 64 + i * 16 + fr, rw = wc * 64 + i * 16 + fr;
-                const int c = kk * 4 + fg;
+            for (int i = 0; i < WM; ++i) {
+                const int rx = wr * (WM * 16) + i * 16 + fr;
                 xf[i] = *(const Frag*)(sA + rx * 128 + ((c ^ (rx & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < WN; ++i) {
+                const int rw = wc * (WN * 16) + i * 16 + fr;
                 wf[i] = *(const Frag*)(sB + rw * 128 + ((c ^ (rw & 7)) << 4));
             }
             if (vtile) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < WN; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = KD::mfma(xf[mi], wf[ni], acc[ni][mi]);
+                    for (int mi = 0; mi < WM; ++mi) acc[ni][mi] = KD::mfma(xf[mi], wf[ni], acc[ni][mi]);
             } else {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < WN; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = KD::mfma(wf[ni], xf[mi], acc[ni][mi]);
+                    for (int mi = 0; mi < WM; ++mi) acc[ni][mi] = KD::mfma(wf[ni], xf[mi], acc[ni][mi]);
             }
         }
     }
@@ -126,12 +143,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     if (vtile) {
         // acc[ni][mi][j] = D[m = mrow + j][n = ncol]; V^T[seg][n - n_split][t .. t+3]
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wc * 64 + ni * 16 + fr;
+        for (int ni = 0; ni < WN; ++ni) {
+            const int n = n0 + wc * (WN * 16) + ni * 16 + fr;
             const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m = m0 + wr * 64 + mi * 16 + fg * 4;
+            for (int mi = 0; mi < WM; ++mi) {
+                const int m = m0 + wr * (WM * 16) + mi * 16 + fg * 4;
                 if (m < a.M && n < a.N) {
                     const int seg = m / a.seg_T, t = m - seg * a.seg_T;
                     O4 o;
@@ -145,15 +162,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     }
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int oc = ((n0 + wc * 64) >> 1) + q * 16 + fg * 4;
-            const int ng = n0 + wc * 64 + q * 32 + fg * 4;           // gate columns ng .. ng+3, up columns ng+16 ..
+        for (int q = 0; q < WN / 2; ++q) {
+            const int oc = ((n0 + wc * (WN * 16)) >> 1) + q * 16 + fg * 4;
+            const int ng = n0 + wc * (WN * 16) + q * 32 + fg * 4;    // gate columns ng .. ng+3, up columns ng+16 ..
             f32x4 sbg = {0.f, 0.f, 0.f, 0.f}, sbu = {0.f, 0.f, 0.f, 0.f};
             if constexpr (KD::I8) if (ng + 19 < a.N) { sbg = *(const f32x4*)(a.q.scb + ng); sbu = *(const f32x4*)(a.q.scb + ng + 16); }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m = m0 + wr * 64 + mi * 16 + fr;
-                if (m < a.M && (n0 + wc * 64 + q * 32) < a.N) {
+            for (int mi = 0; mi < WM; ++mi) {
+                const int m = m0 + wr * (WM * 16) + mi * 16 + fr;
+                if (m < a.M && (n0 + wc * (WN * 16) + q * 32) < a.N) {
                     const I8Row rw = i8_row<KD>(a, m);
                     O4 o;
 #pragma unroll
@@ -168,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         return;
     }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + fg * 4;
+    for (int ni = 0; ni < WN; ++ni) {
+        const int n = n0 + wc * (WN * 16) + ni * 16 + fg * 4;
         if (n >= a.N) continue;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) {
@@ -179,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         f32x4 sb = {0.f, 0.f, 0.f, 0.f};
         if constexpr (KD::I8) sb = *(const f32x4*)(a.q.scb + n);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wr * 64 + mi * 16 + fr;
+        for (int mi = 0; mi < WM; ++mi) {
+            const int m = m0 + wr * (WM * 16) + mi * 16 + fr;
             if (m >= a.M) continue;
             const I8Row rw = i8_row<KD>(a, m);
             O4 o;
@@ -266,17 +283,34 @@ void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     }
     launch_gemm128(a, epi, s);
 }
+template <typename KD, int EPI, int NS, int WM, int WN> static void launch_gemm128_v(const GemmArgs& a, hipStream_t s) {
+    constexpr int TBM = 32 * WM, TBN = 32 * WN;
+    const size_t lds = (size_t)NS * (TBM + TBN) * BK * 2;
+    if (lds > 65536) ensure_dyn_lds((const void*)gemm_kernel<KD, EPI, NS, WM, WN>, (int)lds);
+    const int tilesM = (a.M + TBM - 1) / TBM, tilesN = (a.N + TBN - 1) / TBN;
+    hipLaunchKernelGGL((gemm_kernel<KD, EPI, NS, WM, WN>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(256), lds, s, a);
+}
+// shape of the launch: 0 = 128 x 128 tiles, two-stage ring, two blocks per CU; 1 = 32 x 64 tiles, four-stage ring (grids of 128 x 128 tiles
+// that would leave half of the CUs idle); 2 = 32 x 32 tiles (when even the 32 x 64 grid covers at most half of the CUs; not for the SwiGLU
+// epilogue, whose gate / up pairs need 32 columns per wave)
+template <typename KD, int EPI> static void launch_gemm128_e(const GemmArgs& a, int shape, hipStream_t s) {
+    if constexpr (EPI == EPI_QKV_VT) launch_gemm128_v<KD, EPI, 2, 4, 4>(a, s);
+    else if (shape == 2 && EPI != EPI_SWIGLU) launch_gemm128_v<KD, EPI, 4, 1, EPI == EPI_SWIGLU ? 2 : 1>(a, s);
+    else if (shape >= 1) launch_gemm128_v<KD, EPI, 4, 1, 2>(a, s);
+    else launch_gemm128_v<KD, EPI, 2, 4, 4>(a, s);
+}
 static void launch_gemm128(const GemmArgs& a, int epi, hipStream_t s) {
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
-    dim3 grid(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), block(256);
-    const size_t lds = 2 * STAGE_BYTES;
+    const int batch = a.batch > 0 ? a.batch : 1;
+    int shape = (!g_opts.gemm128_shallow && (long)tilesM * tilesN * batch <= device_cus() / 2 && a.K / (128 / (a.q.sca ? 1 : 2)) >= 4) ? 1 : 0;
+    if (shape == 1 && (long)((a.M + 31) / 32) * ((a.N + 63) / 64) * batch <= device_cus() / 2) shape = 2;
     KD_SWITCH(a, KD, {
         switch (epi) {
-            case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<KD, EPI_BIAS>), grid, block, lds, s, a); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<KD, EPI_BIAS_GELU>), grid, block, lds, s, a); break;
-            case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_kernel<KD, EPI_BIAS_RESID>), grid, block, lds, s, a); break;
-            case EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<KD, EPI_SWIGLU>), grid, block, lds, s, a); break;
-            case EPI_QKV_VT: if constexpr (!KD::I8) hipLaunchKernelGGL((gemm_kernel<KD, EPI_QKV_VT>), grid, block, lds, s, a); break;
+            case EPI_BIAS: launch_gemm128_e<KD, EPI_BIAS>(a, shape, s); break;
+            case EPI_BIAS_GELU: launch_gemm128_e<KD, EPI_BIAS_GELU>(a, shape, s); break;
+            case EPI_BIAS_RESID: launch_gemm128_e<KD, EPI_BIAS_RESID>(a, shape, s); break;
+            case EPI_SWIGLU: launch_gemm128_e<KD, EPI_SWIGLU>(a, shape, s); break;
+            case EPI_QKV_VT: if constexpr (!KD::I8) launch_gemm128_e<KD, EPI_QKV_VT>(a, shape, s); break;
         }
     });
 }
