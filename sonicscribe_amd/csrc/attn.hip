@@ -669,6 +669,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     }
     __syncthreads();
     KT(a, 3);
+    float amx = 0.f;                         // int8 mode: absmax of this thread's outputs without the elements >= 6.0
     for (int idx = tid; idx < G * HD; idx += 512) {
         const int h = idx / HD, e = idx % HD;
         float M = -1e30f;
@@ -677,7 +678,24 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { const float f = __expf(s_m[w][h] - M); num += f * s_acc[w][h][e]; den += f * s_l[w][h]; }
-        ((T*)a.O)[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = (T)(num / den);
+        const T ov = (T)(num / den);
+        ((T*)a.O)[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = ov;
+        const float av = fabsf((float)ov);
+        amx = fmaxf(amx, av < LLM_INT8_THRESHOLD ? av : 0.f);
+    }
+    if (a.amax_out) {
+        // this block's share of the row absmax for o_proj's on-the-fly quantisation (SkinnyArgs.x_amax): one plain store per block into the
+        // row's 4 partials (an atomicMax per wave onto one word per row cost 8 us per launch: 13.1 -> 21.4)
+        amx = wave_max(amx);
+        __syncthreads();                     // s_l is free: every thread has left the merge loop
+        if (lane == 0) s_l[wid][0] = amx;
+        __syncthreads();
+        if (tid == 0) {
+            float m = s_l[0][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, s_l[w][0]);
+            a.amax_out[b * 4 + kvh] = m;
+        }
     }
     KT(a, 4);
 }

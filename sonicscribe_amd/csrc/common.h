@@ -189,6 +189,9 @@ struct SkinnyArgs {
     int M, N, K, ksplit;
     int dt;                          // DT_BF16 / DT_F16
     int i8;                          // int8 operands (Linear8bitLt decode step): int32 slabs, dequantised by the consumer
+    const float* x_amax;             // i8 only, optional: X holds the UNQUANTISED fp16 rows and x_amax[row][0..3] partial maxima (written by the
+                                     // producer's blocks) of their absmax without the elements >= 6.0: the kernel quantises its X slice while
+                                     // staging it - int8 = rn(x * 127 / absmax), 0 for outliers (LLM.int8 row-wise)
     long long* kt;                   // diagnostics: per-block timestamps [block][8] (100 MHz wall clock), null in production
 };
 // in-kernel timeline point `slot` of this block (thread 0 only); a null pointer costs one scalar compare

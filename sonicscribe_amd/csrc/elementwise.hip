@@ -150,12 +150,20 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
     const V8 t = *(const V8*)xr;                      // (requested before the slabs: one round trip for both)
     if (dq.sca) {
         // int8: the row's outlier pairs and this thread's slabs are requested together, the pairs go through LDS (int8_util.h)
-        const OutlStage os = outl_issue(dq, row);
         const int col[1] = {c < nv ? c * 8 : 0};
-        const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
-        outl_commit(dq, row, os, s_ok, s_ox);
         float a[1][8];
-        slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
+        if (dq.scan) {
+            // the projection quantised its input on the fly: this block lists the input row's outliers itself (K <= 4 * 8 * blockDim.x)
+            const OutlScan<4> sc = outl_scan_issue<4>(dq, row);
+            const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
+            const OutlStage os = outl_scan_commit<4>(dq, row, sc, s_ok, s_ox, parti);
+            slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
+        } else {
+            const OutlStage os = outl_issue(dq, row);
+            const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
+            outl_commit(dq, row, os, s_ok, s_ox);
+            slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = a[0][j];
     }

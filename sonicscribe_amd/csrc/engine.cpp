@@ -59,11 +59,12 @@ struct sonic_engine {
     // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
     int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
     int q_kmax = 0; bf16_t* qkv_rm = nullptr;
-    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8;   // rows deferred to the outlier side product leave the GEMM here
+    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0;   // rows deferred to the outlier side product leave the GEMM here
     // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
     float *ov_hn = nullptr, *ov_att = nullptr, *ov_act = nullptr;      // the outliers' values beside the lists
+    float *amax_att = nullptr, *amax_act = nullptr;                     // [64][4] partial row maxima written by producers that do not own whole rows
     std::map<std::string, bool> raw_f16;   // int8 mode: tensors already converted to fp16 at load
     bf16_t* embed = nullptr; bf16_t* embed_t = nullptr;
     std::vector<DecLayerW> dec;
@@ -494,6 +495,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
         A(dalloc(e, &e->oc_hn, 64)); A(dalloc(e, &e->oc_att, 64)); A(dalloc(e, &e->oc_act, 64));
         A(dalloc(e, &e->ol_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ol_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ol_act, (size_t)64 * d.dec_ff));
         A(dalloc(e, &e->ov_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ov_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ov_act, (size_t)64 * d.dec_ff));
+        A(dalloc(e, &e->amax_att, 64 * 4)); A(dalloc(e, &e->amax_act, 64 * 4));
     }
     A(dalloc(e, &e->src, tc)); A(dalloc(e, &e->tok_seq, tc)); A(dalloc(e, &e->tok_pos_pf, tc));
     A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
@@ -930,6 +932,13 @@ static void skinny(sonic_engine* e, const bf16_t* X, long ldx, const bf16_t* W, 
     launch_skinny(a, e->st);
 }
 // int8 decode step: quantised rows Xq [M][K] x fragment-tiled int8 weights -> int32 slabs (dequantised by the consumer)
+// the same projection on UNQUANTISED fp16 rows with their gathered absmax: the kernel quantises its X slice while staging it
+static int skinny_i8_xq(sonic_engine* e, const bf16_t* X16, const float* amax, const int8_t* Wt, float* P, int M, int N, int K) {
+    SkinnyArgs a{};
+    a.X = X16; a.ldx = K; a.W = (const bf16_t*)Wt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit_i8(N, K); a.i8 = 1; a.x_amax = amax;
+    launch_skinny(a, e->st);
+    return a.ksplit;
+}
 static int skinny_i8(sonic_engine* e, const int8_t* Xq, const int8_t* Wt, float* P, int M, int N, int K) {
     SkinnyArgs a{};
     a.X = (const bf16_t*)Xq; a.ldx = K; a.W = (const bf16_t*)Wt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = skinny_pick_ksplit_i8(N, K); a.i8 = 1;
@@ -1020,10 +1029,20 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
         da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = DT_F16; da.dq = deq(q_hn, L.qqkv, D, e->shn);
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
+        // o_proj's input rows are spread over the attention blocks of 4 kv heads: they gather the row absmax (atomicMax), o_proj quantises on the
+        // fly and its consumer lists the outliers itself - no one-block-per-row quantisation launch in between (option i8_no_xq: the round-2 form)
+        const bool xq = !e->opt_i8_no_xq;
+        if (xq) da.amax_out = e->amax_att;
         launch_decode_attn(da, R, e->st);
-        launch_quant_rows(e->satt, e->QD, R, e->QD, q_att, e->st);
-        ks = skinny_i8(e, e->att_q, L.qo.cbt, e->slab, R, D, e->QD);
-        DeqInfo dq = deq(q_att, L.qo, e->QD, e->satt);
+        DeqInfo dq;
+        if (xq) {
+            ks = skinny_i8_xq(e, e->satt, e->amax_att, L.qo.cbt, e->slab, R, D, e->QD);
+            dq = deq(q_att, L.qo, e->QD, e->satt); dq.sca = e->amax_att; dq.scan = 1;
+        } else {
+            launch_quant_rows(e->satt, e->QD, R, e->QD, q_att, e->st);
+            ks = skinny_i8(e, e->att_q, L.qo.cbt, e->slab, R, D, e->QD);
+            dq = deq(q_att, L.qo, e->QD, e->satt);
+        }
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st, DT_F16, &dq, &q_hn);
         ks = skinny_i8(e, e->hn_q, L.qgu.cbt, e->slab, R, 2 * FF, D);
         launch_swiglu_quant(e->slab, ks, mpad, FF, e->sact, R, deq(q_hn, L.qgu, D, e->shn), q_act, e->st);
@@ -1100,6 +1119,7 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     HIPC(e, hipMemcpyAsync(e->last_row, hp.last_row.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(e->max_new_d, hp.max_new.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
     launch_fill_i32(e->n_new, 0, 64, e->st);
+    if (e->amax_att) { launch_fill_i32((int*)e->amax_att, 0, 64 * 4, e->st); launch_fill_i32((int*)e->amax_act, 0, 64 * 4, e->st); }   // (partials nobody writes stay 0)
     launch_fill_i32(e->finished, 0, 64, e->st);
     launch_fill_i32(e->step_ctr, 0, 64, e->st);
     HIPC(e, hipMemcpyAsync(e->n_active, &R, 4, hipMemcpyHostToDevice, e->st));
@@ -1832,6 +1852,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "i8_no_xq")) { e->opt_i8_no_xq = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm128_shallow")) { e->opts.gemm128_shallow = value; return SONIC_OK; }
     if (!strcmp(key, "no_skinny_i8_wide")) { e->opts.no_skinny_i8_wide = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }

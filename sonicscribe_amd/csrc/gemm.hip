@@ -389,7 +389,10 @@ __global__ __launch_bounds__(512) void skinny_readfloor_kernel(SkinnyArgs a) {
 // block that lands on the CU), so at 48-64 activation rows - where the image of a 1024-deep slice is 64 KiB of int8 - a block should own as
 // many weight rows as keeps the grid at one block per CU: gate/up of the full-size model as 96 rows x 1024 (128 x 2 = 256 blocks, 96 KiB
 // of W per 64 KiB image) instead of 32 rows x 1024 (768 blocks, three images per CU).
-template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1>
+// XQ (int8 kind): the activation rows arrive unquantised (fp16) with their absmax; the block quantises its slice on the way into LDS.  This
+// removes the separate one-block-per-row quantisation launch between a producer that does not own whole rows (decode attention: one block
+// per (row, kv head); the fused gate/up kernel: 24 columns per block) and the projection that consumes it.
+template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = false>
 __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     typedef typename KD::elem ET_; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
     // element size; elements per 16-B chunk, per MFMA k-step, per 128-B LDS row, per 1-KiB weight tile
@@ -405,7 +408,22 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     const int kb = blockIdx.y * BKk;
     KT(a, 0);
     // X slice first (small, out of L2): it has to be complete in LDS - for all waves - before the first MFMA
-    {
+    // XQ: fp16 rows -> registers (asm loads: the compiler must not see them, or its own wait counts would include the weight loads below),
+    // G8 = groups of 8 elements per row of the slice; group idx = p * 512 + tid of the MB * 16 * G8 groups: row idx / G8, group idx % G8
+    constexpr int G8 = BKk / 8, XTOT = MB * 16 * G8, XP = XQ ? (XTOT + 511) / 512 : 1;
+    static_assert(!XQ || KD::I8, "XQ: int8 kind");
+    f16x8 xq[XP]; f32x4 xam[XP];
+    if constexpr (XQ) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const int idx = min(p * 512 + tid, XTOT - 1);
+            int row = idx / G8; row = row < a.M ? row : a.M - 1;
+            const f16_t* src = (const f16_t*)a.X + (long)row * a.ldx + kb + (idx % G8) * 8;
+            const float* am = a.x_amax + row * 4;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xq[p]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xam[p]) : "v"(am) : "memory");
+        }
+    } else {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
 #pragma unroll
         for (int t = 0; t < PW; ++t) {
@@ -441,7 +459,29 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][mb][e] = 0;
     KT(a, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");       // this wave's X pieces are in LDS
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");       // this wave's X pieces are in LDS (XQ: in registers)
+    if constexpr (XQ) {
+        // quantise (elementwise.hip quant_emit_row's arithmetic) and park in the image: byte (row m, element k) of a 128-element k-block at
+        // kblock * KBS + m * 128 + ((chunk ^ (m & 7)) << 4) + k % 16
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            asm volatile("" : "+v"(xq[p]), "+v"(xam[p]));
+            const int idx = p * 512 + tid;
+            if (XTOT % 512 != 0 && idx >= XTOT) continue;
+            const int m = idx / G8, g8 = idx % G8, kblock = g8 >> 4, c = (g8 & 15) >> 1, half = g8 & 1;
+            const float bm = fmaxf(fmaxf(xam[p][0], xam[p][1]), fmaxf(xam[p][2], xam[p][3])), scale = 127.0f / bm;
+            int pk[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = (float)xq[p][j];
+                const bool out = !(fabsf(y) < LLM_INT8_THRESHOLD);
+                const int qv = (out || !(bm > 0.f)) ? 0 : (int)rintf(y * scale);
+                pk[j >> 2] |= (qv & 0xFF) << ((j & 3) * 8);
+            }
+            *(int2*)(smem + kblock * KBS + m * 128 + ((c ^ (m & 7)) << 4) + half * 8) = make_int2(pk[0], pk[1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                                    // (raw barrier: __syncthreads would add a vmcnt(0) fence)
     KT(a, 2);
 #pragma unroll
@@ -845,12 +885,12 @@ template <typename KD, int MB> static void launch_skinny_mb(const SkinnyArgs& a,
         default: launch_skinny_v<KD, MB, 1>(a, s); break;
     }
 }
-template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
+template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = false> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
     constexpr int EB = sizeof(typename KD::elem), KS = 64 / EB, ROWE = 128 / EB;
     constexpr int NI = (WK * KSW * KS / ROWE) * MB * 2;
     const size_t img = (size_t)NI * 1024, red = (size_t)8 * NT * MB * 1024, lds = img > red ? img : red;
-    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW, NT>, (int)lds);
-    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW, NT>), dim3(a.N / (WN * NT * 16), nkslices), dim3(512), lds, s, a);
+    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW, NT, XQ>, (int)lds);
+    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW, NT, XQ>), dim3(a.N / (WN * NT * 16), nkslices), dim3(512), lds, s, a);
 }
 template <typename KD, int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
     if (cfg == 1) launch_xs_v<KD, MB, 4, 2, 16>(a, a.K / 1024, s);
@@ -885,6 +925,15 @@ int skinny_pick_ksplit_i8(int N, int K) {
     }
 }
 template <int MB> static void launch_skinny_i8(const SkinnyArgs& a, hipStream_t s) {
+    if (a.x_amax) {                  // fp16 rows quantised while staged (the configurations the decode step uses for o_proj / down_proj)
+        switch (skinny_i8_cfg(a.N, a.K)) {
+            case 2: launch_xs_v<KI8, MB, 2, 4, 3, 2, true>(a, a.K / 768, s); break;
+            case 3: launch_xs_v<KI8, MB, 2, 4, 2, 1, true>(a, a.K / 512, s); break;
+            case 0: case 1: launch_xs_v<KI8, MB, 2, 4, 4, 1, true>(a, a.K / 1024, s); break;
+            default: launch_xs_v<KI8, MB, 2, 4, 1, 1, true>(a, a.K / 256, s); break;
+        }
+        return;
+    }
     switch (skinny_i8_cfg(a.N, a.K)) {
         case 1: launch_xs_v<KI8, MB, 2, 4, 4, 3>(a, a.K / 1024, s); break;
         case 2: launch_xs_v<KI8, MB, 2, 4, 3, 2>(a, a.K / 768, s); break;

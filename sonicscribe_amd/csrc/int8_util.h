@@ -108,10 +108,72 @@ __device__ __forceinline__ void outl_commit(const DeqInfo& q, int row, const Out
     }
     __syncthreads();
 }
+// The same stage when nobody has listed the row's outliers (DeqInfo.scan): the block reads the row of x16 itself - thread t owns the 8-element
+// groups [t * GPT, (t + 1) * GPT), so list positions ascend with k exactly as quant_emit_row writes them - and fills the LDS stage; entries
+// beyond it spill into the row's oc_list / oc_val space (read back by this block only).  s_i: >= 17 ints of scratch.
+template <int GPT> struct OutlScan { f16x8 x[GPT]; };
+template <int GPT>
+__device__ __forceinline__ OutlScan<GPT> outl_scan_issue(const DeqInfo& q, int row) {
+    OutlScan<GPT> r;
+    const int ng = q.K >> 3;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const int g8 = min((int)threadIdx.x * GPT + i, ng - 1);
+        r.x[i] = *(const f16x8*)((const f16_t*)q.x16 + (long)row * q.ldx16 + g8 * 8);
+    }
+    return r;
+}
+template <int GPT>
+__device__ __forceinline__ OutlStage outl_scan_commit(const DeqInfo& q, int row, const OutlScan<GPT>& r, int* s_k, float* s_x, int* s_i) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6, ng = q.K >> 3;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i)
+        if (tid * GPT + i < ng) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt += !(fabsf((float)r.x[i][j]) < LLM_INT8_THRESHOLD);
+        }
+    int incl = cnt;
+    if (__ballot(cnt > 0)) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    }
+    if (lane == 63) s_i[wid] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { if (w < wid) base += s_i[w]; total += s_i[w]; }
+    OutlStage o;
+    o.g = row; o.n = total; o.cap = OUTL_CAP; o.kk = 0; o.xv = 0.f;
+    if (total > 0) {                                   // block-uniform
+        int pos = base + incl - cnt;
+        if (cnt > 0) {
+#pragma unroll
+            for (int i = 0; i < GPT; ++i)
+                if (tid * GPT + i < ng) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = (float)r.x[i][j];
+                        if (!(fabsf(y) < LLM_INT8_THRESHOLD)) {
+                            const int k = (tid * GPT + i) * 8 + j;
+                            if (pos < OUTL_CAP) { s_k[pos] = k; s_x[pos] = y; }
+                            else { ((int*)q.oc_list)[(long)row * q.oc_ld + pos] = k; ((float*)q.oc_val)[(long)row * q.oc_ld + pos] = y; }
+                            ++pos;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    return o;
+}
+
 // outlier i of the row: from LDS, or (lists longer than OUTL_CAP) from memory
 __device__ __forceinline__ void outl_get(const DeqInfo& q, int row, const OutlStage& o, const int* s_k, const float* s_x, int i, int& k, float& xv) {
     if (i < o.cap) { k = s_k[i]; xv = s_x[i]; }
-    else { k = q.oc_list[(long)o.g * q.oc_ld + i]; xv = (float)((const f16_t*)q.x16)[(long)row * q.ldx16 + k]; }
+    else {
+        k = q.oc_list[(long)o.g * q.oc_ld + i];
+        xv = q.scan ? q.oc_val[(long)o.g * q.oc_ld + i] : (float)((const f16_t*)q.x16)[(long)row * q.ldx16 + k];
+    }
 }
 // byte address of W[n][k] (see deq_w); consecutive n inside a 16-row group are `deq_w_stride` bytes apart
 __device__ __forceinline__ const int8_t* deq_w_ptr(const DeqInfo& q, int n, int k) {
@@ -133,7 +195,8 @@ __device__ __forceinline__ Slab8<NG, KU> slab8_load(const DeqInfo& q, const floa
             const int* p = Pi + ((long)(k < ks ? k : 0) * mpad + row) * N + col[g];
             s.sl[k][g][0] = *(const i32x4*)p; s.sl[k][g][1] = *(const i32x4*)(p + 4);
         }
-    s.sa = q.sca[row];
+    if (q.scan) { const f32x4 pm = *(const f32x4*)(q.sca + row * 4); s.sa = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])); }
+    else s.sa = q.sca[row];
 #pragma unroll
     for (int g = 0; g < NG; ++g) { s.sb[g][0] = *(const f32x4*)(q.scb + col[g]); s.sb[g][1] = *(const f32x4*)(q.scb + col[g] + 4); }
     return s;

@@ -16,6 +16,10 @@ struct DeqInfo {
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
     const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div
     const float* oc_val;              // optional (decode: one row = one group): x value of every list entry, same indexing as oc_list
+    int scan;                         // decode consumers that own a row: 1 = nobody listed the row's outliers (its producer did not own whole rows and
+                                      // the projection quantised it on the fly, SkinnyArgs.x_amax): the consumer finds them in x16 itself, ascending;
+                                      // sca then holds 4 partial maxima per row ([M][4], the row absmax is their maximum).
+                                      // oc_list / oc_val are this row's spill space for lists longer than the LDS stage
 };
 // A producer that owns whole rows also emits them quantised for the next Linear8bitLt (decode step: one row = one reference call,
 // so the outlier "columns" are the row's own elements >= 6.0)
@@ -52,6 +56,8 @@ struct DecodeAttnArgs {
     float scale;
     int dt;
     DeqInfo dq;           // int8 mode: P holds int32 slabs of the quantised QKV projection
+    float* amax_out;      // int8 mode, optional: [B][4] per-block partials (kv head) of the output rows' absmax without the elements >= 6.0; Hkv <= 4,
+                          // unused partials stay 0
     long long* kt;        // diagnostics: per-block timestamps (common.h KT)
 };
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s);

@@ -245,6 +245,39 @@ def test_int8_fullwidth_layer_vs_oracle(orc):
     e.close()
 
 
+@pytest.mark.parametrize("dims_name", ["tiny", "fullwidth"])
+def test_int8_quantise_on_the_fly_equals_separate_pass(dims_name):
+    """Decode step, int8 mode: o_proj's input is quantised by the projection kernel itself while it stages its X slice (row absmax gathered
+    by the attention blocks with atomicMax, outliers listed by the consumer) instead of by a one-block-per-row launch in between
+    (`i8_no_xq=1`, the round-2 form).  Same quantisation arithmetic, exact int32 sums, same outlier order: the step logits must be
+    bit-identical, at the tiny tilings (K slices of 256) and at the full-size ones (K slices of 512, 5 rows so that the padded rows of the
+    64-row image are exercised)."""
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    if dims_name == "tiny":
+        d, n_samples, B = spec.TINY, 80000, 5
+    else:
+        d, n_samples, B = replace(spec.FULL, enc_layers=1, dec_layers=2, vocab=1024, audio_token_id=1000, eos_ids=()), 160000, 5
+    e = Engine(d, 0, MODE_INT8, max_batch=8, max_ctx=320)
+    e.load_synthetic(11)
+    segs = [synth.synth_pcm(300 + i, n_samples) for i in range(B)]
+    prompt = _prompt(n_samples, d)
+    n_new = 6
+    force = np.random.default_rng(3).integers(2, min(900, d.vocab - 1), (B, n_new)).astype(np.int32)
+    e.set_forced_ids(force)
+    try:
+        ids_a, lg_a = e.transcribe_batch(segs, [prompt] * B, [n_new] * B, want_logits=True)
+        e.set_option("i8_no_xq", 1)
+        ids_b, lg_b = e.transcribe_batch(segs, [prompt] * B, [n_new] * B, want_logits=True)
+        e.set_option("i8_no_xq", 0)
+        ids_c, lg_c = e.transcribe_batch(segs, [prompt] * B, [n_new] * B, want_logits=True)    # and the gathered absmax is clean again
+    finally:
+        e.set_forced_ids(None)
+        e.close()
+    assert np.isfinite(lg_a).all()
+    assert np.array_equal(lg_a, lg_b), float(np.abs(lg_a - lg_b).max())
+    assert np.array_equal(lg_a, lg_c)
+
+
 def test_int8_bench_config_full_depth_vs_oracle(orc):
     """BASELINE config 4 at its real size: 32 + 28 layers, vocabulary 59264, INT8 mode, 64 x 20 s segments in one batch (what
     `bench.py --mode int8 --batch 64` times).  Two steps under teacher forcing:
