@@ -278,6 +278,46 @@ def test_int8_quantise_on_the_fly_equals_separate_pass(dims_name):
     assert np.array_equal(lg_a, lg_c)
 
 
+def test_int8_on_the_fly_quantisation_with_outliers_vs_oracle(orc):
+    """The same path when o_proj's input rows DO hold outliers (the synthetic weights give none: attention outputs stay below 3.6): the
+    decoder's v_proj weights are scaled so that attention outputs pass 6.0; the consumer's own scan of the row must list them in the order
+    the separate pass does (bit-identical logits) and the result must stay on the int8 oracle."""
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    d = spec.TINY
+    st = synth.synth_state_dict(d, 23, 2)
+    dec_v = [k for k in st if k.endswith("self_attn.v_proj.weight") and st[k].shape == (d.dec_kv_heads * d.dec_head_dim, d.dec_d)]
+    assert dec_v
+    for k in dec_v:
+        st[k] = f16(st[k] * 24.0)
+    e = Engine(d, 0, MODE_INT8, max_batch=4, max_ctx=320)
+    e.load_state_dict(st)
+    om = orc.Model(d, st, mode=orc.MODE_INT8)
+    segs = [synth.synth_pcm(70 + i, 80000) for i in range(3)]
+    prompt = _prompt(80000, d)
+    n_new = 5
+    force = np.random.default_rng(4).integers(2, 900, (3, n_new)).astype(np.int32)
+    e.set_forced_ids(force)
+    try:
+        _, lg_a = e.transcribe_batch(segs, [prompt] * 3, [n_new] * 3, want_logits=True)
+        att = e.debug_read("satt", (3, d.dec_heads * d.dec_head_dim))
+        e.set_option("i8_no_xq", 1)
+        _, lg_b = e.transcribe_batch(segs, [prompt] * 3, [n_new] * 3, want_logits=True)
+    finally:
+        e.set_forced_ids(None)
+        e.close()
+    n_out = int((np.abs(att) >= 6.0).sum())
+    print(f"attention output rows of the last step hold {n_out} elements >= 6.0 (absmax {np.abs(att).max():.1f})")
+    assert n_out > 0, "the test no longer produces outliers in o_proj's input"
+    assert np.array_equal(lg_a, lg_b), float(np.abs(lg_a - lg_b).max())
+    worst = 0.0
+    for i in range(3):
+        feats, mask = orc.logmel(segs[i])
+        r = om.transcribe(feats, int(mask.sum()), prompt, n_new, force_ids=force[i])
+        worst = max(worst, float(np.abs(lg_a[:, i] - r["step_logits"]).max()))
+    print(f"int8 tiny with attention outliers: max|dlogit| vs oracle {worst:.4f}")
+    assert worst <= 0.2
+
+
 def test_int8_bench_config_full_depth_vs_oracle(orc):
     """BASELINE config 4 at its real size: 32 + 28 layers, vocabulary 59264, INT8 mode, 64 x 20 s segments in one batch (what
     `bench.py --mode int8 --batch 64` times).  Two steps under teacher forcing:
