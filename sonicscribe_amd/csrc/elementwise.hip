@@ -57,8 +57,10 @@ __device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active,
 
 // ---------------------------------------------------------------- LayerNorm (modeling_glmasr.py:246-247,305)
 // one wave per row, d % 8 == 0, d <= 2048; two-pass in registers (mean, then centred variance).
+// qa.q != null (int8 mode, the row feeds a Linear8bitLt): the wave that normalised the row also emits what the first two passes of
+// launch_quant_act would compute from it - row absmax without the elements >= 6.0, int8 codes (those elements as 0), and their group flags.
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float* w, const float* b, T* y, int rows, int d, float eps) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float* w, const float* b, T* y, int rows, int d, float eps, QuantActArgs qa) {
     typedef typename ET<T>::v8 V8;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -84,14 +86,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
             for (int j = 0; j < 8; ++j) { const float c = v[i][j] - mean; q += c * c; }
         }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / d + eps);
+    float amax = -1.17549435e-38f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             V8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (T)(((v[i][j] - mean) * rstd) * w[c * 8 + j] + b[c * 8 + j]);
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (T)(((v[i][j] - mean) * rstd) * w[c * 8 + j] + b[c * 8 + j]);
+                v[i][j] = (float)o[j];
+                const float av = fabsf(v[i][j]);
+                if (av < LLM_INT8_THRESHOLD) amax = fmaxf(amax, av);
+            }
             *(V8*)(y + (long)row * d + c * 8) = o;
+        }
+    }
+    if (!qa.q) return;
+    amax = wave_max(amax);
+    if (lane == 0) qa.sca[row] = amax;
+    const int g = qa.gmap ? qa.gmap[row / qa.gdiv] : row / qa.gdiv;
+    unsigned char* fl = qa.flags + (long)g * qa.K;
+    const float scale = 127.0f / amax;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            int pk[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool out = !(fabsf(v[i][j]) < LLM_INT8_THRESHOLD);
+                if (out) fl[c * 8 + j] = 1;                       // (benign race: every writer stores the same value)
+                const int qv = (out || !(amax > 0.f)) ? 0 : (int)rintf(v[i][j] * scale);
+                pk[j >> 2] |= (qv & 0xFF) << ((j & 3) * 8);
+            }
+            *(int2*)(qa.q + (long)row * qa.K + c * 8) = make_int2(pk[0], pk[1]);
         }
     }
 }
@@ -521,8 +550,9 @@ __global__ void synth_fill_kernel(unsigned long long key, long n, float scale, f
 }
 
 // ---------------------------------------------------------------- launchers
-void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt) {
-    DT_SWITCH(dt, T, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps));
+void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt, const QuantActArgs* qa) {
+    const QuantActArgs q = qa ? *qa : QuantActArgs{};
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps, q));
 }
 void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt) {
     DT_SWITCH(dt, T, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map));

@@ -59,7 +59,7 @@ struct sonic_engine {
     // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
     int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
     int q_kmax = 0; bf16_t* qkv_rm = nullptr;
-    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0;   // rows deferred to the outlier side product leave the GEMM here
+    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0; int opt_i8_no_lnq = 0;   // rows deferred to the outlier side product leave the GEMM here
     // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
@@ -793,13 +793,30 @@ struct QGroup { const int* gmap; int gdiv; int G; };
 // Linear8bitLt = activation quantisation (3 streaming passes) + int8 MFMA GEMM whose epilogue dequantises and adds the outlier columns.
 // rope_cs (optional): fuse the encoder's partial RoPE on columns < rope_ncols into the epilogue; returns whether it was fused (only the
 // 256x256 kernel does it), else the caller runs the separate RoPE pass.
-static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
-                    int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp, const float* rope_cs = nullptr, int rope_T = 0, int rope_ncols = 0) {
-    if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return false; }
+static QuantActArgs make_qa(sonic_engine* e, const bf16_t* X, long ldx, int M, int K, const QGroup& grp) {
     QuantActArgs qa{};
     qa.X = X; qa.ld = ldx; qa.M = M; qa.K = K; qa.gmap = grp.gmap; qa.gdiv = grp.gdiv; qa.G = grp.G; qa.flags = e->q_flags;
     qa.q = e->qa; qa.sca = e->q_sca; qa.oc_cnt = e->q_oc_cnt; qa.oc_list = e->q_oc_list; qa.oc_ld = e->q_kmax;
-    launch_quant_act(qa, e->st);
+    return qa;
+}
+// LayerNorm whose output feeds a Linear8bitLt directly (ld == K == d): in int8 mode the norm kernel also quantises the row
+static bool layernorm_q(sonic_engine* e, const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int d, float eps, const QGroup& grp) {
+    if (e->i8 && !e->opt_i8_no_lnq) {
+        const QuantActArgs qa = make_qa(e, y, d, M, d, grp);
+        launch_quant_act_begin(qa, e->st);
+        launch_layernorm(x, w, b, y, M, d, eps, e->st, e->dt, &qa);
+        return true;
+    }
+    launch_layernorm(x, w, b, y, M, d, eps, e->st, e->dt);
+    return false;
+}
+static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
+                    int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp, const float* rope_cs = nullptr, int rope_T = 0, int rope_ncols = 0,
+                    bool prequant = false) {
+    if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return false; }
+    const QuantActArgs qa = make_qa(e, X, ldx, M, K, grp);
+    if (prequant) launch_quant_act_finish(qa, e->st);      // the LayerNorm that wrote X also wrote its codes, absmax and flags
+    else launch_quant_act(qa, e->st);
     GemmArgs a{};
     a.A = (const bf16_t*)e->qa; a.lda = K; a.W = (const bf16_t*)q.cb; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = DT_F16;
     a.q.sca = e->q_sca; a.q.scb = q.scb; a.q.x16 = X; a.q.ldx16 = ldx; a.q.oc_cnt = e->q_oc_cnt; a.q.oc_list = e->q_oc_list; a.q.oc_ld = e->q_kmax;
@@ -848,7 +865,7 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
     e->gemm_ev_used = 0;
     for (int l = 0; l < d.enc_layers; ++l) {
         const EncLayerW& L = e->enc[l];
-        launch_layernorm(e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, e->st, dt);
+        const bool pq1 = layernorm_q(e, e->x, L.ln1w, L.ln1b, e->ln, M, C, d.enc_ln_eps, grp);
         const bool tev = e->opt_gemm_timing && (size_t)(8 * l + 7) < e->gemm_ev.size();
         auto mark = [&](int i) { if (tev) (void)hipEventRecord(e->gemm_ev[8 * l + i], e->st); };
         FlashArgs f{};
@@ -860,7 +877,7 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
             mark(0);
             const bool can_fuse = e->hd_e == 64 && d.enc_rotary_dim == 32 && !e->opt_no_fused_rope;
             const bool roped = qlinear(e, EPI_BIAS, e->ln, C, nullptr, L.qqkv, L.bqkv, e->qkv_rm, 3L * C, M, 3 * C, C, nullptr, 0, grp,
-                                       can_fuse ? e->enc_cs : nullptr, T, 2 * C);
+                                       can_fuse ? e->enc_cs : nullptr, T, 2 * C, pq1);
             mark(1);
             if (!roped) launch_rope_enc(e->qkv_rm, 3L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
             launch_transpose_v(e->qkv_rm, 3L * C, 2 * C, e->vt, W, T, C, e->Tp, (long)C * e->Tp, e->st);
@@ -884,9 +901,9 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
         mark(2);
         qlinear(e, EPI_BIAS_RESID, e->att, C, L.wo, L.qo, L.bo, e->x, C, M, C, C, e->x, C, grp);
         mark(3);
-        launch_layernorm(e->x, L.ln2w, L.ln2b, e->ln, M, C, d.enc_ln_eps, e->st, dt);
+        const bool pq2 = layernorm_q(e, e->x, L.ln2w, L.ln2b, e->ln, M, C, d.enc_ln_eps, grp);
         mark(4);
-        qlinear(e, EPI_BIAS_GELU, e->ln, C, L.w1, L.q1, L.b1, e->ff, d.enc_ff, M, d.enc_ff, C, nullptr, 0, grp);
+        qlinear(e, EPI_BIAS_GELU, e->ln, C, L.w1, L.q1, L.b1, e->ff, d.enc_ff, M, d.enc_ff, C, nullptr, 0, grp, nullptr, 0, 0, pq2);
         mark(5);
         if (tev) e->gemm_ev_used = l + 1;
         mark(6);
@@ -1852,6 +1869,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "i8_no_lnq")) { e->opt_i8_no_lnq = value; return SONIC_OK; }      // int8 encoder: LayerNorm does not quantise its rows (A/B)
     if (!strcmp(key, "i8_no_xq")) { e->opt_i8_no_xq = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm128_shallow")) { e->opts.gemm128_shallow = value; return SONIC_OK; }
     if (!strcmp(key, "no_skinny_i8_wide")) { e->opts.no_skinny_i8_wide = value; drop_graphs(e); return SONIC_OK; }

@@ -109,7 +109,9 @@ struct LogmelConst {
 void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev, int max_samples, const LogmelConst& lc,
                    float* logspec, int* segmax, int B, int n_frames, int n_mels, bf16_t* feats_fm, float* feats_f32, hipStream_t s, int dt = DT_BF16);
 
-void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt = DT_BF16);
+struct QuantActArgs;
+void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt = DT_BF16,
+                      const QuantActArgs* qa = nullptr);
 void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt = DT_BF16);
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
                         int dt = DT_BF16, const DeqInfo* dq = nullptr, const QuantOut* qo = nullptr);
@@ -149,6 +151,11 @@ struct QuantActArgs {
     int8_t* q; float* sca; int* oc_cnt; int* oc_list; int oc_ld;
 };
 void launch_quant_act(const QuantActArgs& a, hipStream_t s);
+// The same result in two halves when the producer of X owns whole rows (LayerNorm): `begin` clears the group flags, the producer writes X and, in
+// the same pass, the row's absmax, its int8 codes (its own elements >= 6.0 as 0) and the flags of those elements (launch_layernorm's `qa`);
+// `finish` lists the groups' outlier columns and zeroes them in the rows that held smaller values there.  Two streaming passes over X fewer.
+void launch_quant_act_begin(const QuantActArgs& a, hipStream_t s);
+void launch_quant_act_finish(const QuantActArgs& a, hipStream_t s);
 // finishes the rows an int8 GEMM deferred (GemmI8::defer_out): dense fp16 MFMA product over their gathered outlier columns + residual
 void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s);
 // decode flavour: every row is its own group; one block per row

@@ -103,6 +103,24 @@ __global__ __launch_bounds__(256) void qa_lists_kernel(QuantActArgs a) {
     if (tid == 0) a.oc_cnt[g] = total;
     for (int k = k0; k < k1; ++k) if (fl[k]) a.oc_list[(long)g * a.oc_ld + base++] = k;
 }
+// after qa_lists when the producer quantised the rows before the group's flags were complete: a column some OTHER row of the group flagged
+// still holds this row's code; one thread per row walks its group's list (empty for most groups)
+__global__ __launch_bounds__(256) void qa_fix_kernel(QuantActArgs a) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= a.M) return;
+    const int g = a.gmap ? a.gmap[m / a.gdiv] : m / a.gdiv;
+    const int cnt = a.oc_cnt[g];
+    for (int i = 0; i < cnt; ++i) a.q[(long)m * a.K + a.oc_list[(long)g * a.oc_ld + i]] = 0;
+}
+void launch_quant_act_begin(const QuantActArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    launch_fill_i32((int*)a.flags, 0, (int)(((long)a.G * a.K + 3) / 4), s);
+}
+void launch_quant_act_finish(const QuantActArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    hipLaunchKernelGGL(qa_lists_kernel, dim3(a.G), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(qa_fix_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a);
+}
 void launch_quant_act(const QuantActArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     launch_fill_i32((int*)a.flags, 0, (int)(((long)a.G * a.K + 3) / 4), s);

@@ -318,6 +318,50 @@ def test_int8_on_the_fly_quantisation_with_outliers_vs_oracle(orc):
     assert worst <= 0.2
 
 
+@pytest.mark.parametrize("ln_scale", [1.0, 3.5])
+def test_int8_layernorm_quantises_its_rows(orc, ln_scale):
+    """int8 encoder: the LayerNorm in front of q/k/v and fc1 writes the row's absmax, int8 codes and outlier flags in the pass that writes
+    the row; only the list + fix-up passes remain (`i8_no_lnq=1`: the three streaming passes of round 2).  Bit-identical logits, also when
+    LayerNorm outputs pass 6.0 (weights scaled by 3.5: rows of a request flag columns for each other, which the fix-up pass must zero in
+    the rows that had quantised them), a two-window request included; and the result stays on the int8 oracle."""
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    d = spec.TINY
+    st = synth.synth_state_dict(d, 29, 2)
+    n_scaled = 0
+    for k in st:
+        if "audio_tower.layers" in k and k.endswith("layernorm.weight"):
+            st[k] = f16(st[k] * ln_scale); n_scaled += 1
+    assert n_scaled == 2 * d.enc_layers
+    e = Engine(d, 0, MODE_INT8, max_batch=4, max_ctx=1024)
+    e.load_state_dict(st)
+    om = orc.Model(d, st, mode=orc.MODE_INT8)
+    from sonicscribe_amd import frontend
+    short = synth.synth_pcm(80, 80000)
+    n_long = 40 * 16000
+    long_pcm = frontend.normalise_to_int16(synth.synth_pcm(81, n_long).astype(np.float32) / 32768.0)
+    wins = [long_pcm[s0:e0] for s0, e0 in frontend.split_windows(n_long, d)]
+    assert len(wins) == 2
+    n_audio, _ = frontend.request_audio_tokens(n_long, d)
+    p_s = _prompt(80000, d)
+    p_l = [1, 17, 23, 5] + [d.audio_token_id] * n_audio + [7, 301, 302, 303, 9, 11]
+    n_new = 4
+    force = np.random.default_rng(6).integers(2, 900, (2, n_new)).astype(np.int32)
+    e.set_forced_ids(force)
+    try:
+        _, lg_a = e.transcribe_batch([short] + wins, [p_s, p_l], [n_new, n_new], req_win=[0, 1, 3], want_logits=True)
+        e.set_option("i8_no_lnq", 1)
+        _, lg_b = e.transcribe_batch([short] + wins, [p_s, p_l], [n_new, n_new], req_win=[0, 1, 3], want_logits=True)
+    finally:
+        e.set_forced_ids(None)
+        e.close()
+    assert np.array_equal(lg_a, lg_b), float(np.abs(lg_a - lg_b).max())
+    f0, m0 = orc.logmel(short)
+    r = om.transcribe(f0, int(m0.sum()), p_s, n_new, force_ids=force[0])
+    worst = float(np.abs(lg_a[:, 0] - r["step_logits"]).max())
+    print(f"int8 tiny, LayerNorm weights x {ln_scale}: max|dlogit| vs oracle {worst:.4f}")
+    assert worst <= 0.2
+
+
 def test_int8_bench_config_full_depth_vs_oracle(orc):
     """BASELINE config 4 at its real size: 32 + 28 layers, vocabulary 59264, INT8 mode, 64 x 20 s segments in one batch (what
     `bench.py --mode int8 --batch 64` times).  Two steps under teacher forcing:
