@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
 // ---------------------------------------------------------------- RMSNorm (modeling_llama.py:60-65)
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const float* w, T* y, int rows, int d, float eps,
-                                                      const int* row_map /* optional gather: y[r] = norm(x[row_map[r]]) */) {
+                                                      const int* row_map /* optional gather: y[r] = norm(x[row_map[r]]) */, QuantActArgs qa) {
     typedef typename ET<T>::v8 V8;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -147,14 +147,42 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const float* w
     }
     const float r = 1.0f / sqrtf(wave_sum(s) / d + eps);
     T* yr = y + (long)row * d;
+    float amax = -1.17549435e-38f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             V8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (T)(w[c * 8 + j] * rT<T>(v[i][j] * r));
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (T)(w[c * 8 + j] * rT<T>(v[i][j] * r));
+                v[i][j] = (float)o[j];
+                const float av = fabsf(v[i][j]);
+                if (av < LLM_INT8_THRESHOLD) amax = fmaxf(amax, av);
+            }
             *(V8*)(yr + c * 8) = o;
+        }
+    }
+    if (!qa.q) return;
+    // int8 mode, the row feeds a Linear8bitLt: absmax, codes and group flags in the same pass (as layernorm_kernel)
+    amax = wave_max(amax);
+    if (lane == 0) qa.sca[row] = amax;
+    const int g = qa.gmap ? qa.gmap[row / qa.gdiv] : row / qa.gdiv;
+    unsigned char* fl = qa.flags + (long)g * qa.K;
+    const float scale = 127.0f / amax;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            int pk[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool out = !(fabsf(v[i][j]) < LLM_INT8_THRESHOLD);
+                if (out) fl[c * 8 + j] = 1;
+                const int qv = (out || !(amax > 0.f)) ? 0 : (int)rintf(v[i][j] * scale);
+                pk[j >> 2] |= (qv & 0xFF) << ((j & 3) * 8);
+            }
+            *(int2*)(qa.q + (long)row * qa.K + c * 8) = make_int2(pk[0], pk[1]);
         }
     }
 }
@@ -554,8 +582,9 @@ void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y
     const QuantActArgs q = qa ? *qa : QuantActArgs{};
     DT_SWITCH(dt, T, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps, q));
 }
-void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt) {
-    DT_SWITCH(dt, T, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map));
+void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt, const QuantActArgs* qa) {
+    const QuantActArgs q = qa ? *qa : QuantActArgs{};
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map, q));
 }
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
                         int dt, const DeqInfo* dq, const QuantOut* qo) {

@@ -810,6 +810,16 @@ static bool layernorm_q(sonic_engine* e, const bf16_t* x, const float* w, const 
     launch_layernorm(x, w, b, y, M, d, eps, e->st, e->dt);
     return false;
 }
+static bool rmsnorm_q(sonic_engine* e, const bf16_t* x, const float* w, bf16_t* y, int M, int d, float eps, const QGroup& grp) {
+    if (e->i8 && !e->opt_i8_no_lnq) {
+        const QuantActArgs qa = make_qa(e, y, d, M, d, grp);
+        launch_quant_act_begin(qa, e->st);
+        launch_rmsnorm(x, w, y, M, d, eps, nullptr, e->st, e->dt, &qa);
+        return true;
+    }
+    launch_rmsnorm(x, w, y, M, d, eps, nullptr, e->st, e->dt);
+    return false;
+}
 static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
                     int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp, const float* rope_cs = nullptr, int rope_T = 0, int rope_ncols = 0,
                     bool prequant = false) {
@@ -1150,8 +1160,8 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
-        launch_rmsnorm(e->dx, L.ln1, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st, dt);
-        qlinear(e, EPI_BIAS, e->dhn, D, L.wqkv, L.qqkv, nullptr, e->dqkv, e->qkvN, M, e->qkvN, D, nullptr, 0, grp);
+        const bool pq1 = rmsnorm_q(e, e->dx, L.ln1, e->dhn, M, D, d.dec_rms_eps, grp);
+        qlinear(e, EPI_BIAS, e->dhn, D, L.wqkv, L.qqkv, nullptr, e->dqkv, e->qkvN, M, e->qkvN, D, nullptr, 0, grp, nullptr, 0, 0, pq1);
         RopeAppendArgs ra{}; ra.dt = dt;
         ra.qkv = e->dqkv; ra.ld = e->qkvN; ra.q_out = e->dq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = e->Vts; ra.vt_ld = e->max_ctx;
         ra.tok_seq = e->tok_seq; ra.tok_pos = e->tok_pos_pf; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = M;
@@ -1164,8 +1174,8 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
         f.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_flash(f, 128, true, R, hp.max_p, e->st);
         qlinear(e, EPI_BIAS_RESID, e->datt, e->QD, L.wo, L.qo, nullptr, e->dx, D, M, D, e->QD, e->dx, D, grp);
-        launch_rmsnorm(e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, nullptr, e->st, dt);
-        qlinear(e, EPI_SWIGLU, e->dhn, D, L.wgu, L.qgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D, nullptr, 0, grp);
+        const bool pq2 = rmsnorm_q(e, e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, grp);
+        qlinear(e, EPI_SWIGLU, e->dhn, D, L.wgu, L.qgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D, nullptr, 0, grp, nullptr, 0, 0, pq2);
         qlinear(e, EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, L.qdown, nullptr, e->dx, D, M, D, d.dec_ff, e->dx, D, grp);
         if (e->taps_on) HIPC(e, hipMemcpyAsync(e->taps + (size_t)(l + 1) * e->tok_cap * D, e->dx, (size_t)M * D * 2, hipMemcpyDeviceToDevice, e->st));
     }

@@ -112,7 +112,8 @@ void launch_logmel(const int16_t* pcm, long pcm_stride, const int* n_samples_dev
 struct QuantActArgs;
 void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt = DT_BF16,
                       const QuantActArgs* qa = nullptr);
-void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt = DT_BF16);
+void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt = DT_BF16,
+                    const QuantActArgs* qa = nullptr);
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
                         int dt = DT_BF16, const DeqInfo* dq = nullptr, const QuantOut* qo = nullptr);
 void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt = DT_BF16);

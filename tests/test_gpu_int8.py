@@ -320,8 +320,9 @@ def test_int8_on_the_fly_quantisation_with_outliers_vs_oracle(orc):
 
 @pytest.mark.parametrize("ln_scale", [1.0, 3.5])
 def test_int8_layernorm_quantises_its_rows(orc, ln_scale):
-    """int8 encoder: the LayerNorm in front of q/k/v and fc1 writes the row's absmax, int8 codes and outlier flags in the pass that writes
-    the row; only the list + fix-up passes remain (`i8_no_lnq=1`: the three streaming passes of round 2).  Bit-identical logits, also when
+    """int8 encoder / prefill: the LayerNorm in front of q/k/v and fc1 (the RMSNorm in front of q/k/v and gate/up) writes the row's absmax,
+    int8 codes and outlier flags in the pass that writes the row; only the list + fix-up passes remain (`i8_no_lnq=1`: the three streaming
+    passes of round 2).  Bit-identical logits, also when
     LayerNorm outputs pass 6.0 (weights scaled by 3.5: rows of a request flag columns for each other, which the fix-up pass must zero in
     the rows that had quantised them), a two-window request included; and the result stays on the int8 oracle."""
     from sonicscribe_amd.engine import Engine, MODE_INT8
@@ -329,9 +330,9 @@ def test_int8_layernorm_quantises_its_rows(orc, ln_scale):
     st = synth.synth_state_dict(d, 29, 2)
     n_scaled = 0
     for k in st:
-        if "audio_tower.layers" in k and k.endswith("layernorm.weight"):
-            st[k] = f16(st[k] * ln_scale); n_scaled += 1
-    assert n_scaled == 2 * d.enc_layers
+        if ".layers." in k and k.endswith("layernorm.weight"):          # encoder LayerNorms and decoder RMSNorms in front of linears
+            st[k] = f16(st[k] * (ln_scale if "audio_tower" in k else min(ln_scale, 2.0))); n_scaled += 1      # (RMSNorm x 2: ~0.3 % of its outputs pass 6.0)
+    assert n_scaled == 2 * d.enc_layers + 2 * d.dec_layers
     e = Engine(d, 0, MODE_INT8, max_batch=4, max_ctx=1024)
     e.load_state_dict(st)
     om = orc.Model(d, st, mode=orc.MODE_INT8)
@@ -359,7 +360,7 @@ def test_int8_layernorm_quantises_its_rows(orc, ln_scale):
     r = om.transcribe(f0, int(m0.sum()), p_s, n_new, force_ids=force[0])
     worst = float(np.abs(lg_a[:, 0] - r["step_logits"]).max())
     print(f"int8 tiny, LayerNorm weights x {ln_scale}: max|dlogit| vs oracle {worst:.4f}")
-    assert worst <= 0.2
+    assert worst <= 0.25
 
 
 def test_int8_bench_config_full_depth_vs_oracle(orc):
