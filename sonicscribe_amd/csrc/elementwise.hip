@@ -59,7 +59,7 @@ __device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active,
 // one wave per row, d % 8 == 0, d <= 2048; two-pass in registers (mean, then centred variance).
 // qa.q != null (int8 mode, the row feeds a Linear8bitLt): the wave that normalised the row also emits what the first two passes of
 // launch_quant_act would compute from it - row absmax without the elements >= 6.0, int8 codes (those elements as 0), and their group flags.
-template <typename T>
+template <typename T, bool Q>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float* w, const float* b, T* y, int rows, int d, float eps, QuantActArgs qa) {
     typedef typename ET<T>::v8 V8;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -95,14 +95,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 o[j] = (T)(((v[i][j] - mean) * rstd) * w[c * 8 + j] + b[c * 8 + j]);
-                v[i][j] = (float)o[j];
-                const float av = fabsf(v[i][j]);
-                if (av < LLM_INT8_THRESHOLD) amax = fmaxf(amax, av);
+                if constexpr (Q) {
+                    v[i][j] = (float)o[j];
+                    const float av = fabsf(v[i][j]);
+                    if (av < LLM_INT8_THRESHOLD) amax = fmaxf(amax, av);
+                }
             }
             *(V8*)(y + (long)row * d + c * 8) = o;
         }
     }
-    if (!qa.q) return;
+    if constexpr (!Q) return;
     amax = wave_max(amax);
     if (lane == 0) qa.sca[row] = amax;
     const int g = qa.gmap ? qa.gmap[row / qa.gdiv] : row / qa.gdiv;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
 }
 
 // ---------------------------------------------------------------- RMSNorm (modeling_llama.py:60-65)
-template <typename T>
+template <typename T, bool Q>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const float* w, T* y, int rows, int d, float eps,
                                                       const int* row_map /* optional gather: y[r] = norm(x[row_map[r]]) */, QuantActArgs qa) {
     typedef typename ET<T>::v8 V8;
@@ -156,14 +158,16 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const float* w
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 o[j] = (T)(w[c * 8 + j] * rT<T>(v[i][j] * r));
-                v[i][j] = (float)o[j];
-                const float av = fabsf(v[i][j]);
-                if (av < LLM_INT8_THRESHOLD) amax = fmaxf(amax, av);
+                if constexpr (Q) {
+                    v[i][j] = (float)o[j];
+                    const float av = fabsf(v[i][j]);
+                    if (av < LLM_INT8_THRESHOLD) amax = fmaxf(amax, av);
+                }
             }
             *(V8*)(yr + c * 8) = o;
         }
     }
-    if (!qa.q) return;
+    if constexpr (!Q) return;
     // int8 mode, the row feeds a Linear8bitLt: absmax, codes and group flags in the same pass (as layernorm_kernel)
     amax = wave_max(amax);
     if (lane == 0) qa.sca[row] = amax;
@@ -580,11 +584,13 @@ __global__ void synth_fill_kernel(unsigned long long key, long n, float scale, f
 // ---------------------------------------------------------------- launchers
 void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt, const QuantActArgs* qa) {
     const QuantActArgs q = qa ? *qa : QuantActArgs{};
-    DT_SWITCH(dt, T, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps, q));
+    if (q.q) { DT_SWITCH(dt, T, hipLaunchKernelGGL((layernorm_kernel<T, true>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps, q)); }
+    else { DT_SWITCH(dt, T, hipLaunchKernelGGL((layernorm_kernel<T, false>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, b, (T*)y, rows, d, eps, q)); }
 }
 void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt, const QuantActArgs* qa) {
     const QuantActArgs q = qa ? *qa : QuantActArgs{};
-    DT_SWITCH(dt, T, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map, q));
+    if (q.q) { DT_SWITCH(dt, T, hipLaunchKernelGGL((rmsnorm_kernel<T, true>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map, q)); }
+    else { DT_SWITCH(dt, T, hipLaunchKernelGGL((rmsnorm_kernel<T, false>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map, q)); }
 }
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
                         int dt, const DeqInfo* dq, const QuantOut* qo) {
