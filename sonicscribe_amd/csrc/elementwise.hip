@@ -213,7 +213,11 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
         // int8: the row's outlier pairs and this thread's slabs are requested together, the pairs go through LDS (int8_util.h)
         const int col[1] = {c < nv ? c * 8 : 0};
         float a[1][8];
-        if (dq.scan) {
+        if (dq.dbg & 1) {
+            const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
+            OutlStage os{}; os.n = 0;
+            slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
+        } else if (dq.scan) {
             // the projection quantised its input on the fly: this block lists the input row's outliers itself (K <= 4 * 8 * blockDim.x)
             const OutlScan<4> sc = outl_scan_issue<4>(dq, row);
             const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
         for (int j = 0; j < 8; ++j) { o[j] = (T)(w[c * 8 + j] * rT<T>(v[j] * r)); yo[j] = (float)o[j]; }
         *(V8*)(y + (long)row * d + c * 8) = o;
     }
-    if (qo.q) quant_emit_row(yo, c < nv, c, row, qo, part, parti);
+    if (qo.q && !(dq.dbg & 2)) quant_emit_row(yo, c < nv, c, row, qo, part, parti);
 }
 
 // decode: act[r][c] = T(T(silu(T g)) * T u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)

@@ -59,7 +59,7 @@ struct sonic_engine {
     // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
     int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
     int q_kmax = 0; bf16_t* qkv_rm = nullptr;
-    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0; int opt_i8_no_lnq = 0;   // rows deferred to the outlier side product leave the GEMM here
+    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0; int opt_i8_no_lnq = 0; int opt_i8_dbg = 0;   // rows deferred to the outlier side product leave the GEMM here
     // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
@@ -1045,7 +1045,7 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
     const QuantOut q_act{e->act_q, FF, e->sca_act, e->oc_act, e->ol_act, FF, e->ov_act};
     auto deq = [&](const QuantOut& q, const QW& w, int K, const bf16_t* x16) {
         DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.cbt = w.cbt; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
-        dq.row_group = nullptr; dq.group_div = 1; dq.oc_val = q.oc_val;
+        dq.row_group = nullptr; dq.group_div = 1; dq.oc_val = q.oc_val; dq.dbg = e->opt_i8_dbg;
         return dq;
     };
     for (int l = 0; l < d.dec_layers; ++l) {
@@ -1880,6 +1880,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "i8_no_lnq")) { e->opt_i8_no_lnq = value; return SONIC_OK; }      // int8 encoder: LayerNorm does not quantise its rows (A/B)
+    if (!strcmp(key, "i8_dbg")) { e->opt_i8_dbg = value; drop_graphs(e); return SONIC_OK; }     // timing experiments (wrong results)
     if (!strcmp(key, "i8_no_xq")) { e->opt_i8_no_xq = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm128_shallow")) { e->opts.gemm128_shallow = value; return SONIC_OK; }
     if (!strcmp(key, "no_skinny_i8_wide")) { e->opts.no_skinny_i8_wide = value; drop_graphs(e); return SONIC_OK; }

@@ -16,6 +16,7 @@ struct DeqInfo {
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
     const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div
     const float* oc_val;              // optional (decode: one row = one group): x value of every list entry, same indexing as oc_list
+    int dbg;                          // timing experiments only (option i8_dbg; results are wrong): bit 0 skip the outlier stage, bit 1 skip the re-quantisation
     int scan;                         // decode consumers that own a row: 1 = nobody listed the row's outliers (its producer did not own whole rows and
                                       // the projection quantised it on the fly, SkinnyArgs.x_amax): the consumer finds them in x16 itself, ascending;
                                       // sca then holds 4 partial maxima per row ([M][4], the row absmax is their maximum).
