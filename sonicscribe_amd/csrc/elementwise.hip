@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
     float s = 0.f;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     T* xr = x + (long)row * d + (c < nv ? c : 0) * 8;
+    // the norm weight is requested FIRST: it is cold every step (8 KiB per layer, read once per token) and used only behind the block's
+    // reduction - loaded where it is used, it was a second HBM round trip of the kernel's critical path
+    f32x4 nw0 = *(const f32x4*)(w + (c < nv ? c : 0) * 8), nw1 = *(const f32x4*)(w + (c < nv ? c : 0) * 8 + 4);
     const V8 t = *(const V8*)xr;                      // (requested before the slabs: one round trip for both)
     if (dq.sca) {
         // int8: the row's outlier pairs and this thread's slabs are requested together, the pairs go through LDS (int8_util.h)
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
         for (int j = 0; j < 8; ++j) { o[j] = (T)((float)t[j] + rT<T>(acc[j])); v[j] = (float)o[j]; s += v[j] * v[j]; }
         *(V8*)xr = o;
     }
+    asm volatile("" : "+v"(nw0), "+v"(nw1));          // (keeps the weight loads above the barrier)
     s = wave_sum(s);
     if (lane == 0) part[wid] = s;
     __syncthreads();
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
     if (c < nv) {
         V8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] = (T)(w[c * 8 + j] * rT<T>(v[j] * r)); yo[j] = (float)o[j]; }
+        for (int j = 0; j < 8; ++j) { o[j] = (T)((j < 4 ? nw0[j & 3] : nw1[j & 3]) * rT<T>(v[j] * r)); yo[j] = (float)o[j]; }
         *(V8*)(y + (long)row * d + c * 8) = o;
     }
     if (qo.q && !(dq.dbg & 2)) quant_emit_row(yo, c < nv, c, row, qo, part, parti);
@@ -451,6 +455,10 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
     const long ks_stride = (long)a.mpad * a.V;
     float* dump = a.logits_dump ? a.logits_dump + (long)a.step_counter[b] * a.dump_stride_step + (long)b * a.V : nullptr;
     float best = -INFINITY; int bi = 0x7fffffff;
+    // the first layer's norm weight for the tail of this kernel, requested before anything else (cold every step; behind the token's
+    // embedding row it was one more dependent round trip)
+    f32x4 gw0 = {0.f, 0.f, 0.f, 0.f}, gw1 = {0.f, 0.f, 0.f, 0.f};
+    if (a.y && (a.d >> 3) <= 1024 && tid < (a.d >> 3)) { gw0 = *(const f32x4*)(a.norm_w + tid * 8); gw1 = *(const f32x4*)(a.norm_w + tid * 8 + 4); }
     // four strides per trip with all their slab loads issued first (the rolled form paid one L2 round trip per stride)
     constexpr int U = 4;
     for (int i0 = tid * 4; i0 < a.V; i0 += 1024 * 4 * U) {
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
     if (c < nv) {
         V8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] = (T)(a.norm_w[c * 8 + j] * rT<T>((float)xv[j] * r)); yo[j] = (float)o[j]; }
+        for (int j = 0; j < 8; ++j) { o[j] = (T)((j < 4 ? gw0[j & 3] : gw1[j & 3]) * rT<T>((float)xv[j] * r)); yo[j] = (float)o[j]; }
         *(V8*)((T*)a.y + (long)b * a.d + c * 8) = o;
     }
     if (a.qo.q) quant_emit_row(yo, c < nv, c, b, a.qo, sv, si);
