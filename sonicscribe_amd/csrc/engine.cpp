@@ -59,7 +59,7 @@ struct sonic_engine {
     // int8 mode scratch: quantised activations of the GEMM in flight, row statistics, outlier columns per request, window -> request map
     int8_t* qa = nullptr; float* q_sca = nullptr; unsigned char* q_flags = nullptr; int *q_oc_cnt = nullptr, *q_oc_list = nullptr, *win_req = nullptr;
     int q_kmax = 0; bf16_t* qkv_rm = nullptr;
-    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0; int opt_i8_no_lnq = 0; int opt_i8_dbg = 0;   // rows deferred to the outlier side product leave the GEMM here
+    bf16_t* defer_tmp = nullptr; size_t defer_cap = 0; int opt_i8_defer_thr = 8; int opt_i8_no_xq = 0; int opt_i8_no_lnq = 0; int opt_i8_dbg = 0; int opt_i8_no_qkv_fuse = 0;   // rows deferred to the outlier side product leave the GEMM here
     // int8 decode step: the three quantised row sets (input norm output, attention output, SwiGLU output)
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
@@ -820,9 +820,12 @@ static bool rmsnorm_q(sonic_engine* e, const bf16_t* x, const float* w, bf16_t* 
     launch_rmsnorm(x, w, y, M, d, eps, nullptr, e->st, e->dt);
     return false;
 }
+// the encoder's fused q|k|v linear in int8 mode: where V^T goes when the 256x256 kernel can take the whole epilogue (RoPE on q / k on the way out
+// of the staged tile, V transposed while staging)
+struct QkvVt { bf16_t* Vt; int n_split, seg_T, vt_ld; long vt_seg_stride; };
 static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
                     int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp, const float* rope_cs = nullptr, int rope_T = 0, int rope_ncols = 0,
-                    bool prequant = false) {
+                    bool prequant = false, const QkvVt* vt = nullptr) {
     if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return false; }
     const QuantActArgs qa = make_qa(e, X, ldx, M, K, grp);
     if (prequant) launch_quant_act_finish(qa, e->st);      // the LayerNorm that wrote X also wrote its codes, absmax and flags
@@ -831,8 +834,13 @@ static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const b
     a.A = (const bf16_t*)e->qa; a.lda = K; a.W = (const bf16_t*)q.cb; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = DT_F16;
     a.q.sca = e->q_sca; a.q.scb = q.scb; a.q.x16 = X; a.q.ldx16 = ldx; a.q.oc_cnt = e->q_oc_cnt; a.q.oc_list = e->q_oc_list; a.q.oc_ld = e->q_kmax;
     a.q.row_group = grp.gmap; a.q.group_div = grp.gdiv;
-    const bool fuse = false && rope_cs && !g_opts.gemm_force128 && gemm256_eligible(a, epi);   // int8 kind: the fused form spills (gemm256.hip), RoPE stays its own pass
-    if (fuse) { a.rope_cs = rope_cs; a.rope_T = rope_T; a.rope_ncols = rope_ncols; }
+    // int8 q|k|v: RoPE + V^T inside the GEMM's epilogue (round 3; the register form of the 16-bit kinds spilled beside the dequantisation, the int8
+    // kind does both on the staged tile).  Returns true: the caller skips its RoPE and transpose passes.
+    bool fuse = false;
+    if (vt && rope_cs && !e->opt_i8_no_qkv_fuse && !g_opts.gemm_force128) {
+        GemmArgs t = a; t.Vt = vt->Vt; t.n_split = vt->n_split; t.seg_T = vt->seg_T; t.vt_ld = vt->vt_ld; t.vt_seg_stride = vt->vt_seg_stride;
+        if (gemm256_eligible(t, EPI_QKV_VT)) { a = t; a.rope_cs = rope_cs; a.rope_T = rope_T; a.rope_ncols = rope_ncols; epi = EPI_QKV_VT; fuse = true; }
+    }
     // residual-epilogue linears (o_proj, fc2, down_proj: their inputs are activation outputs, where long outlier lists occur): requests with
     // more than `i8_defer_thr` outlier columns are finished by the dense side product instead of the epilogue's per-element list walk
     const bool defer = epi == EPI_BIAS_RESID && e->defer_tmp && e->opt_i8_defer_thr >= 0 && (size_t)M * ldc <= e->defer_cap;
@@ -886,11 +894,14 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
             // ([M][3C]) and V is transposed by its own pass (the fused V^T epilogue plus the dequantisation spills registers)
             mark(0);
             const bool can_fuse = e->hd_e == 64 && d.enc_rotary_dim == 32 && !e->opt_no_fused_rope;
-            const bool roped = qlinear(e, EPI_BIAS, e->ln, C, nullptr, L.qqkv, L.bqkv, e->qkv_rm, 3L * C, M, 3 * C, C, nullptr, 0, grp,
-                                       can_fuse ? e->enc_cs : nullptr, T, 2 * C, pq1);
+            const QkvVt vt{e->vt, 2 * C, T, e->Tp, (long)C * e->Tp};
+            const bool fused = qlinear(e, EPI_BIAS, e->ln, C, nullptr, L.qqkv, L.bqkv, e->qkv_rm, 3L * C, M, 3 * C, C, nullptr, 0, grp,
+                                       can_fuse ? e->enc_cs : nullptr, T, 2 * C, pq1, &vt);
             mark(1);
-            if (!roped) launch_rope_enc(e->qkv_rm, 3L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
-            launch_transpose_v(e->qkv_rm, 3L * C, 2 * C, e->vt, W, T, C, e->Tp, (long)C * e->Tp, e->st);
+            if (!fused) {
+                launch_rope_enc(e->qkv_rm, 3L * C, M, T, 2 * H, e->hd_e, d.enc_rotary_dim, e->enc_cs, e->st, dt);
+                launch_transpose_v(e->qkv_rm, 3L * C, 2 * C, e->vt, W, T, C, e->Tp, (long)C * e->Tp, e->st);
+            }
             f.Q = e->qkv_rm; f.q_ld = 3L * C; f.K = e->qkv_rm + C; f.k_ld = 3L * C;
             f.q_seq_stride = (long)T * 3 * C; f.k_seq_stride = (long)T * 3 * C;
         } else {
@@ -1880,6 +1891,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "i8_no_lnq")) { e->opt_i8_no_lnq = value; return SONIC_OK; }      // int8 encoder: LayerNorm does not quantise its rows (A/B)
+    if (!strcmp(key, "i8_no_qkv_fuse")) { e->opt_i8_no_qkv_fuse = value; return SONIC_OK; }   // int8 encoder: RoPE and V^T as their own passes (A/B)
     if (!strcmp(key, "i8_dbg")) { e->opt_i8_dbg = value; drop_graphs(e); return SONIC_OK; }     // timing experiments (wrong results)
     if (!strcmp(key, "i8_no_xq")) { e->opt_i8_no_xq = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm128_shallow")) { e->opts.gemm128_shallow = value; return SONIC_OK; }

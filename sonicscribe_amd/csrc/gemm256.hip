@@ -114,7 +114,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
 
-    const bool vtile = (EPI == EPI_QKV_VT) && (n0 >= a.n_split);
+    // V tiles of the fused QKV GEMM leave transposed.  16-bit kinds compute them transposed (operands swapped in the MFMA); the int8 kind keeps
+    // the normal orientation - its dequantising epilogue is written per row - and transposes while staging (vtile8)
+    const bool vtile = (EPI == EPI_QKV_VT) && !KD::I8 && (n0 >= a.n_split);
+    const bool vtile8 = (EPI == EPI_QKV_VT) && KD::I8 && (n0 >= a.n_split);
     Frag af[4][2], b0[2][2], b1[2][2];
     auto read_a = [&](int buf, int half) {
         const char* s = smem + buf * TILE_BYTES + (half ? SLOT_A1 : SLOT_A0) * HT_BYTES;
@@ -307,6 +310,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             for (int mb = 0; mb < 8; ++mb) smem[LDS256_BYTES + wr * 128 + mb * 16 + fr] = rws[mb].defer ? 1 : 0;
         }
     }
+    if constexpr (KD::I8 && EPI == EPI_QKV_VT) {
+        if (vtile8) {
+            // int8 V tile: module outputs as in the bias epilogue (dequantisation + outlier columns of the row's request), staged TRANSPOSED
+            // (row = n, 2-byte stores), then the same coalesced V^T rows out as the 16-bit kinds
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int nl = wc * 64 + nb * 16 + fg * 4, n = n0 + nl;
+                const int nc = n + 3 < a.N ? n : 0;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) { const f32x4 b4 = *(const f32x4*)(a.bias + nc); bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3]; }
+                const f32x4 sb = *(const f32x4*)(a.q.scb + nc);
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(OT*)(smem + (nl + j) * CLD + (wr * 128 + mb * 16 + fr) * 2) = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 32; ++it) {
+                const int c = it * 512 + tid, nl = c >> 6, mc = c & 63;
+                const int m = m0 + mc * 4, n = n0 + nl;
+                if (m < a.M && n < a.N) {
+                    const int seg = m / a.seg_T, t = m - seg * a.seg_T;
+                    *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = *(const O4*)(smem + nl * CLD + mc * 8);
+                }
+            }
+            return;
+        }
+    }
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -352,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         f32x4 sb = {0.f, 0.f, 0.f, 0.f};
         if constexpr (KD::I8) sb = *(const f32x4*)(a.q.scb + nc);
         if (rope && nb == 1) continue;                       // written together with block 0
-        if constexpr (KD::I8 && EPI != EPI_QKV_VT) {
+        if constexpr (KD::I8) {
             // Outlier columns as an outer product.  When the 8 rows of this lane belong to one request (one outlier list; a 256-row tile
             // spans at most a few requests) the list is walked ONCE per 8 x 4 block: per column k, 1 index + 8 activations + 4 weights are
             // loaded for 32 products, instead of 2 loads per product in the per-element loop (prefill down_proj with ~360 outlier columns:
@@ -464,6 +499,30 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int m = m0 + row, n = n0 + ch * 8;
         if (m < a.M && n < a.N) {
             O8 v = *(const O8*)(smem + row * CLD + ch * 16);
+            if constexpr (KD::I8 && EPI == EPI_QKV_VT) {
+                // int8 q / k tile: the encoder's partial RoPE on the way out (the register form of the 16-bit kinds is over the VGPR budget
+                // beside the dequantisation): a head is 64 columns = 8 chunks; chunk 0 / 1 hold dims [0,16), their partners [16,32) sit two
+                // chunks on; this thread writes both.  Same arithmetic as rope_enc_kernel.
+                if (a.rope_cs && n0 < a.rope_ncols) {
+                    const int hl = (ch & 7) * 8;
+                    if (hl >= 16 && hl < 32) continue;
+                    if (hl < 16) {
+                        const O8 v2 = *(const O8*)(smem + row * CLD + (ch + 2) * 16);
+                        const float* cs = a.rope_cs + (long)(m % a.rope_T) * 32 + hl;
+                        const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4), s0 = *(const f32x4*)(cs + 16), s1 = *(const f32x4*)(cs + 20);
+                        O8 o1, o2;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float x1 = (float)v[j], x2 = (float)v2[j], cc = j < 4 ? c0[j & 3] : c1[j & 3], ss = j < 4 ? s0[j & 3] : s1[j & 3];
+                            o1[j] = (OT)(rT<OT>(x1 * cc) + rT<OT>(-x2 * ss));
+                            o2[j] = (OT)(rT<OT>(x2 * cc) + rT<OT>(x1 * ss));
+                        }
+                        *(O8*)(C + (long)m * a.ldc + n) = o1;
+                        *(O8*)(C + (long)m * a.ldc + n + 16) = o2;
+                        continue;
+                    }
+                }
+            }
             if constexpr (DEFER) {
                 if (smem[LDS256_BYTES + row]) { *(O8*)((OT*)a.q.defer_out + (long)blockIdx.z * a.strideC + (long)m * a.ldc + n) = v; continue; }
             }
@@ -489,7 +548,7 @@ template <int EPI> static void launch256(const GemmArgs& a0, hipStream_t s) {
     // raster group height: 8 M tiles per group; 2 when the matrix is at most 5 tiles wide (out_proj / fc2 of the encoder, N = 1280: +3-6 %
     // at M = 48000, tools/ab_gemm_raster.py); the option overrides both
     if (a.raster_gm <= 0) a.raster_gm = g_opts.gemm256_gm != 8 ? g_opts.gemm256_gm : ((a.N + T256 - 1) / T256 <= 5 ? 2 : 8);
-    if (a.q.sca) { if constexpr (EPI != EPI_QKV_VT) launch256v<KI8, EPI, true>(a, s); }
+    if (a.q.sca) launch256v<KI8, EPI, true>(a, s);
     else if (a.dt == DT_F16) launch256v<KF16, EPI, true>(a, s);
     else if (g_opts.gemm256_stagger) launch256v<KBF16, EPI, true>(a, s);
     else launch256v<KBF16, EPI, false>(a, s);                  // the un-staggered schedule is kept for bf16 experiments only
@@ -510,6 +569,6 @@ void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_BIAS_GELU: launch256<EPI_BIAS_GELU>(a, s); break;
         case EPI_BIAS_RESID: launch256<EPI_BIAS_RESID>(a, s); break;
         case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, s); break;
-        case EPI_QKV_VT: launch256<EPI_QKV_VT>(a, s); break;      // (never with int8 operands: the int8 encoder writes V row-major and transposes it)
+        case EPI_QKV_VT: launch256<EPI_QKV_VT>(a, s); break;
     }
 }

@@ -363,6 +363,44 @@ def test_int8_layernorm_quantises_its_rows(orc, ln_scale):
     assert worst <= 0.25
 
 
+@pytest.mark.parametrize("ln_scale", [1.0, 3.5])
+def test_int8_fused_qkv_rope_vt_equals_separate_passes(orc, ln_scale):
+    """int8 encoder at full width (d = 1280, 20 heads): the fused q|k|v Linear8bitLt runs on the 256x256 kernel with the partial RoPE applied on
+    the way out of the staged tile and V transposed while staging (`i8_no_qkv_fuse=1`: row-major Q|K|V + a RoPE pass + a transpose pass).  Same
+    arithmetic in both: bit-identical logits, also when the LayerNorm output holds outlier columns (weights x 3.5); and on the int8 oracle."""
+    from sonicscribe_amd.engine import Engine, MODE_INT8
+    d = replace(spec.FULL, enc_layers=1, dec_layers=1, vocab=1024, audio_token_id=1000, eos_ids=(990, 991, 992))
+    st = {}
+    for name, shape, kind in spec.tensor_inventory(d):
+        scale, offset = synth.kind_params(kind, shape)
+        st[name] = orc.synth_fill(31, name, int(np.prod(shape)), scale, offset, 2).reshape(shape)
+    for k in st:
+        if "audio_tower.layers" in k and k.endswith("input_layernorm.weight"):
+            st[k] = f16(st[k] * ln_scale)
+    e = Engine(d, 0, MODE_INT8, max_batch=2, max_ctx=320)
+    e.load_state_dict(st)
+    segs = [synth.synth_pcm(90 + i, 320000 if i == 0 else 100000) for i in range(2)]
+    prompts = [_prompt(len(x), d) for x in segs]
+    n_new = 2
+    force = np.asarray([[100, 200], [400, 500]], np.int32)
+    e.set_forced_ids(force)
+    try:
+        _, lg_a = e.transcribe_batch(segs, prompts, [n_new, n_new], want_logits=True)
+        e.set_option("i8_no_qkv_fuse", 1)
+        _, lg_b = e.transcribe_batch(segs, prompts, [n_new, n_new], want_logits=True)
+    finally:
+        e.set_forced_ids(None)
+        e.close()
+    assert np.isfinite(lg_a).all()
+    assert np.array_equal(lg_a, lg_b), float(np.abs(lg_a - lg_b).max())
+    om = orc.Model(d, st, mode=orc.MODE_INT8)
+    feats, mask = orc.logmel(segs[1])
+    r = om.transcribe(feats, int(mask.sum()), prompts[1], n_new, force_ids=force[1])
+    worst = float(np.abs(lg_a[:, 1] - r["step_logits"]).max())
+    print(f"int8 full-width 1+1, LayerNorm x {ln_scale}: max|dlogit| vs oracle {worst:.4f}")
+    assert worst <= 0.25
+
+
 def test_int8_bench_config_full_depth_vs_oracle(orc):
     """BASELINE config 4 at its real size: 32 + 28 layers, vocabulary 59264, INT8 mode, 64 x 20 s segments in one batch (what
     `bench.py --mode int8 --batch 64` times).  Two steps under teacher forcing:
