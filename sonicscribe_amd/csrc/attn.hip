@@ -670,6 +670,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     __syncthreads();
     KT(a, 3);
     float amx = 0.f;                         // int8 mode: absmax of this thread's outputs without the elements >= 6.0
+    int nbig = 0;                            // ... and how many are >= 6.0
     for (int idx = tid; idx < G * HD; idx += 512) {
         const int h = idx / HD, e = idx % HD;
         float M = -1e30f;
@@ -682,19 +683,22 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
         ((T*)a.O)[(long)b * a.Hq * HD + (kvh * G + h) * HD + e] = ov;
         const float av = fabsf((float)ov);
         amx = fmaxf(amx, av < LLM_INT8_THRESHOLD ? av : 0.f);
+        nbig += !(av < LLM_INT8_THRESHOLD);
     }
     if (a.amax_out) {
         // this block's share of the row absmax for o_proj's on-the-fly quantisation (SkinnyArgs.x_amax): one plain store per block into the
         // row's 4 partials (an atomicMax per wave onto one word per row cost 8 us per launch: 13.1 -> 21.4)
         amx = wave_max(amx);
-        __syncthreads();                     // s_l is free: every thread has left the merge loop
-        if (lane == 0) s_l[wid][0] = amx;
+        const int wbig = __popcll(__ballot(nbig > 0)) > 0 ? (int)wave_sum((float)nbig) : 0;
+        __syncthreads();                     // s_l / s_m are free: every thread has left the merge loop
+        if (lane == 0) { s_l[wid][0] = amx; s_m[wid][0] = (float)wbig; }
         __syncthreads();
         if (tid == 0) {
-            float m = s_l[0][0];
+            float m = s_l[0][0], nb = s_m[0][0];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) m = fmaxf(m, s_l[w][0]);
+            for (int w = 1; w < NW; ++w) { m = fmaxf(m, s_l[w][0]); nb += s_m[w][0]; }
             a.amax_out[b * 4 + kvh] = m;
+            if (a.big_out) a.big_out[b * 4 + kvh] = (int)nb;
         }
     }
     KT(a, 4);

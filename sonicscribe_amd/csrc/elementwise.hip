@@ -15,6 +15,8 @@
 // A block that owns one whole row (thread c holds its elements [8c, 8c+8) as fp16 values in y, threads with !active hold nothing)
 // emits the row quantised: absmax without the elements >= 6.0, int8 = rn(y * 127 / absmax) (0 for outliers), and the ascending
 // list of the outlier positions.  Every thread of the block must call it.  s_f: >= 16 floats, s_i: >= 17 ints of LDS scratch.
+// FRESH: nobody has touched s_f / s_i in this kernel before (no barrier needed in front of the first write).
+template <bool FRESH = false>
 __device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active, int c, int row, const QuantOut& qo, float* s_f, int* s_i) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6;
     float amax = -1.17549435e-38f;
@@ -29,7 +31,7 @@ __device__ __forceinline__ void quant_emit_row(const float (&y)[8], bool active,
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
     }
-    __syncthreads();                                  // scratch may still be in use by the caller
+    if constexpr (!FRESH) __syncthreads();           // scratch may still be in use by the caller
     if (lane == 63) s_i[wid] = incl;
     if (lane == 0) s_f[wid] = amax;
     __syncthreads();
@@ -198,8 +200,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, int ksplit, int mpad, const float* w, T* y,
                                                           int rows, int d, float eps, DeqInfo dq, QuantOut qo) {
     typedef typename ET<T>::v8 V8;
-    __shared__ float part[16];
-    __shared__ int parti[17];
+    __shared__ float part[16], qpart[16];             // (qpart / qparti: the re-quantisation's own scratch - no barrier before its first write)
+    __shared__ int parti[17], qparti[17];
     __shared__ int s_ok[OUTL_CAP];
     __shared__ float s_ox[OUTL_CAP];
     const int row = blockIdx.x, c = threadIdx.x, lane = c & 63, wid = c >> 6;
@@ -222,9 +224,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
             slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
         } else if (dq.scan) {
             // the projection quantised its input on the fly: this block lists the input row's outliers itself (K <= 4 * 8 * blockDim.x)
+            // (the producers' per-block counts say whether there is anything to find: usually not, and then the block scan and its barriers
+            //  are skipped; the row itself is requested either way, before the verdict is known)
+            i32x4 nb4 = {1, 0, 0, 0};
+            if (dq.scan_cnt) nb4 = *(const i32x4*)(dq.scan_cnt + row * 4);
             const OutlScan<4> sc = outl_scan_issue<4>(dq, row);
             const Slab8<1, 8> sl = slab8_load<1, 8>(dq, P, ksplit, mpad, row, col, d);
-            const OutlStage os = outl_scan_commit<4>(dq, row, sc, s_ok, s_ox, parti);
+            OutlStage os{}; os.n = 0;
+            if ((nb4[0] | nb4[1] | nb4[2] | nb4[3]) != 0) os = outl_scan_commit<4>(dq, row, sc, s_ok, s_ox, parti);     // (block-uniform)
             slab8_finish<1, 8>(dq, P, ksplit, mpad, row, col, d, sl, os, s_ok, s_ox, a);
         } else {
             const OutlStage os = outl_issue(dq, row);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
         for (int j = 0; j < 8; ++j) { o[j] = (T)((j < 4 ? nw0[j & 3] : nw1[j & 3]) * rT<T>(v[j] * r)); yo[j] = (float)o[j]; }
         *(V8*)(y + (long)row * d + c * 8) = o;
     }
-    if (qo.q && !(dq.dbg & 2)) quant_emit_row(yo, c < nv, c, row, qo, part, parti);
+    if (qo.q && !(dq.dbg & 2)) quant_emit_row<true>(yo, c < nv, c, row, qo, qpart, qparti);
 }
 
 // decode: act[r][c] = T(T(silu(T g)) * T u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(1024) void swiglu_quant_kernel(const float* P, int 
         for (int j = 0; j < 8; ++j) { o[j] = (f16_t)(rT<f16_t>(silu_f(gu[0][j])) * gu[1][j]); y[j] = (float)o[j]; }
         *(f16x8*)(act + (long)row * ff + c * 8) = o;
     }
-    quant_emit_row(y, active, c, row, qo, part, parti);
+    quant_emit_row<true>(y, active, c, row, qo, part, parti);
 }
 
 // decode flavour of the activation quantiser: one block per row of an fp16 matrix (K <= 8192)
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(1024) void quant_rows_kernel(const f16_t* X, long l
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = (float)t[j];
     }
-    quant_emit_row(y, active, c, row, qo, part, parti);
+    quant_emit_row<true>(y, active, c, row, qo, part, parti);
 }
 
 // ---------------------------------------------------------------- encoder RoPE (modeling_glmasr.py:153-168)

@@ -64,6 +64,7 @@ struct sonic_engine {
     int8_t *hn_q = nullptr, *att_q = nullptr, *act_q = nullptr; float *sca_hn = nullptr, *sca_att = nullptr, *sca_act = nullptr;
     int *oc_hn = nullptr, *oc_att = nullptr, *oc_act = nullptr, *ol_hn = nullptr, *ol_att = nullptr, *ol_act = nullptr;
     float *ov_hn = nullptr, *ov_att = nullptr, *ov_act = nullptr;      // the outliers' values beside the lists
+    int* big_att = nullptr;                                             // [64][4] per-block counts of attention outputs >= 6.0
     float *amax_att = nullptr, *amax_act = nullptr;                     // [64][4] partial row maxima written by producers that do not own whole rows
     std::map<std::string, bool> raw_f16;   // int8 mode: tensors already converted to fp16 at load
     bf16_t* embed = nullptr; bf16_t* embed_t = nullptr;
@@ -495,7 +496,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
         A(dalloc(e, &e->oc_hn, 64)); A(dalloc(e, &e->oc_att, 64)); A(dalloc(e, &e->oc_act, 64));
         A(dalloc(e, &e->ol_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ol_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ol_act, (size_t)64 * d.dec_ff));
         A(dalloc(e, &e->ov_hn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->ov_att, (size_t)64 * e->QD)); A(dalloc(e, &e->ov_act, (size_t)64 * d.dec_ff));
-        A(dalloc(e, &e->amax_att, 64 * 4)); A(dalloc(e, &e->amax_act, 64 * 4));
+        A(dalloc(e, &e->amax_att, 64 * 4)); A(dalloc(e, &e->amax_act, 64 * 4)); A(dalloc(e, &e->big_att, 64 * 4));
     }
     A(dalloc(e, &e->src, tc)); A(dalloc(e, &e->tok_seq, tc)); A(dalloc(e, &e->tok_pos_pf, tc));
     A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
@@ -1070,12 +1071,12 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
         // o_proj's input rows are spread over the attention blocks of 4 kv heads: they gather the row absmax (atomicMax), o_proj quantises on the
         // fly and its consumer lists the outliers itself - no one-block-per-row quantisation launch in between (option i8_no_xq: the round-2 form)
         const bool xq = !e->opt_i8_no_xq;
-        if (xq) da.amax_out = e->amax_att;
+        if (xq) { da.amax_out = e->amax_att; da.big_out = e->big_att; }
         launch_decode_attn(da, R, e->st);
         DeqInfo dq;
         if (xq) {
             ks = skinny_i8_xq(e, e->satt, e->amax_att, L.qo.cbt, e->slab, R, D, e->QD);
-            dq = deq(q_att, L.qo, e->QD, e->satt); dq.sca = e->amax_att; dq.scan = 1;
+            dq = deq(q_att, L.qo, e->QD, e->satt); dq.sca = e->amax_att; dq.scan = 1; dq.scan_cnt = e->big_att;
         } else {
             launch_quant_rows(e->satt, e->QD, R, e->QD, q_att, e->st);
             ks = skinny_i8(e, e->att_q, L.qo.cbt, e->slab, R, D, e->QD);
@@ -1157,7 +1158,7 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     HIPC(e, hipMemcpyAsync(e->last_row, hp.last_row.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(e->max_new_d, hp.max_new.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
     launch_fill_i32(e->n_new, 0, 64, e->st);
-    if (e->amax_att) { launch_fill_i32((int*)e->amax_att, 0, 64 * 4, e->st); launch_fill_i32((int*)e->amax_act, 0, 64 * 4, e->st); }   // (partials nobody writes stay 0)
+    if (e->amax_att) { launch_fill_i32((int*)e->amax_att, 0, 64 * 4, e->st); launch_fill_i32((int*)e->amax_act, 0, 64 * 4, e->st); launch_fill_i32(e->big_att, 0, 64 * 4, e->st); }   // (partials nobody writes stay 0)
     launch_fill_i32(e->finished, 0, 64, e->st);
     launch_fill_i32(e->step_ctr, 0, 64, e->st);
     HIPC(e, hipMemcpyAsync(e->n_active, &R, 4, hipMemcpyHostToDevice, e->st));

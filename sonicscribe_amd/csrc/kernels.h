@@ -16,6 +16,8 @@ struct DeqInfo {
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
     const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div
     const float* oc_val;              // optional (decode: one row = one group): x value of every list entry, same indexing as oc_list
+    const int* scan_cnt;              // with scan: optional [M][4] per-block counts of the elements >= 6.0 (written beside the partial maxima): all zero - the
+                                      // common case - and the consumer skips its scan of the row
     int dbg;                          // timing experiments only (option i8_dbg; results are wrong): bit 0 skip the outlier stage, bit 1 skip the re-quantisation
     int scan;                         // decode consumers that own a row: 1 = nobody listed the row's outliers (its producer did not own whole rows and
                                       // the projection quantised it on the fly, SkinnyArgs.x_amax): the consumer finds them in x16 itself, ascending;
@@ -59,6 +61,7 @@ struct DecodeAttnArgs {
     DeqInfo dq;           // int8 mode: P holds int32 slabs of the quantised QKV projection
     float* amax_out;      // int8 mode, optional: [B][4] per-block partials (kv head) of the output rows' absmax without the elements >= 6.0; Hkv <= 4,
                           // unused partials stay 0
+    int* big_out;         // with amax_out: [B][4] how many of the block's outputs are >= 6.0
     long long* kt;        // diagnostics: per-block timestamps (common.h KT)
 };
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s);
