@@ -18,11 +18,15 @@ def energy_vad(rows, pcm, thr):
     return np.array([np.abs(p.astype(np.int32)).mean() / 12000.0 > t for p, t in zip(pcm, thr)])
 
 
-def test_128_sessions_gate_to_ring_decodes():
+@pytest.mark.parametrize("dims_name", ["tiny", "full"])
+def test_128_sessions_gate_to_ring_decodes(dims_name):
+    """`full`: the same 128 sessions on GLM-ASR-Nano dimensions (32 + 28 layers, vocabulary 59264) - BASELINE config 5's session count on one GPU;
+    a sample of the finals and partials is compared with solo `transcribe()` calls (every one at `tiny`)."""
     from sonicscribe_amd.asr import ASRModel
     from sonicscribe_amd.sessions import GatedSessions
     S = 128
-    m = ASRModel.from_synthetic(spec.TINY, device="cuda:0", max_batch=32, max_ctx=512)
+    full = dims_name == "full"
+    m = ASRModel.from_synthetic(spec.FULL if full else spec.TINY, device="cuda:0", max_batch=32, max_ctx=512)
     g = GatedSessions(m, [f"client-{i}" for i in range(S)])
     rng = np.random.default_rng(5)
     lead = rng.integers(3, 25, size=S)                 # silent chunks before the utterance
@@ -47,7 +51,7 @@ def test_128_sessions_gate_to_ring_decodes():
     by_sess = {e["session"]: e for e in finals}
     assert len(by_sess) == S
     checked = 0
-    for e in finals + partials[::7]:
+    for e in (finals[::9] + partials[::41] if full else finals + partials[::7]):
         s = int(e["session"].split("-")[1])
         a, n = e["first_sample"], e["n_samples"]
         max_new = 15 if e["type"] == "partial" else min(50 + int(n / 16000 * 5), 200)
