@@ -29,7 +29,7 @@ struct DevTensor {
 };
 
 // int8 mode (asr.py:169-210): a quantised Linear keeps row-wise int8 weights + row absmax instead of its 16-bit matrix
-struct QW { int8_t* cb = nullptr; float* scb = nullptr; int8_t* cbt = nullptr; };   // cbt: fragment-tiled copy for the decode step
+struct QW { int8_t* cb = nullptr; float* scb = nullptr; int8_t* cbt = nullptr; int8_t* cbk = nullptr; };   // cbt: fragment-tiled copy, cbk: k-major copy (decode step)
 struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; QW qqkv, qo, q1, q2; };
 #define KT_SLOT_BLOCKS 512                                   // "ktrace" diagnostics: blocks recorded per kernel slot, 8 timestamps each
 struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          // row-major (prefill GEMM)
@@ -668,6 +668,11 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
         TRY(dalloc_big(e, &q->cbt, (size_t)N * K, false));
         launch_tile_weights_i8(q->cb, q->cbt, N, K, e->st);
         e->weight_bytes += (int64_t)N * K;
+        if (!getenv("SONIC_NO_CBK")) {           // k-major copy for the decode consumers' outlier gathers (8 consecutive bytes instead of 8 sectors)
+            TRY(dalloc_big(e, &q->cbk, (size_t)N * K, false));
+            launch_transpose_i8(q->cb, q->cbk, N, K, e->st);
+            e->weight_bytes += (int64_t)N * K;
+        }
     }
     HIPC(e, hipStreamSynchronize(e->st));
     for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w16) { e->allocs.erase(it); break; }
@@ -1055,8 +1060,8 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
     const QuantOut q_hn{e->hn_q, D, e->sca_hn, e->oc_hn, e->ol_hn, D, e->ov_hn};
     const QuantOut q_att{e->att_q, e->QD, e->sca_att, e->oc_att, e->ol_att, e->QD, e->ov_att};
     const QuantOut q_act{e->act_q, FF, e->sca_act, e->oc_act, e->ol_act, FF, e->ov_act};
-    auto deq = [&](const QuantOut& q, const QW& w, int K, const bf16_t* x16) {
-        DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.cbt = w.cbt; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
+    auto deq = [&](const QuantOut& q, const QW& w, int K, const bf16_t* x16, int N) {
+        DeqInfo dq{}; dq.sca = q.sca; dq.scb = w.scb; dq.cb = w.cb; dq.cbt = w.cbt; dq.cbk = w.cbk; dq.N = N; dq.K = K; dq.x16 = x16; dq.ldx16 = K; dq.oc_cnt = q.oc_cnt; dq.oc_list = q.oc_list; dq.oc_ld = q.oc_ld;
         dq.row_group = nullptr; dq.group_div = 1; dq.oc_val = q.oc_val; dq.dbg = e->opt_i8_dbg;
         return dq;
     };
@@ -1065,7 +1070,7 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
         int ks = skinny_i8(e, e->hn_q, L.qqkv.cbt, e->slab, R, e->qkvN, D);
         DecodeAttnArgs da{};
-        da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = DT_F16; da.dq = deq(q_hn, L.qqkv, D, e->shn);
+        da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = DT_F16; da.dq = deq(q_hn, L.qqkv, D, e->shn, e->qkvN);
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         // o_proj's input rows are spread over the attention blocks of 4 kv heads: they gather the row absmax (atomicMax), o_proj quantises on the
@@ -1076,17 +1081,17 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
         DeqInfo dq;
         if (xq) {
             ks = skinny_i8_xq(e, e->satt, e->amax_att, L.qo.cbt, e->slab, R, D, e->QD);
-            dq = deq(q_att, L.qo, e->QD, e->satt); dq.sca = e->amax_att; dq.scan = 1; dq.scan_cnt = e->big_att;
+            dq = deq(q_att, L.qo, e->QD, e->satt, D); dq.sca = e->amax_att; dq.scan = 1; dq.scan_cnt = e->big_att;
         } else {
             launch_quant_rows(e->satt, e->QD, R, e->QD, q_att, e->st);
             ks = skinny_i8(e, e->att_q, L.qo.cbt, e->slab, R, D, e->QD);
-            dq = deq(q_att, L.qo, e->QD, e->satt);
+            dq = deq(q_att, L.qo, e->QD, e->satt, D);
         }
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st, DT_F16, &dq, &q_hn);
         ks = skinny_i8(e, e->hn_q, L.qgu.cbt, e->slab, R, 2 * FF, D);
-        launch_swiglu_quant(e->slab, ks, mpad, FF, e->sact, R, deq(q_hn, L.qgu, D, e->shn), q_act, e->st);
+        launch_swiglu_quant(e->slab, ks, mpad, FF, e->sact, R, deq(q_hn, L.qgu, D, e->shn, 2 * FF), q_act, e->st);
         ks = skinny_i8(e, e->act_q, L.qdown.cbt, e->slab, R, D, FF);
-        dq = deq(q_act, L.qdown, FF, e->sact);
+        dq = deq(q_act, L.qdown, FF, e->sact, D);
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, DT_F16, &dq, &q_hn);
     }

@@ -177,10 +177,11 @@ __device__ __forceinline__ void outl_get(const DeqInfo& q, int row, const OutlSt
 }
 // byte address of W[n][k] (see deq_w); consecutive n inside a 16-row group are `deq_w_stride` bytes apart
 __device__ __forceinline__ const int8_t* deq_w_ptr(const DeqInfo& q, int n, int k) {
+    if (q.cbk) return q.cbk + (long)k * q.N + n;
     if (q.cbt) return q.cbt + ((long)(n >> 4) * (q.K >> 6) + (k >> 6)) * 1024 + ((((k & 63) >> 4) * 16) + (n & 15)) * 16 + (k & 15);
     return q.cb + (long)n * q.K + k;
 }
-__device__ __forceinline__ long deq_w_stride(const DeqInfo& q) { return q.cbt ? 16 : q.K; }
+__device__ __forceinline__ long deq_w_stride(const DeqInfo& q) { return q.cbk ? 1 : q.cbt ? 16 : q.K; }
 
 // NG groups of 8 consecutive output columns (col[g] % 8 == 0) of one row.  KU = slabs requested up front.
 template <int NG, int KU> struct Slab8 { i32x4 sl[KU][NG][2]; f32x4 sb[NG][2]; float sa; };
@@ -239,9 +240,18 @@ __device__ __forceinline__ void slab8_finish(const DeqInfo& q, const float* P, i
         int8_t w0[NG][8], w1[NG][8];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int8_t* p0 = deq_w_ptr(q, col[g], k0); const int8_t* p1 = deq_w_ptr(q, col[g], k1);
+            if (q.cbk) {                                 // k-major copy: the 8 columns are 8 consecutive bytes
+                const int2 b0 = *(const int2*)(q.cbk + (long)k0 * q.N + col[g]), b1 = *(const int2*)(q.cbk + (long)k1 * q.N + col[g]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { w0[g][j] = p0[j * ws]; w1[g][j] = p1[j * ws]; }
+                for (int j = 0; j < 8; ++j) {
+                    w0[g][j] = (int8_t)(((j < 4 ? b0.x : b0.y) >> ((j & 3) * 8)) & 0xFF);
+                    w1[g][j] = (int8_t)(((j < 4 ? b1.x : b1.y) >> ((j & 3) * 8)) & 0xFF);
+                }
+            } else {
+                const int8_t* p0 = deq_w_ptr(q, col[g], k0); const int8_t* p1 = deq_w_ptr(q, col[g], k1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { w0[g][j] = p0[j * ws]; w1[g][j] = p1[j * ws]; }
+            }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -258,9 +268,15 @@ __device__ __forceinline__ void slab8_finish(const DeqInfo& q, const float* P, i
         int8_t w0[NG][8];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int8_t* p0 = deq_w_ptr(q, col[g], k0);
+            if (q.cbk) {
+                const int2 b0 = *(const int2*)(q.cbk + (long)k0 * q.N + col[g]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w0[g][j] = p0[j * ws];
+                for (int j = 0; j < 8; ++j) w0[g][j] = (int8_t)(((j < 4 ? b0.x : b0.y) >> ((j & 3) * 8)) & 0xFF);
+            } else {
+                const int8_t* p0 = deq_w_ptr(q, col[g], k0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w0[g][j] = p0[j * ws];
+            }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g)

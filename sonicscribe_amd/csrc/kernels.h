@@ -12,6 +12,7 @@ struct DeqInfo {
     const int8_t* cb; int K;          // [N][K] row-major int8 weights
     const int8_t* cbt;                // optional fragment-tiled copy (launch_tile_weights_i8): a column gather W[:, k] touches one 64-byte
                                       // span per 16 rows there instead of one cache line per row
+    const int8_t* cbk; int N;         // optional k-major copy [K][N] (launch_transpose_i8): the gather of 8 consecutive output columns is ONE 8-byte load
     const bf16_t* x16; long ldx16;    // the GEMM's unquantised input (fp16 storage)
     const int* oc_cnt; const int* oc_list; int oc_ld;   // outlier columns per group: count [G], ascending list [G][oc_ld]
     const int* row_group; int group_div;                 // group of row r = row_group ? row_group[r / group_div] : r / group_div
@@ -166,5 +167,6 @@ void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s);
 // decode flavour: every row is its own group; one block per row
 void launch_quant_rows(const bf16_t* X, long ld, int M, int K, const QuantOut& qo, hipStream_t s);
 void launch_tile_weights_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s);
+void launch_transpose_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s);     // wt[k][n] = w[n][k]
 // int8 encoder: V columns [col0, col0 + C) of the row-major QKV matrix -> V^T [seg][C][vt_ld]
 void launch_transpose_v(const bf16_t* qkv, long ld, int col0, bf16_t* vt, int n_seg, int T, int C, int vt_ld, long vt_seg_stride, hipStream_t s);

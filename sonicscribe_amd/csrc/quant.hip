@@ -227,6 +227,21 @@ void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL(i8_outlier_side_kernel, dim3((g.M + 63) / 64, (g.N + 127) / 128), dim3(256), 0, s, a);
 }
 
+// ---------------------------------------------------------------- k-major copy of an int8 weight matrix: wt[k][n] = w[n][k]
+// (decode step: a consumer that adds a row's outlier columns needs W[:, k] for its output columns; out of the fragment-tiled copy that is one
+//  byte per 16-byte chunk - 512 HBM sectors per outlier and row - out of this copy it is 8 consecutive bytes per thread, 32 sectors)
+__global__ __launch_bounds__(256) void transpose_i8_kernel(const int8_t* w, int8_t* wt, int N, int K) {
+    __shared__ int8_t tile[64][68];
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) { const int n = n0 + i, k = k0 + tx; if (n < N && k < K) tile[i][tx] = w[(long)n * K + k]; }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) { const int k = k0 + i, n = n0 + tx; if (k < K && n < N) wt[(long)k * N + n] = tile[tx][i]; }
+}
+void launch_transpose_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_i8_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, s, w, wt, N, K);
+}
+
 // ---------------------------------------------------------------- int8 encoder: V columns of the row-major QKV matrix -> V^T [seg][C][vt_ld]
 // (the 16-bit path writes V^T from the QKV GEMM's epilogue; with the dequantisation on top that epilogue spills registers)
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* qkv, long ld, int col0, bf16_t* vt, int T, int C, int vt_ld, long vt_seg_stride) {
