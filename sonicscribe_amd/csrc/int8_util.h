@@ -101,6 +101,7 @@ __device__ __forceinline__ OutlStage outl_issue(const DeqInfo& q, int row) {
 // LDS + barrier; every thread of the block.  s_k / s_x: OUTL_CAP entries each.
 __device__ __forceinline__ void outl_commit(const DeqInfo& q, int row, const OutlStage& o, int* s_k, float* s_x) {
     const int t = threadIdx.x;
+    if (o.n <= 0) return;                              // (block-uniform: the usual case costs neither LDS traffic nor a barrier)
     if (t < OUTL_CAP) {
         const int kk = min(max(o.kk, 0), q.K - 1);
         s_k[t] = kk;
