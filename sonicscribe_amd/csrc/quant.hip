@@ -121,8 +121,57 @@ void launch_quant_act_finish(const QuantActArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(qa_lists_kernel, dim3(a.G), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qa_fix_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a);
 }
+// passes 1 + 2 in one: a row's absmax does not depend on the other rows of its group (only its OWN elements >= 6.0 are left out), so the wave
+// that read the row can quantise it at once - own outliers as 0 - and raise their flags; the columns OTHER rows flag are zeroed afterwards
+// by qa_fix, as for the rows a LayerNorm quantised.  One read of X instead of two.  NCH * 512 >= K.
+template <int NCH>
+__global__ __launch_bounds__(256) void qa_rowquant_kernel(QuantActArgs a) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int g = a.gmap ? a.gmap[m / a.gdiv] : m / a.gdiv;
+    const f16_t* xr = (const f16_t*)a.X + (long)m * a.ld;
+    unsigned char* fl = a.flags + (long)g * a.K;
+    const int nv = a.K >> 3;
+    f16x8 t[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { const int c = lane + i * 64; if (c < nv) t[i] = *(const f16x8*)(xr + c * 8); }
+    float amax = -1.17549435e-38f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + i * 64 < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float v = fabsf((float)t[i][j]); if (v < LLM_INT8_THRESHOLD) amax = fmaxf(amax, v); }
+        }
+    amax = wave_max(amax);
+    if (lane == 0) a.sca[m] = amax;
+    const float scale = 127.0f / amax;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            int pk[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)t[i][j];
+                const bool out = !(fabsf(v) < LLM_INT8_THRESHOLD);
+                if (out) fl[c * 8 + j] = 1;                       // (benign race: every writer stores the same value)
+                const int qv = (out || !(amax > 0.f)) ? 0 : (int)rintf(v * scale);
+                pk[j >> 2] |= (qv & 0xFF) << ((j & 3) * 8);
+            }
+            *(int2*)(a.q + (long)m * a.K + c * 8) = make_int2(pk[0], pk[1]);
+        }
+    }
+}
 void launch_quant_act(const QuantActArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
+    if (!getenv("SONIC_QA_3PASS") && a.K % 8 == 0 && a.K <= 12 * 512) {
+        launch_fill_i32((int*)a.flags, 0, (int)(((long)a.G * a.K + 3) / 4), s);
+        if (a.K <= 4 * 512) hipLaunchKernelGGL(qa_rowquant_kernel<4>, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(qa_rowquant_kernel<12>, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(qa_lists_kernel, dim3(a.G), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(qa_fix_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a);
+        return;
+    }
     launch_fill_i32((int*)a.flags, 0, (int)(((long)a.G * a.K + 3) / 4), s);
     hipLaunchKernelGGL(qa_stats_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qa_quant_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
