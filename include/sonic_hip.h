@@ -37,6 +37,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table (tests/test_host_logic.py checks
+ * `nm -D` against this header).  SONIC_ABI_VERSION moves whenever a signature or a struct layout below changes. */
+#define SONIC_API __attribute__((visibility("default")))
+#define SONIC_ABI_VERSION 4
+SONIC_API int sonic_abi_version(void);
+
 typedef struct sonic_engine sonic_engine;
 
 typedef enum {
@@ -78,37 +84,48 @@ typedef struct {
 } sonic_timings;
 
 /* ---- lifetime ---- */
-int sonic_device_count(void);
+SONIC_API int sonic_device_count(void);
 /* max_batch: windows per call (<= 64); max_ctx: decoder context capacity per sequence (multiple of 64). */
-int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out);
-void sonic_destroy(sonic_engine* e);
-const char* sonic_last_error(sonic_engine* e); /* e may be NULL: error of the last failed sonic_create on this thread */
+SONIC_API int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out);
+SONIC_API void sonic_destroy(sonic_engine* e);
+SONIC_API const char* sonic_last_error(sonic_engine* e); /* e may be NULL: error of the last failed sonic_create on this thread */
 /* name (NUL-terminated, truncated to name_cap), total / currently free device memory, hipRuntimeGetVersion(); any output may be NULL */
-int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_bytes, int64_t* free_bytes, int32_t* hip_runtime_version);
+SONIC_API int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_bytes, int64_t* free_bytes, int32_t* hip_runtime_version);
 /* allocated: bytes of this engine's live device allocations; reserved: allocated + the uncached blocks destroyed engines left in the
  * process-wide pool of this engine's device (sonic_destroy parks them, the next engine that needs the same size takes them) */
-int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes);
+SONIC_API int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes);
 /* frees the pooled uncached blocks of device_id (< 0: every device) after a device synchronise and a system-scope cache write-back +
  * invalidate; returns the bytes freed, 0 while an engine is still alive on the device.  The pool only holds the per-step activation
  * buffers (tens of MB per engine shape; weights and the KV cache are ordinary allocations that sonic_destroy frees), and it is NOT
  * released automatically: on this stack, memory recycled from uncached to ordinary allocations came back with stale cache lines
  * (DESIGN.md 4).  Call it only when the process will not allocate device memory again, or to measure. */
-int64_t sonic_release_pool(int device_id);
+SONIC_API int64_t sonic_release_pool(int device_id);
+
+/* Another batch in flight on the SAME weight copy.  The reference keeps up to three decodes in flight on its one model object in file
+ * mode (backend/main.py:429-445, asyncio.Semaphore(3) + run_in_executor at :616-624) and serialises them on the device; here a slot is a
+ * full engine handle of its own -- stream, PCM staging, activation buffers, KV cache, decode graphs, lock, options -- whose weight and
+ * constant pointers are the owner's (sonic_weight_bytes(owner) does not move, sonic_weight_bytes(slot) == 0).  Batches on different slots
+ * run concurrently on the GPU: one batch's MFMA-bound encoder / prefill fills the bubbles of another's latency-bound decode loop
+ * (DESIGN.md 4).  Every entry point below takes a slot handle; rings created through any handle can be staged by every slot of the same
+ * owner.  sonic_destroy(slot) releases a slot early; sonic_destroy(owner) releases its slots first (their handles are dead after that).
+ * sonic_slot_count: the owner plus its live slots. */
+SONIC_API int sonic_slot_create(sonic_engine* owner_or_slot, sonic_engine** slot_out);
+SONIC_API int sonic_slot_count(sonic_engine* e);
 
 /* ---- weights (names: GlmAsrForConditionalGeneration.state_dict() keys, see sonicscribe_amd/spec.py) ---- */
-int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
-int sonic_load_synthetic(sonic_engine* e, uint64_t seed);          /* portable generator, sonicscribe_amd/synth.py */
-int sonic_finalize_weights(sonic_engine* e);                        /* packs fused QKV / gate-up, conv im2col order */
-int64_t sonic_weight_bytes(sonic_engine* e);
+SONIC_API int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
+SONIC_API int sonic_load_synthetic(sonic_engine* e, uint64_t seed);          /* portable generator, sonicscribe_amd/synth.py */
+SONIC_API int sonic_finalize_weights(sonic_engine* e);                        /* packs fused QKV / gate-up, conv im2col order */
+SONIC_API int64_t sonic_weight_bytes(sonic_engine* e);
 
 /* ---- stage entry points (parity tests) ---- */
 /* pcm: B segments concatenated; offsets[B+1] in samples (segment i = pcm[offsets[i] .. offsets[i+1])), each <= 30 s.
  * feats_out: [B][n_mels][n_frames] fp32 (HF layout), mask_out: [B][n_frames] int32; either may be NULL. */
-int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int B, float* feats_out, int32_t* mask_out);
+SONIC_API int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int B, float* feats_out, int32_t* mask_out);
 /* feats: [B][n_mels][n_frames] fp32 (cast to bf16 as asr.py:280-301 does); n_valid_frames[B].
  * embeds_out: [B][enc_T/merge][dec_d] fp32 (first n_audio_out[b] rows valid).
  * taps (optional, may be NULL): enc_layers_out [B][enc_layers][enc_T][enc_d], enc_out [B][enc_T][enc_d]. */
-int sonic_encode(sonic_engine* e, const float* feats, const int32_t* n_valid_frames, int B,
+SONIC_API int sonic_encode(sonic_engine* e, const float* feats, const int32_t* n_valid_frames, int B,
                  float* embeds_out, int32_t* n_audio_out, float* enc_layers_out, float* enc_out);
 
 /* ---- the hot call ---- */
@@ -116,22 +133,29 @@ int sonic_encode(sonic_engine* e, const float* feats, const int32_t* n_valid_fra
  * req_win == NULL for the single-window case).  prompt_ids concatenated, prompt_off[R+1]; max_new[R].
  * out_ids: [R][out_ld] int32, out_len[R]; step_logits (optional): [max(max_new)][R][vocab] fp32 = the bf16 logits
  * each step's argmax saw (row r of step s valid while s < out_len[r]). */
-int sonic_transcribe_batch(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W,
+SONIC_API int sonic_transcribe_batch(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W,
                            const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                            const int32_t* max_new, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
 
 /* split form: stage (H2D) -> run (device only, timed) -> fetch (D2H) */
-int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W);
-int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+SONIC_API int sonic_stage_pcm(sonic_engine* e, const int16_t* pcm, const int64_t* offsets, int W);
+SONIC_API int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                      const int32_t* max_new, int want_step_logits);
-int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+SONIC_API int sonic_fetch_tokens(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
+/* sonic_run_staged without blocking the caller: the arguments are copied, a worker thread owned by the handle runs the batch, the call
+ * returns at once (the reference's counterpart is loop.run_in_executor(None, asr_model.transcribe, ...), backend/main.py:616-624).  One
+ * outstanding run per handle; until sonic_wait has returned the handle takes no other call (ring appends excepted).
+ * sonic_wait(e, 1, NULL) blocks until the run is complete and returns ITS status; sonic_wait(e, 0, &busy) polls. */
+SONIC_API int sonic_run_staged_async(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                                     const int32_t* max_new, int want_step_logits);
+SONIC_API int sonic_wait(sonic_engine* e, int block, int32_t* busy_out);
 /* stage entry points: sonic_run_staged = sonic_prefill + sonic_decode_step(max(max_new) - 1).  sonic_prefill runs log-mel, encoder,
  * projector, decoder prefill and emits the first token of every request; sonic_decode_step runs up to n_steps further greedy steps
  * (*steps_done_out of them: fewer once the largest budget is reached or every row stopped) and reports the rows still running.
  * sonic_fetch_tokens may be called after either. */
-int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+SONIC_API int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                   const int32_t* max_new, int want_step_logits);
-int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32_t* steps_done_out);
+SONIC_API int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32_t* steps_done_out);
 /* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as
  * 2048-byte chunks in a host dict (backend/audio_manager.py:21-33, fed from backend/main.py:813-842) and concatenates on the host for
  * every partial / final decode (audio_manager.py:99-123).  A decode names sample ranges of rings instead of handing over host buffers;
@@ -141,62 +165,62 @@ int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32
  * is decoding.  A ring belongs to the engine it was created on; sonic_destroy frees the rings that are still alive (their handles
  * are dead after that). */
 typedef struct sonic_ring sonic_ring;
-int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, sonic_ring** out);
-void sonic_ring_destroy(sonic_ring* r);
+SONIC_API int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, sonic_ring** out);
+SONIC_API void sonic_ring_destroy(sonic_ring* r);
 /* append n samples (any chunk size <= capacity); *first_index = absolute sample index of pcm[0].  Returns at once: the samples are
  * copied to a pinned mirror and their H2D copy is queued; decodes that name them order behind it */
-int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, int64_t* first_index);
-int64_t sonic_ring_head(sonic_ring* r);     /* samples appended so far */
+SONIC_API int sonic_ring_append(sonic_ring* r, const int16_t* pcm, int64_t n, int64_t* first_index);
+SONIC_API int64_t sonic_ring_head(sonic_ring* r);     /* samples appended so far */
 /* sonic_transcribe_batch with every window either host samples (rings == NULL or rings[w] == NULL: int16 PCM already peak-normalised,
  * host_off[W+1]; ring windows have empty host ranges) or samples [ring_start[w], ring_start[w] + ring_n[w]) of rings[w], which must
  * still be inside the ring's last `capacity` samples.  The windows of one request (req_win) share one peak.  Without req_win R == W. */
-int sonic_transcribe_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
+SONIC_API int sonic_transcribe_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
                            const int64_t* ring_start, const int32_t* ring_n, int W, const int32_t* req_win, int R,
                            const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new,
                            int32_t* out_ids, int out_ld, int32_t* out_len, float* step_logits);
 /* the staging half alone (then sonic_run_staged / sonic_fetch_tokens) */
-int sonic_stage_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
+SONIC_API int sonic_stage_mixed(sonic_engine* e, const int16_t* host_pcm, const int64_t* host_off, sonic_ring* const* rings,
                       const int64_t* ring_start, const int32_t* ring_n, int W, const int32_t* req_win, int R);
 
 /* Teacher forcing (parity tests; mirrors the oracle's force_ids): while set, token n of request r is ids[r * ld + n] instead of
  * the argmax -- logits are still computed and returned, EOS / budget rules apply to the forced token (HF:generation/utils.py:2925-2936
  * with next_tokens replaced).  ids == NULL clears.  Forced runs use the eager decode loop. */
-int sonic_set_forced_ids(sonic_engine* e, const int32_t* ids, int R, int ld);
-int sonic_get_timings(sonic_engine* e, sonic_timings* out);
-int sonic_synchronize(sonic_engine* e);
+SONIC_API int sonic_set_forced_ids(sonic_engine* e, const int32_t* ids, int R, int ld);
+SONIC_API int sonic_get_timings(sonic_engine* e, sonic_timings* out);
+SONIC_API int sonic_synchronize(sonic_engine* e);
 
 /* ---- single-kernel test hooks (host fp32 in/out, converted to bf16 on device; used by tests/ only) ---- */
-int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float* bias, const float* resid, float* C,
+SONIC_API int sonic_test_gemm(sonic_engine* e, const float* A, const float* W, const float* bias, const float* resid, float* C,
                     int M, int N, int K, int epi);
-int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K);
-int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K);
+SONIC_API int sonic_test_skinny(sonic_engine* e, const float* X, const float* W, float* C, int M, int N, int K);
+SONIC_API int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float* Wgu_interleaved, float* act, int M, int N, int K);
 /* the argmax + greedy controller on caller-provided lm_head partial slabs [ksplit][mpad][V] fp32: token picked per row
  * (first maximum of the bf16-rounded slab sum) and optionally the bf16 logits [B][V] it compared */
 /* one Linear8bitLt call (backend/asr.py:182-198: bnb.nn.Linear8bitLt(has_fp16_weights=False, threshold=6.0)) through the engine's int8
  * kernels: W [N][K] quantised row-wise on the device, X [M][K] in groups of group_rows rows (one group = one reference call), int8 MFMA
  * GEMM + dequantising epilogue epi.  fp32 buffers holding fp16 values.  Needs an engine created with SONIC_MODE_INT8. */
-int sonic_test_linear_int8(sonic_engine* e, const float* X, const float* W, const float* bias, const float* resid, float* out,
+SONIC_API int sonic_test_linear_int8(sonic_engine* e, const float* X, const float* W, const float* bias, const float* resid, float* out,
                            int M, int N, int K, int group_rows, int epi);
-int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit, int mpad, int V, int B, int32_t* tok_out, float* logits_out);
-int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
+SONIC_API int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit, int mpad, int V, int B, int32_t* tok_out, float* logits_out);
+SONIC_API int sonic_test_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
                          int B, int Tq, int Tk, int Hq, int Hkv, int hd, int causal);
-int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
+SONIC_API int sonic_test_decode_attention(sonic_engine* e, const float* q, const float* k, const float* v, float* out,
                                 int B, int Tk, int Hq, int Hkv);
-int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, int rms);
+SONIC_API int sonic_test_layernorm(sonic_engine* e, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, int rms);
 /* times `iters` launches of the encoder's dominant GEMM shape on the engine stream with HIP events */
-int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch);
+SONIC_API int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, int iters, float* ms_per_launch);
 /* times the decode-step skinny GEMM (variant: 0 LDS-DMA nt, 1 LDS-DMA default policy, 2 registers nt, 3 registers plain, 9 pure-read floor) */
-int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int iters, float* us_per_launch);
+SONIC_API int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int variant, int iters, float* us_per_launch);
 /* debug read-back of an internal bf16 activation buffer as fp32 ("prefill_tap" with index = 0 (embeddings) .. dec_layers,
  * "pe", "dx", "dqkv", "dq", "datt", "dact", "enc_x"); tests / diagnostics only */
-int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
+SONIC_API int sonic_debug_read(sonic_engine* e, const char* name, int index, float* out, int64_t n);
 /* diagnostics: in-kernel timestamps (100 MHz device wall clock) of the decode kernels of one decoder layer, recorded while the option
  * "ktrace" = layer index is set: out[slot][block < 512][8 points], slots 0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down */
-int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n);
+SONIC_API int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n);
 /* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
- * "no_graph" (eager decode loop), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
+ * "no_graph" (eager decode loop), "decode_chunk" (token steps per hipGraph launch = granularity of the early-stop check, default 4), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
  * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table) */
-int sonic_set_option(sonic_engine* e, const char* key, int value);
+SONIC_API int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,11 @@ from .engine import Engine, MODE_INT8, MODE_NATIVE, SonicError, device_count, de
 from .spec import FULL, ModelDims
 
 
+# Batches in flight per replica on ONE weight copy (engine slots, include/sonic_hip.h sonic_slot_create).  The reference's file mode keeps up to
+# three decodes in flight on its one model object (backend/main.py:429-445); here they overlap on the device instead of serialising.
+DEFAULT_SLOTS = 2
+
+
 # --------------------------------------------------------------------------------------- prompts
 class SyntheticPrompt:
     """Stand-in for the checkpoint's tokenizer + chat template (absent offline): fixed prefix / suffix ids
@@ -111,12 +116,12 @@ class AudioStream:
         self.next_chunk_id = 0
         self._oldest = 0                          # smallest chunk id still in the buffer
 
-    def add_audio_chunk(self, audio_data: bytes) -> int:
-        """audio_manager.py:21-33: store one wire chunk, return its chunk id."""
+    def add_audio_chunk(self, audio_data: bytes, timestamp: Optional[float] = None) -> int:
+        """audio_manager.py:21-33: store one wire chunk (with its arrival time, data_basic.py:11-20), return its chunk id."""
         first = self.ring.append(audio_data)
         cid = self.next_chunk_id
         self.next_chunk_id += 1
-        self._chunks[cid] = (first, len(audio_data) // 2)
+        self._chunks[cid] = (first, len(audio_data) // 2, time.time() if timestamp is None else float(timestamp))
         floor = first + len(audio_data) // 2 - self.visible           # chunks older than the buffer (audio_manager.py:35-59 drops them by age)
         while self._oldest < cid and self._chunks[self._oldest][0] < floor:
             del self._chunks[self._oldest]
@@ -126,6 +131,11 @@ class AudioStream:
     @property
     def oldest_chunk_id(self) -> int:
         return self._oldest
+
+    def chunk_timestamp(self, chunk_id: int, default: float = 0.0) -> float:
+        """arrival time of a chunk still in the buffer (AudioChunk.timestamp); `default` once it left"""
+        c = self._chunks.get(int(chunk_id))
+        return c[2] if c is not None else default
 
     def chunk_range_samples(self, start_chunk_id: int, end_chunk_id: int):
         """(first sample index, sample count) of chunks start..end inclusive, restricted to what the buffer still holds
@@ -164,8 +174,8 @@ class AudioStream:
 class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
                  cpu_threads: Optional[int] = None, cpu_interop_threads: Optional[int] = None,
-                 *, max_batch: int = 32, max_ctx: int = 1024, _dims: Optional[ModelDims] = None, _synthetic_seed: Optional[int] = None,
-                 _allow_synthetic_prompt: bool = False):
+                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, _dims: Optional[ModelDims] = None,
+                 _synthetic_seed: Optional[int] = None, _allow_synthetic_prompt: bool = False):
         if mode not in ["native", "int8"]:
             raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
         dev = str(device)
@@ -214,9 +224,11 @@ class ASRModel:
                     raise RuntimeError(f"could not load the processor / tokenizer from {self.checkpoint_dir}: {ex}") from ex
                 self.prompt = SyntheticPrompt(self.dims)
         self.model = self.models[0]                  # main.py:84-86 checks and deletes `.model`
-        self._dispatcher = Dispatcher(self.models)
+        self.slots = max(1, int(slots))
+        self._slot_engines = [[eng.slot() for _ in range(self.slots - 1)] for eng in self.models]     # same weights, further batches in flight
+        self._dispatcher = Dispatcher(self.models, slots=self._slot_engines)
         print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
-              f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s))")
+              f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s), {self.slots} batch slot(s) each)")
 
     @classmethod
     def from_synthetic(cls, dims: ModelDims = FULL, seed: int = 20260128, device: str = "cuda", mode: str = "native", **kw) -> "ASRModel":
@@ -315,7 +327,7 @@ class ASRModel:
         v = di["hip_runtime_version"]
         info.update({"cuda_version": f"HIP {v // 10000000}.{(v // 100000) % 100}.{v % 100000}", "gpu_name": di["name"],
                      "gpu_memory_total_mb": di["total_bytes"] / 1024 ** 2})
-        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])),
+        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])), "slots_per_replica": self.__dict__.get("slots", 1),
                      "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0})
         return info
 
@@ -324,8 +336,9 @@ class ASRModel:
         if c is not None:
             c.close()
         self.__dict__.pop("model", None)
+        self.__dict__.pop("_slot_engines", None)
         for m in self.__dict__.pop("models", []):
-            m.close()
+            m.close()                                # (an engine closes its slots first)
 
     def __delattr__(self, name):   # main.py:84-86 does `del asr_model.model`
         if name == "model":

@@ -284,6 +284,7 @@ void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hip
 
 // ------------------------------------------------------------------------------------------------
 
+#ifdef SONIC_AB      // A/B builds only (make SONIC_AB=1): the product library carries what runs
 // Round-2 form of the decode attention (P.V on the VALU), kept for A/B runs (option "decode_attn_v1").
 // HD = 128, group size G = Hq/Hkv <= 4.  One block (8 waves) per (sequence, kv head).
 //  0. the first 16-key slice of K and V of every wave is requested before anything else (addresses do not depend on kv_len:
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(512) void decode_attn_v1_kernel(DecodeAttnArgs a) {
     }
     KT(a, 4);
 }
+#endif
 
 // 16x16x16 MFMA on the engine's 16-bit element type (the P.V product of the decode attention: 16 keys per step)
 template <typename T> struct PV16;
@@ -705,6 +707,8 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
 }
 
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {
+#ifdef SONIC_AB
     if (g_opts.decode_attn_v1) { DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_v1_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a)); return; }
+#endif
     DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a));
 }

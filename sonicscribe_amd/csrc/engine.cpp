@@ -9,9 +9,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sonic_hip.h"
@@ -97,11 +99,24 @@ struct sonic_engine {
     int R = 0, max_steps = 0, greedy_calls = 0, steps_run = 0; bool run_logits = false;   // state of the staged batch between the stage entry points
     int* force_d = nullptr; int force_ld = 0, force_R = 0;   // teacher forcing for the next runs (sonic_set_forced_ids)
     std::vector<int> last_qlen, last_maxnew;
-    std::map<int, hipGraphExec_t> graphs;
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;        // (rows, token steps) -> captured chunk of the decode loop
+    hipEvent_t chk_ev[2]{};                                        // the pipelined early-stop check: n_active copied out behind chunk k while chunk k+1 is already queued
+
+    // Slots (sonic_slot_create): further in-flight batches on ONE weight copy.  A slot is an engine of its own in every respect - stream, activation
+    // buffers, KV cache, PCM staging, decode graphs, lock, options - except that its weight / constant pointers are the owner's.
+    sonic_engine* owner = nullptr;                                 // slot: whose weights these are (never a slot itself)
+    std::vector<sonic_engine*> slots;                              // owner: its slots (destroyed with it at the latest)
+    std::mutex rings_mu;                                           // owner: guards `rings` (the registry every slot stages from)
+
+    // sonic_run_staged_async / sonic_wait: a worker thread of the engine's own runs the batch, the caller's thread returns at once
+    struct AsyncJob { std::vector<int32_t> req_win, prompt_ids, max_new; std::vector<int64_t> prompt_off; int R = 0; bool has_rw = false; int want_logits = 0; } a_job;
+    std::thread a_thread; std::mutex a_mu; std::condition_variable a_cv;
+    bool a_started = false, a_pending = false, a_running = false, a_done = false, a_stop = false; int a_status = 0;
 
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
+    int opt_decode_chunk = 4;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
     int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
     std::vector<struct sonic_ring*> rings;          // rings created on this engine and not yet destroyed (freed with the engine at the latest)
@@ -401,6 +416,7 @@ static int build_constants(sonic_engine* e) {
 }
 
 // ------------------------------------------------------------------------------------------ create / destroy
+extern "C" int sonic_abi_version(void) { return SONIC_ABI_VERSION; }
 extern "C" int sonic_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 static int check_dims(const sonic_dims& d, int max_batch, int max_ctx, int mode) {
@@ -428,34 +444,24 @@ static int check_dims(const sonic_dims& d, int max_batch, int max_ctx, int mode)
     return SONIC_OK;
 }
 
-extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out) {
-    if (!dims || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
-    *out = nullptr;
-    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
-    g_opts = LaunchOpts{};
-    TRY(check_dims(*dims, max_batch, max_ctx, mode));
-    if (mode == SONIC_MODE_INT8 && (dims->dec_ff > 8192 || dims->enc_d % 128 || dims->enc_ff % 128 || (dims->dec_heads * dims->dec_head_dim) % 128))
-        return fail(nullptr, SONIC_ERR_INVALID, "int8 mode: dec_ff must be <= 8192 and every quantised K a multiple of 128");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SONIC_ERR_HIP, "no HIP device available");
-    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
-    sonic_engine* e = new sonic_engine();
-    e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
-    e->i8 = mode == SONIC_MODE_INT8; e->dt = e->i8 ? DT_F16 : DT_BF16;
-    auto bail = [&](int code) { g_create_err = e->err; sonic_destroy(e); return code; };
-    if (hipSetDevice(device_id) != hipSuccess) { e->err = "hipSetDevice failed"; return bail(SONIC_ERR_HIP); }
-    if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(SONIC_ERR_HIP); }
+extern "C" void sonic_destroy(sonic_engine* e);
+// Everything an engine (or a slot) owns besides weights and constants: its stream, PCM staging, activation buffers, KV cache, decode-step
+// buffers, control words, events.
+static int alloc_state(sonic_engine* e) {
+    if (hipSetDevice(e->device) != hipSuccess) { e->err = "hipSetDevice failed"; return SONIC_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return SONIC_ERR_HIP; }
     const sonic_dims& d = e->d;
+    const int Bm = e->Bm, max_batch = e->Bm, max_ctx = e->max_ctx;
     e->T = d.enc_T; e->Tp = (d.enc_T + T_PAD_ALIGN - 1) / T_PAD_ALIGN * T_PAD_ALIGN; e->Ta = d.enc_T / d.merge; e->hd_e = d.enc_d / d.enc_heads;
     e->QD = d.dec_heads * d.dec_head_dim; e->KD = d.dec_kv_heads * d.dec_head_dim; e->qkvN = e->QD + 2 * e->KD;
     // prompt tokens of one batch: at most Ta audio rows per window plus text; a long max_ctx (multi-window requests) must not
     // multiply every prefill buffer by it
     { const int per = max_ctx < e->Ta + 256 ? max_ctx : e->Ta + 256; e->tok_cap = max_batch * per; }
     e->out_cap = max_ctx;
-    const int Bm = max_batch, T = e->T, C = d.enc_d;
+    const int T = e->T, C = d.enc_d;
     const size_t Mp = (size_t)Bm * T + 128;
     int s;
-#define A(x) do { s = (x); if (s != SONIC_OK) return bail(s); } while (0)
+#define A(x) do { s = (x); if (s != SONIC_OK) return s; } while (0)
     A(dalloc(e, &e->pcm, (size_t)Bm * d.n_frames * 160)); A(dalloc(e, &e->n_samples_d, Bm)); A(dalloc(e, &e->ring_peak, Bm));
     A(dalloc(e, &e->logspec, (size_t)Bm * d.n_frames * d.n_mels)); A(dalloc(e, &e->segmax, Bm));
     A(dalloc(e, &e->feats_fm, (size_t)Bm * (d.n_frames + 2) * d.n_mels + 4096));
@@ -502,24 +508,95 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     A(dalloc(e, &e->q_off, 64)); A(dalloc(e, &e->q_len, 64)); A(dalloc(e, &e->last_row, 64));
     {
         int iota[64]; for (int i = 0; i < 64; ++i) iota[i] = i;
-        if (h2d(e, e->seq_iota, iota, sizeof iota) != hipSuccess) { e->err = "memcpy failed"; return bail(SONIC_ERR_HIP); }
+        if (h2d(e, e->seq_iota, iota, sizeof iota) != hipSuccess) { e->err = "memcpy failed"; return SONIC_ERR_HIP; }
     }
-    if (hipHostMalloc((void**)&e->n_active_h, 64, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return bail(SONIC_ERR_HIP); }
-    for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
+    if (hipHostMalloc((void**)&e->n_active_h, 64, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+    for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->gemm_ev.resize(8 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));   // per layer: [start, end] of the QKV, o, fc1, fc2 GEMM launches
-    for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return bail(SONIC_ERR_HIP); }
-    A(build_constants(e));
+    for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
 #undef A
+    for (auto& v : e->chk_ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->n_samples_h.assign(Bm, 0);
-    if (hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; return bail(SONIC_ERR_HIP); }
+    return SONIC_OK;
+}
+
+extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out) {
+    if (!dims || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
+    g_opts = LaunchOpts{};
+    TRY(check_dims(*dims, max_batch, max_ctx, mode));
+    if (mode == SONIC_MODE_INT8 && (dims->dec_ff > 8192 || dims->enc_d % 128 || dims->enc_ff % 128 || (dims->dec_heads * dims->dec_head_dim) % 128))
+        return fail(nullptr, SONIC_ERR_INVALID, "int8 mode: dec_ff must be <= 8192 and every quantised K a multiple of 128");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SONIC_ERR_HIP, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    sonic_engine* e = new sonic_engine();
+    e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
+    e->i8 = mode == SONIC_MODE_INT8; e->dt = e->i8 ? DT_F16 : DT_BF16;
+    int s = alloc_state(e);
+    if (s == SONIC_OK) s = build_constants(e);
+    if (s == SONIC_OK && hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
+    if (s != SONIC_OK) { g_create_err = e->err; sonic_destroy(e); return s; }
     { std::lock_guard<std::mutex> lk(g_uc_mu); g_live_engines[device_id] += 1; e->registered = true; }
     *out = e;
     return SONIC_OK;
 }
 
+// Another batch in flight on the SAME weights (what the reference's file mode does in spirit: backend/main.py:429-445 keeps three decodes in
+// flight on one model object).  The slot is a full engine handle - stage / run / fetch / rings / options all work on it - with its own stream,
+// activation buffers, KV cache, PCM staging and decode graphs; every weight and constant pointer is the owner's, so sonic_weight_bytes of the
+// owner does not move and the slot's is 0.  The decode loop is latency-bound: a second batch's MFMA-bound encoder / prefill and its
+// decode steps fill the bubbles of the first one's.  Slots die with their owner at the latest; sonic_destroy(slot) releases one early.
+extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
+    if (!parent || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    sonic_engine* root = parent->owner ? parent->owner : parent;
+    std::lock_guard<std::mutex> lk(root->mu);
+    (void)hipGetLastError();
+    if (!root->finalized) return fail(nullptr, SONIC_ERR_INVALID, "sonic_slot_create needs an engine whose weights are finalized");
+    g_opts = root->opts;
+    sonic_engine* e = new sonic_engine();
+    e->d = root->d; e->device = root->device; e->mode = root->mode; e->Bm = root->Bm; e->max_ctx = root->max_ctx; e->i8 = root->i8; e->dt = root->dt;
+    int s = alloc_state(e);
+    if (s == SONIC_OK && hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
+    if (s != SONIC_OK) { g_create_err = e->err; sonic_destroy(e); return s; }
+    // the owner's weights and constants, by pointer (read-only on the request path)
+    e->conv1w = root->conv1w; e->conv2w = root->conv2w; e->conv1b = root->conv1b; e->conv2b = root->conv2b;
+    e->enc = root->enc; e->enc_nw = root->enc_nw; e->enc_nb = root->enc_nb; e->gelu_lut = root->gelu_lut;
+    e->pj1w = root->pj1w; e->pj2w = root->pj2w; e->pj1b = root->pj1b; e->pj2b = root->pj2b; e->qpj1 = root->qpj1; e->qpj2 = root->qpj2;
+    e->embed = root->embed; e->embed_t = root->embed_t; e->dec = root->dec; e->dec_nw = root->dec_nw;
+    e->lc = root->lc; e->enc_cs = root->enc_cs; e->dec_cs = root->dec_cs;
+    e->opts = root->opts; e->opt_no_graph = root->opt_no_graph; e->opt_no_fused_rope = root->opt_no_fused_rope; e->opt_no_gelu_lut = root->opt_no_gelu_lut;
+    e->opt_i8_defer_thr = root->opt_i8_defer_thr; e->opt_i8_no_xq = root->opt_i8_no_xq; e->opt_i8_no_lnq = root->opt_i8_no_lnq; e->opt_i8_no_qkv_fuse = root->opt_i8_no_qkv_fuse;
+    e->opt_decode_chunk = root->opt_decode_chunk;
+    e->weight_bytes = 0; e->finalized = true; e->owner = root;
+    root->slots.push_back(e);
+    { std::lock_guard<std::mutex> lk2(g_uc_mu); g_live_engines[e->device] += 1; e->registered = true; }
+    *out = e;
+    return SONIC_OK;
+}
+extern "C" int sonic_slot_count(sonic_engine* e) {
+    if (!e) return 0;
+    sonic_engine* root = e->owner ? e->owner : e;
+    std::lock_guard<std::mutex> lk(root->mu);
+    return 1 + (int)root->slots.size();
+}
+
 static void ring_free(struct sonic_ring* r);
+static void async_shutdown(sonic_engine* e);
 extern "C" void sonic_destroy(sonic_engine* e) {
     if (!e) return;
+    async_shutdown(e);                                   // the worker of sonic_run_staged_async finishes its batch and exits
+    if (e->owner) {                                      // a slot leaves its owner's list (under the owner's lock: sonic_slot_create / sonic_slot_count walk it)
+        std::lock_guard<std::mutex> lk(e->owner->mu);
+        auto& v = e->owner->slots;
+        v.erase(std::remove(v.begin(), v.end(), e), v.end());
+    } else {
+        std::vector<sonic_engine*> kids;
+        { std::lock_guard<std::mutex> lk(e->mu); kids.swap(e->slots); }
+        for (sonic_engine* k : kids) { k->owner = nullptr; k->finalized = false; sonic_destroy(k); }   // slots first: they read this engine's weights
+    }
     (void)hipSetDevice(e->device);
     if (e->st) (void)hipStreamSynchronize(e->st);
     for (sonic_ring* r : e->rings) ring_free(r);       // rings the caller left behind go with their engine
@@ -535,6 +612,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->feats_f32) (void)hipFree(e->feats_f32);
     if (e->n_active_h) (void)hipHostFree(e->n_active_h);
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
+    for (auto& v : e->chk_ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
     if (e->st) (void)hipStreamDestroy(e->st);
     const int dev = e->device;
@@ -1075,7 +1153,7 @@ static void decode_step_i8(sonic_engine* e, int R, bool dump) {
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         // o_proj's input rows are spread over the attention blocks of 4 kv heads: they gather the row absmax (atomicMax), o_proj quantises on the
         // fly and its consumer lists the outliers itself - no one-block-per-row quantisation launch in between (option i8_no_xq: the round-2 form)
-        const bool xq = !e->opt_i8_no_xq;
+        const bool xq = !e->opt_i8_no_xq && d.dec_kv_heads <= 4 && !e->opts.decode_attn_v1;   // the partials are [64][4]: one per kv-head block
         if (xq) { da.amax_out = e->amax_att; da.big_out = e->big_att; }
         launch_decode_attn(da, R, e->st);
         DeqInfo dq;
@@ -1246,37 +1324,62 @@ static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, co
     return SONIC_OK;
 }
 
-// up to n_steps further token steps of the staged batch: hipGraph replay of one captured step (eager under teacher forcing / when the
-// step logits are wanted).  Stops early once every row hit EOS / its budget (checked every 16 steps, as the free-running loop always did).
+// A captured chunk of the greedy loop: `n` token steps for `R` rows as ONE hipGraph (kv_len / tok_pos / the token ids live on the device, so
+// the steps of a chunk need nothing from the host).
+static int chunk_graph(sonic_engine* e, int R, int n, hipGraphExec_t* out) {
+    auto it = e->graphs.find({R, n});
+    if (it != e->graphs.end()) { *out = it->second; return SONIC_OK; }
+    hipGraph_t g = nullptr; hipGraphExec_t gx = nullptr;
+    HIPC(e, hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < n; ++i) decode_step(e, R, false);
+    HIPC(e, hipStreamEndCapture(e->st, &g));
+    hipError_t r = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPC(e, r);
+    e->graphs[{R, n}] = gx;
+    *out = gx;
+    return SONIC_OK;
+}
+
+// up to n_steps further token steps of the staged batch (HF:generation/utils.py:2876-2943), in chunks of `decode_chunk` steps: one hipGraph
+// launch per chunk (eager under teacher forcing / when the step logits are wanted).  Ragged termination: behind every chunk the device's
+// count of running rows is copied to pinned memory; the host reads the copy of chunk k only after it has queued chunk k+1, so the stream
+// never runs dry while the host looks (a host that is late by less than a chunk costs nothing), and the loop stops one chunk after every row
+// hit EOS / its budget (finished rows are frozen: the extra steps rewrite their own cache slot and emit nothing).
 static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
     const int R = e->R, left = e->max_steps - 1 - e->steps_run;
     if (n_steps > left) n_steps = left;
     const bool want_logits = e->run_logits;
     const bool use_graph = !want_logits && !e->opt_no_graph && !e->force_d;
-    hipGraphExec_t gx = nullptr;
-    if (use_graph && n_steps > 0) {
-        auto it = e->graphs.find(R);
-        if (it == e->graphs.end()) {
-            hipGraph_t g = nullptr;
-            HIPC(e, hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
-            decode_step(e, R, false);
-            HIPC(e, hipStreamEndCapture(e->st, &g));
-            HIPC(e, hipGraphInstantiate(&gx, g, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(g);
-            e->graphs[R] = gx;
-        } else gx = it->second;
-    }
-    int done = 0;
-    for (int i = 0; i < n_steps; ++i) {
-        const int s = e->steps_run + 1;                  // index of the token this step produces (token 0 came out of prefill)
-        if (gx) HIPC(e, hipGraphLaunch(gx, e->st)); else decode_step(e, R, want_logits);
-        ++done; ++e->steps_run; ++e->greedy_calls;
-        if ((s & 15) == 0 && s + 1 < e->max_steps) {   // ragged termination: stop once every row hit EOS / its budget
-            HIPC(e, hipMemcpyAsync(e->n_active_h, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
-            HIPC(e, hipStreamSynchronize(e->st));
-            if (*e->n_active_h <= 0) { e->steps_run = e->max_steps - 1; break; }
+    const int C = e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1;
+    int done = 0, slot = 0, prev = -1;
+    bool all_stopped = false;
+    while (done < n_steps && !all_stopped) {
+        const int n = n_steps - done < C ? n_steps - done : C;
+        if (use_graph) {
+            hipGraphExec_t gx = nullptr;
+            TRY(chunk_graph(e, R, n, &gx));
+            HIPC(e, hipGraphLaunch(gx, e->st));
+        } else {
+            for (int i = 0; i < n; ++i) decode_step(e, R, want_logits);
+        }
+        done += n; e->steps_run += n; e->greedy_calls += n;
+        if (e->steps_run + 1 < e->max_steps) {                 // more steps may follow (in this call or the next): leave a check behind this chunk
+            HIPC(e, hipMemcpyAsync(e->n_active_h + slot, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+            HIPC(e, hipEventRecord(e->chk_ev[slot], e->st));
+            if (prev >= 0) {
+                HIPC(e, hipEventSynchronize(e->chk_ev[prev]));
+                if (e->n_active_h[prev] <= 0) all_stopped = true;
+            }
+            prev = slot; slot ^= 1;
         }
     }
+    if (!all_stopped && prev >= 0 && done >= n_steps && e->steps_run + 1 < e->max_steps) {
+        // the caller asked for fewer steps than the budget (sonic_decode_step): its own synchronise follows, look at the last check now
+        HIPC(e, hipEventSynchronize(e->chk_ev[prev]));
+        if (e->n_active_h[prev] <= 0) all_stopped = true;
+    }
+    if (all_stopped) e->steps_run = e->max_steps - 1;
     if (done_out) *done_out = done;
     return SONIC_OK;
 }
@@ -1360,7 +1463,10 @@ extern "C" int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, soni
     }
     zero_fill(e, r->buf, (size_t)capacity_samples * 2);
     HIPC(e, hipStreamSynchronize(e->st));
-    e->rings.push_back(r);
+    // rings live in the registry of the weight owner: every slot of an engine may stage from every ring of it
+    sonic_engine* root = e->owner ? e->owner : e;
+    r->e = root;
+    { std::lock_guard<std::mutex> rl(root->rings_mu); root->rings.push_back(r); }
     *out = r;
     return SONIC_OK;
 }
@@ -1376,7 +1482,9 @@ static void ring_free(sonic_ring* r) {
 extern "C" void sonic_ring_destroy(sonic_ring* r) {
     if (!r) return;
     {
-        std::lock_guard<std::mutex> lk(r->e->mu);      // (not while a batch that may be staging from this ring holds the engine)
+        // Unregister first: a batch that names this ring from now on is refused (stage_mixed_locked looks the pointer up under the same lock
+        // before it touches it); a batch that already holds the ring's lock finishes its staging kernels before ring_free gets the lock.
+        std::lock_guard<std::mutex> lk(r->e->rings_mu);
         auto& v = r->e->rings;
         v.erase(std::remove(v.begin(), v.end(), r), v.end());
     }
@@ -1439,15 +1547,20 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
     // every ring of the batch stays locked from the range check until the staging kernels have run (this function ends with a stream
     // synchronise): an append in between could overwrite the oldest samples of a window that starts at the tail of its ring
     std::vector<sonic_ring*> used;
-    if (rings)
+    std::vector<std::unique_lock<std::mutex>> held;
+    if (rings) {
+        sonic_engine* root = e->owner ? e->owner : e;
+        std::lock_guard<std::mutex> rl(root->rings_mu);        // registry lookup + ring locks as one step against sonic_ring_destroy
         for (int w = 0; w < W; ++w)
             if (rings[w] && std::find(used.begin(), used.end(), rings[w]) == used.end()) {
-                if (rings[w]->e != e) return fail(e, SONIC_ERR_INVALID, "window %d: ring belongs to another engine", w);
+                if (std::find(root->rings.begin(), root->rings.end(), rings[w]) == root->rings.end())
+                    return fail(e, SONIC_ERR_INVALID, "window %d: ring belongs to another engine (or was destroyed)", w);
                 used.push_back(rings[w]);
             }
-    std::vector<std::unique_lock<std::mutex>> held;
-    held.reserve(used.size());
-    for (sonic_ring* rg : used) held.emplace_back(rg->mu);
+        std::sort(used.begin(), used.end());                   // one lock order for every batch (two slots may stage from overlapping ring sets)
+        held.reserve(used.size());
+        for (sonic_ring* rg : used) held.emplace_back(rg->mu);
+    }
     for (int r = 0, w = 0; r < R; ++r) {
         const int w1 = req_win ? req_win[r + 1] : r + 1;
         if (w1 <= w) return fail(e, SONIC_ERR_INVALID, "request %d has no window", r);
@@ -1514,6 +1627,71 @@ extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, 
     if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
     ENTER(e);
     return run_all(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0);
+}
+
+// ---- asynchronous form: the batch runs on a worker thread of the engine's own; the caller's thread returns at once and may drive other slots.
+// One job per engine (slot) at a time; between sonic_run_staged_async and sonic_wait the handle takes no other call except ring appends.
+static int run_staged_entry(sonic_engine* e) {
+    const sonic_engine::AsyncJob& j = e->a_job;
+    ENTER(e);
+    return run_all(e, j.has_rw ? j.req_win.data() : nullptr, j.R, j.prompt_ids.data(), j.prompt_off.data(), j.max_new.data(), j.want_logits != 0);
+}
+static void async_loop(sonic_engine* e) {
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(e->a_mu);
+            e->a_cv.wait(lk, [&] { return e->a_pending || e->a_stop; });
+            if (!e->a_pending) return;                       // (a pending job still runs before the thread leaves)
+            e->a_pending = false; e->a_running = true;
+        }
+        const int st = run_staged_entry(e);
+        {
+            std::lock_guard<std::mutex> lk(e->a_mu);
+            e->a_status = st; e->a_running = false; e->a_done = true;
+        }
+        e->a_cv.notify_all();
+    }
+}
+static void async_shutdown(sonic_engine* e) {
+    {
+        std::lock_guard<std::mutex> lk(e->a_mu);
+        if (!e->a_started) return;
+        e->a_stop = true;
+    }
+    e->a_cv.notify_all();
+    if (e->a_thread.joinable()) e->a_thread.join();
+}
+extern "C" int sonic_run_staged_async(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
+                                      const int32_t* max_new, int want_step_logits) {
+    if (!e || !prompt_ids || !prompt_off || !max_new || R < 1 || R > 64) return SONIC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->a_mu);
+    if (e->a_stop) return SONIC_ERR_INVALID;
+    if (e->a_pending || e->a_running || e->a_done) {         // (e->err belongs to the engine lock; report through the creating thread's slot)
+        return fail(nullptr, SONIC_ERR_INVALID, "sonic_run_staged_async: the previous asynchronous run of this handle has not been waited for (sonic_wait)");
+    }
+    sonic_engine::AsyncJob& j = e->a_job;
+    j.R = R; j.want_logits = want_step_logits; j.has_rw = req_win != nullptr;
+    j.req_win.assign(req_win ? req_win : nullptr, req_win ? req_win + R + 1 : nullptr);
+    j.prompt_off.assign(prompt_off, prompt_off + R + 1);
+    if (prompt_off[0] != 0 || prompt_off[R] < prompt_off[0]) return fail(nullptr, SONIC_ERR_INVALID, "sonic_run_staged_async: prompt_off must start at 0 and ascend");
+    j.prompt_ids.assign(prompt_ids, prompt_ids + prompt_off[R]);
+    j.max_new.assign(max_new, max_new + R);
+    if (!e->a_started) { e->a_thread = std::thread(async_loop, e); e->a_started = true; }
+    e->a_pending = true;
+    e->a_cv.notify_all();
+    return SONIC_OK;
+}
+// blocks until the asynchronous run of this handle is complete and returns ITS status (sonic_last_error(e) has the text); SONIC_OK at once when
+// nothing is outstanding.  *busy_out (optional, with block == 0): 1 while the run is still going, and the call returns SONIC_OK without waiting.
+extern "C" int sonic_wait(sonic_engine* e, int block, int32_t* busy_out) {
+    if (!e) return SONIC_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(e->a_mu);
+    if (busy_out) *busy_out = 0;
+    if (!e->a_pending && !e->a_running && !e->a_done) return SONIC_OK;
+    if (!block && !e->a_done) { if (busy_out) *busy_out = 1; return SONIC_OK; }
+    e->a_cv.wait(lk, [&] { return e->a_done; });
+    e->a_done = false;
+    return e->a_status;
 }
 
 // Stage entry points: the two halves of sonic_run_staged.  sonic_prefill = log-mel, encoder, projector, decoder prefill
@@ -1910,6 +2088,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
+    if (!strcmp(key, "decode_chunk")) { e->opt_decode_chunk = value > 0 ? (value > 64 ? 64 : value) : 1; return SONIC_OK; }   // token steps per graph launch / early-stop check
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
     if (!strcmp(key, "no_fused_rope")) { e->opt_no_fused_rope = value; return SONIC_OK; }  // encoder RoPE as its own pass (A/B against the fused epilogue)
     if (!strcmp(key, "ktrace")) {              // diagnostics: record in-kernel timestamps of decoder layer `value` (-1: off); sonic_debug_ktrace reads them

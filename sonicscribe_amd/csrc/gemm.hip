@@ -247,8 +247,10 @@ static int device_cus() {
 }
 // the 256x256 tile: persistent kernel for the 16-bit kinds (gemm256p.hip), one launch per tile round otherwise (int8 kinds, batched conv stem)
 static void launch_tile256(const GemmArgs& a, int epi, hipStream_t s) {
-    if (!a.q.sca && a.batch <= 1 && g_opts.gemm256_persist) launch_gemm256p(a, epi, device_cus(), s);
-    else launch_gemm256(a, epi, s);
+#ifdef SONIC_AB      // the persistent form lost every A/B: it ships only in `make SONIC_AB=1` builds
+    if (!a.q.sca && a.batch <= 1 && g_opts.gemm256_persist) { launch_gemm256p(a, epi, device_cus(), s); return; }
+#endif
+    launch_gemm256(a, epi, s);
 }
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     if (!g_opts.gemm_force128 && gemm256_eligible(a, epi)) {

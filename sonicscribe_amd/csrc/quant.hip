@@ -195,7 +195,7 @@ struct OutlierSideArgs {
     const int8_t* cb; const float* scb;      // weights [N][K] row-wise int8 + row absmax
     const f16_t* tmp; const f16_t* R; long ldr; f16_t* C; long ldc;   // v in, residual in, out (tmp has C's pitch)
     const int* oc_cnt; const int* oc_list; int oc_ld, thr;
-    const int* row_group; int group_div;
+    const int* row_group; int group_div; int row_off;     // group of row m = row_group[(m + row_off) / group_div], as the GEMM's epilogue (int8_util.h i8_row)
     int M, N, K;
 };
 __global__ __launch_bounds__(256) void i8_outlier_side_kernel(OutlierSideArgs a) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void i8_outlier_side_kernel(OutlierSideArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int m0 = blockIdx.x * RM, n0 = blockIdx.y * RN;
     const int mlast = min(m0 + RM, a.M) - 1;
-    auto group_of = [&](int m) { return a.row_group ? a.row_group[m / a.group_div] : m / a.group_div; };
+    auto group_of = [&](int m) { return a.row_group ? a.row_group[(m + a.row_off) / a.group_div] : (m + a.row_off) / a.group_div; };
     const int g_first = group_of(m0), g_last = group_of(mlast);     // group ids do not decrease with the row
     for (int g = g_first; g <= g_last; ++g) {
         const int cnt = a.oc_cnt[g];
@@ -272,7 +272,7 @@ void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s) {
     a.x16 = (const f16_t*)g.q.x16; a.ldx = g.q.ldx16; a.cb = (const int8_t*)g.W; a.scb = g.q.scb;
     a.tmp = (const f16_t*)g.q.defer_out; a.R = (const f16_t*)g.R; a.ldr = g.ldr; a.C = (f16_t*)g.C; a.ldc = g.ldc;
     a.oc_cnt = g.q.oc_cnt; a.oc_list = g.q.oc_list; a.oc_ld = g.q.oc_ld; a.thr = g.q.defer_thr;
-    a.row_group = g.q.row_group; a.group_div = g.q.group_div; a.M = g.M; a.N = g.N; a.K = g.K;
+    a.row_group = g.q.row_group; a.group_div = g.q.group_div; a.row_off = g.q.row_off; a.M = g.M; a.N = g.N; a.K = g.K;
     hipLaunchKernelGGL(i8_outlier_side_kernel, dim3((g.M + 63) / 64, (g.N + 127) / 128), dim3(256), 0, s, a);
 }
 

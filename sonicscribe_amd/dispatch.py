@@ -15,6 +15,12 @@ has a worker thread that drains its queue into device batches:
     that replica's backlog exceeds the least-loaded one's by more than a batch, then it is rebalanced; keyless requests (file mode:
     independent segments) go to the least-loaded replica.  Segments are independent: no collective, no cross-replica state.
 
+Slots: a replica may hold several engine handles that share ONE weight copy (Engine.slot(), sonic_slot_create) - one worker thread per
+slot, all draining the replica's single queue.  While slot 0's batch is in its latency-bound decode loop, slot 1 takes the next batch
+and its MFMA-bound encoder / prefill (and later its decode steps) fill the first one's bubbles; the reference does the same in spirit
+in file mode (backend/main.py:429-445: three decodes in flight on one model object).  Batch formation is unchanged: whichever slot is
+free takes the oldest request and everything of its step class that fits.
+
 A window is either host PCM or a slice of a session's device ring (engine.RingSlice); ring requests are pinned to the
 replica that owns the ring.  Engines are duck-typed (`max_batch`, `transcribe_batch(segs, prompts, max_new, req_win=...)`) so the dispatcher is testable on CPU
 with stub engines; ctypes releases the GIL inside the real engine call, so G worker threads drive G GPUs concurrently.
@@ -48,15 +54,21 @@ class Request:
 
 
 class _Replica:
-    def __init__(self, engine, index: int):
+    def __init__(self, engine, index: int, slots: Sequence[Any] = ()):
         self.engine, self.index = engine, index
+        self.engines = [engine] + list(slots)      # slot handles share engine's weights; each gets its own worker thread
         self.q: List[Request] = []
         self.cv = threading.Condition()
         self.stop = False
-        self.busy_windows = 0            # windows of the batch on the device right now
+        self.busy = [0] * len(self.engines)        # windows of the batch each slot has on the device right now
         self.batches = 0
-        self.thread = threading.Thread(target=self._loop, name=f"sonic-replica-{index}", daemon=True)
-        self.thread.start()
+        self.threads = [threading.Thread(target=self._loop, args=(k,), name=f"sonic-replica-{index}.{k}", daemon=True) for k in range(len(self.engines))]
+        for t in self.threads:
+            t.start()
+
+    @property
+    def busy_windows(self) -> int:
+        return sum(self.busy)
 
     def load(self) -> int:
         with self.cv:
@@ -69,7 +81,7 @@ class _Replica:
             self.q.append(req)
             self.cv.notify()
 
-    def _take(self) -> List[Request]:
+    def _take(self, k: int = 0) -> List[Request]:
         with self.cv:
             while not self.q and not self.stop:
                 self.cv.wait()
@@ -92,7 +104,9 @@ class _Replica:
                 else:
                     rest.append(r)
             self.q = rest
-            self.busy_windows = used
+            self.busy[k] = used
+            if rest:
+                self.cv.notify()                 # what did not fit (or is of another step class) is for the next free slot
             return batch
 
     @staticmethod
@@ -104,20 +118,21 @@ class _Replica:
         else:
             r.future.set_result(result)
 
-    def _run(self, batch: List[Request]):
+    def _run(self, batch: List[Request], k: int = 0):
+        engine = self.engines[k]
         segs, req_win = [], [0]
         for r in batch:
             segs.extend(r.windows)
             req_win.append(len(segs))
         try:
-            ids, _ = self.engine.transcribe_batch(segs, [r.prompt for r in batch], [r.max_new for r in batch], req_win=req_win)
+            ids, _ = engine.transcribe_batch(segs, [r.prompt for r in batch], [r.max_new for r in batch], req_win=req_win)
         except BaseException as ex:              # a per-request validation error must not poison its neighbours: retry one by one
             if len(batch) == 1:
                 self._finish(batch[0], error=ex)
                 return
             for r in batch:
                 try:
-                    one, _ = self.engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
+                    one, _ = engine.transcribe_batch(r.windows, [r.prompt], [r.max_new], req_win=[0, len(r.windows)])
                 except BaseException as ex2:
                     self._finish(r, error=ex2)
                 else:
@@ -126,14 +141,15 @@ class _Replica:
         for r, i in zip(batch, ids):             # futures complete outside the engine's try block: a callback's error is not an engine error
             self._finish(r, i)
 
-    def _loop(self):
+    def _loop(self, k: int = 0):
         while True:
             batch: List[Request] = []
             try:
-                batch = self._take()
+                batch = self._take(k)
                 if batch:
-                    self.batches += 1            # (counted before the futures complete: a waiter may read it right after its result)
-                    self._run(batch)
+                    with self.cv:
+                        self.batches += 1        # (counted before the futures complete: a waiter may read it right after its result)
+                    self._run(batch, k)
             except BaseException as ex:          # the worker must not die silently: its queue would hang forever
                 for r in batch:
                     try:
@@ -142,7 +158,7 @@ class _Replica:
                         pass
             finally:
                 with self.cv:
-                    self.busy_windows = 0
+                    self.busy[k] = 0
             if not batch and self.stop and not self.q:
                 return
 
@@ -150,17 +166,19 @@ class _Replica:
         with self.cv:
             self.stop = True
             self.cv.notify_all()
-        self.thread.join(timeout=30)
+        for t in self.threads:
+            t.join(timeout=30)
         for r in self.q:
             if not r.future.done():
                 r.future.set_exception(RuntimeError("ASR engine is closed"))
 
 
 class Dispatcher:
-    def __init__(self, engines: Sequence[Any]):
+    def __init__(self, engines: Sequence[Any], slots: Optional[Sequence[Sequence[Any]]] = None):
+        """engines: one per replica (its own weights).  slots[i]: further engine handles that share replica i's weights (Engine.slot())."""
         if not engines:
             raise ValueError("at least one engine")
-        self.replicas = [_Replica(e, i) for i, e in enumerate(engines)]
+        self.replicas = [_Replica(e, i, slots[i] if slots else ()) for i, e in enumerate(engines)]
 
     def __len__(self):
         return len(self.replicas)

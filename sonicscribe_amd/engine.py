@@ -29,7 +29,9 @@ EXPORTS = [
     "sonic_set_forced_ids", "sonic_test_greedy", "sonic_test_linear_int8",
     "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
     "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info", "sonic_release_pool",
+    "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
 ]
+ABI_VERSION = 4
 
 
 class SonicDims(C.Structure):
@@ -128,8 +130,14 @@ def load_library():
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.sonic_test_linear_int8.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.sonic_slot_create.argtypes = [vp, C.POINTER(vp)]
+    lib.sonic_slot_count.argtypes = [vp]
+    lib.sonic_run_staged_async.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
+    lib.sonic_wait.argtypes = [vp, C.c_int, ip]
     for name in EXPORTS:
         getattr(lib, name)
+    if lib.sonic_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"sonicscribe_amd: {LIB_PATH} has ABI version {lib.sonic_abi_version()}, this binding expects {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 
@@ -198,19 +206,39 @@ class Ring:
 class Engine:
     """One model replica on one MI355X."""
 
-    def __init__(self, dims: ModelDims, device_id: int = 0, mode: int = MODE_NATIVE, max_batch: int = 32, max_ctx: int = 1024):
+    def __init__(self, dims: ModelDims, device_id: int = 0, mode: int = MODE_NATIVE, max_batch: int = 32, max_ctx: int = 1024, _slot_of: Optional["Engine"] = None):
         self.lib = load_library()
         self.dims = dims
         self.max_batch, self.max_ctx = max_batch, max_ctx
         self._cd = make_dims(dims)
+        self.owner: Optional["Engine"] = _slot_of       # a slot keeps its weight owner alive
+        self._slots: List["Engine"] = []
         h = C.c_void_p()
-        rc = self.lib.sonic_create(C.byref(self._cd), device_id, mode, max_batch, max_ctx, C.byref(h))
+        if _slot_of is not None:
+            rc = self.lib.sonic_slot_create(_slot_of.h, C.byref(h))
+        else:
+            rc = self.lib.sonic_create(C.byref(self._cd), device_id, mode, max_batch, max_ctx, C.byref(h))
         if rc != 0:
             msg = (self.lib.sonic_last_error(None) or b"").decode()
             if rc == SONIC_ERR_UNSUPPORTED:
                 raise ImportError(msg)
             raise (ValueError if "mode must be" in msg else SonicError)(msg)
         self.h = h
+
+    @property
+    def root(self) -> "Engine":
+        return self.owner if self.owner is not None else self
+
+    def slot(self) -> "Engine":
+        """Another batch in flight on this engine's weights (sonic_slot_create): an Engine of its own in every respect - stream, buffers,
+        KV cache, graphs, lock - that shares the owner's weight allocations.  Closed with its owner at the latest."""
+        root = self.root
+        s = Engine(self.dims, 0, 0, self.max_batch, self.max_ctx, _slot_of=root)
+        root._slots.append(s)
+        return s
+
+    def slot_count(self) -> int:
+        return int(self.lib.sonic_slot_count(self.h))
 
     # -- plumbing
     def _check(self, rc: int):
@@ -222,10 +250,14 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for s in list(self._slots):                      # slots read this engine's weights: they go first
+                s.close()
             for r in list(getattr(self, "_rings", ())):      # rings belong to their engine and go first
                 r.close()
             self.lib.sonic_destroy(self.h)
             self.h = None
+            if self.owner is not None and self in self.owner._slots:
+                self.owner._slots.remove(self)
 
     def ring_create(self, capacity_samples: int) -> "Ring":
         """Device-resident PCM ring of one streaming session (include/sonic_hip.h sonic_ring_*)."""
@@ -314,8 +346,8 @@ class Engine:
         start = np.array([s.start if isinstance(s, RingSlice) else 0 for s in segments], np.int64)
         n = np.array([s.n if isinstance(s, RingSlice) else 0 for s in segments], np.int32)
         for s in segments:
-            if isinstance(s, RingSlice) and s.ring.engine is not self:
-                raise ValueError("a ring slice can only be decoded by the engine that owns the ring")
+            if isinstance(s, RingSlice) and s.ring.engine.root is not self.root:
+                raise ValueError("a ring slice can only be decoded by the engine that owns the ring (or by a slot of it)")
         return pcm, offs, rings, start, n
 
     def transcribe_batch(self, segments: Sequence[Any], prompts: Sequence[Sequence[int]], max_new: Sequence[int],
@@ -389,6 +421,26 @@ class Engine:
         """Repeat the last run_staged call without re-packing (benchmark inner loop)."""
         ids, poffs, mn, rw = self._run_cache
         self._check(self.lib.sonic_run_staged(self.h, _p(rw), len(mn), _p(ids), _p(poffs), _p(mn), 0))
+
+    def run_staged_async(self, prompts: Optional[Sequence[Sequence[int]]] = None, max_new: Optional[Sequence[int]] = None,
+                         req_win: Optional[Sequence[int]] = None):
+        """sonic_run_staged_async: returns at once, a worker thread of the handle runs the batch; wait() collects its status.
+        Without arguments: the arguments of the last run_staged call."""
+        if prompts is not None:
+            ids, poffs = self._pack_prompts(prompts)
+            mn = np.ascontiguousarray(max_new, dtype=np.int32)
+            rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+            self._run_cache = (ids, poffs, mn, rw)
+        ids, poffs, mn, rw = self._run_cache
+        rc = self.lib.sonic_run_staged_async(self.h, _p(rw), len(mn), _p(ids), _p(poffs), _p(mn), 0)
+        if rc != 0:
+            raise SonicError((self.lib.sonic_last_error(None) or b"").decode() or f"sonic_run_staged_async failed with status {rc}")
+
+    def wait(self, block: bool = True) -> bool:
+        """Collect the asynchronous run (raises its error).  block=False: returns False while it is still running."""
+        busy = C.c_int32(0)
+        self._check(self.lib.sonic_wait(self.h, int(block), C.byref(busy)))
+        return not busy.value
 
     def fetch_tokens(self, R: int, out_ld: int):
         out = np.zeros((R, out_ld), np.int32)

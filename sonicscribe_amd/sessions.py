@@ -17,7 +17,6 @@ reference: its weights are not available offline).
 from __future__ import annotations
 
 import time
-from collections import deque
 from concurrent.futures import Future
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -43,20 +42,34 @@ class GatedSessions:
         n = len(self.ids)
         self.streams = [model.open_stream(s, buffer_seconds) for s in self.ids]
         self.gate = BatchedVADGate(n, cfg)
-        self.recent: List[deque] = [deque(maxlen=cfg.window + cfg.smoothing + 2) for _ in range(n)]   # (chunk id, bytes): what the VAD needs
+        # chunk id -> bytes: what the VAD windows are cut from.  The reference keeps the AudioChunk OBJECTS in chunk_accumulator
+        # (vad_processor_manager.py:64-66,85-86), so a window always has its audio however slowly the loop ticks; here a chunk's bytes stay
+        # until the gate's accumulator no longer names its id (pruned in tick()).
+        self.recent: List[Dict[int, bytes]] = [dict() for _ in range(n)]
         self.segment_start = np.full(n, -1, np.int64)     # current_segment.start_chunk_id (-1: none)
+        self.segment_start_time = np.zeros(n, np.float64)  # current_segment.start_time = arrival time of that chunk (connection_manager.py:69-72)
         self.last_partial = np.zeros(n, np.float64)
         self.sr = model.target_sr
 
-    def add_audio_chunk(self, s: int, audio_data: bytes) -> int:
-        """main.py:813-842 -> connection_manager.py:108-125: one wire chunk of session s."""
-        cid = self.streams[s].add_audio_chunk(audio_data)
-        self.recent[s].append((cid, audio_data))
+    def add_audio_chunk(self, s: int, audio_data: bytes, timestamp: Optional[float] = None) -> int:
+        """main.py:813-842 -> connection_manager.py:108-125: one wire chunk of session s (timestamp: its arrival time, data_basic.py:11-20)."""
+        cid = self.streams[s].add_audio_chunk(audio_data, timestamp)
+        self.recent[s][cid] = audio_data
         return cid
 
     def _window_pcm(self, s: int, ids: np.ndarray) -> np.ndarray:
-        have = dict(self.recent[s])
+        have = self.recent[s]
         return np.frombuffer(b"".join(have.get(int(c), b"") for c in ids), dtype=np.int16)
+
+    def _prune_recent(self):
+        """drop the bytes of chunks that neither the gate's accumulator names nor the next look-back can offer again"""
+        g = self.gate
+        for s, have in enumerate(self.recent):
+            floor = self.streams[s].next_chunk_id - self.cfg.smoothing
+            if g.acc_len[s] > 0:
+                floor = min(floor, int(g.acc[s, :g.acc_len[s]].min()))
+            for c in [c for c in have if c < floor]:
+                del have[c]
 
     def tick(self, vad: Callable[[np.ndarray, List[np.ndarray], np.ndarray], np.ndarray], now: Optional[float] = None) -> List[Dict]:
         """One pass of every session's vad_loop body.  Returns the events of this tick: dicts with `session`, `type` in
@@ -74,12 +87,14 @@ class GatedSessions:
             valid[rows] = [len(p) > 0 for p in pcm]
             sp[rows] = np.asarray(vad(rows, pcm, thr[rows]), bool)
         changed, start_id, end_id = self.gate.decide(ready, sp, valid)
+        self._prune_recent()
         events: List[Dict] = []
         for s in np.nonzero(changed)[0]:
             s = int(s)
             st = self.streams[s]
             if start_id[s] >= 0:                                          # create_speech_segment (connection_manager.py:66-72)
                 self.segment_start[s] = start_id[s]
+                self.segment_start_time[s] = st.chunk_timestamp(int(start_id[s]), now)
                 events.append({"session": self.ids[s], "type": "speech_start", "start_chunk_id": int(start_id[s])})
             if end_id[s] >= 0 and self.segment_start[s] >= 0:             # finalize_current_segment + committed transcription (:74-84)
                 seg0, self.segment_start[s] = int(self.segment_start[s]), -1
@@ -109,8 +124,15 @@ class GatedSessions:
             return []
         out = []
         piece = int(MAX_SEGMENT_S * self.sr)
+        # segment_duration = min(actual_duration, segment.duration): the timestamp span start chunk -> speech_end_id chunk bounds both the
+        # split test and the unsplit request's token budget (connection_manager.py:186-192); the audio itself runs to the NEWEST chunk
+        seg_dur = min(ns / self.sr, max(0.0, st.chunk_timestamp(end_chunk_id, time.time()) - float(self.segment_start_time[s])))
+        if seg_dur <= MAX_SEGMENT_S:                                      # one request, whatever its audio length (the processor windows it)
+            return [{"session": self.ids[s], "type": "final", "start_chunk_id": seg0, "end_chunk_id": end_chunk_id, "part": 0, "parts": 1,
+                     "seconds": seg_dur, "first_sample": first, "n_samples": ns,
+                     "future": st.submit_samples(first, ns, committed_max_new_tokens(seg_dur), self.hotwords)}]
         n_sub = -(-ns // piece)
-        for i in range(n_sub):                                            # <= 30 s: one request; longer: pieces cut at sample 480000 * i
+        for i in range(n_sub):                                            # longer: pieces cut at sample 480000 * i, each with its own duration
             a, b = i * piece, min(ns, (i + 1) * piece)
             if (b - a) * 2 < CHUNK_BYTES * 2:                               # transcribe_committed returns "" below two chunks (:32-33)
                 continue

@@ -30,6 +30,28 @@ def test_two_ranks_share_one_gpu_through_torchrun():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["config"]["share_gpu"] is True
     assert abs(out["value"] * out["ms_per_step"] / 1e3 - 2 * B) < 1e-6 * 2 * B      # whole-job segments / max-over-ranks time
+    assert out["config"]["batches_in_flight"] == 2 and out["config"]["weight_copies"] == 1
     shards = {int(m.group(1)): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"\[bench\] rank (\d)/2 device 0 backend gloo segments \[(\d+), (\d+)\)", r.stderr)}
     assert shards == {0: shard_range(2 * B, 0, 2), 1: shard_range(2 * B, 1, 2)}, r.stderr[-1000:]
     assert shards[0][1] <= shards[1][0]                         # disjoint
+
+
+def test_rccl_branch_at_world_size_one():
+    """The `nccl` (= RCCL) branch of bench.py - init_process_group("nccl", device_id=...), the barrier and the device-tensor all_reduce of the
+    elapsed time - executes once on the one-GPU box before the driver's 8-GPU SCALE run does: bench.py under torch.distributed.run with ONE
+    rank (RCCL cannot put two ranks on one device).  The child is started before this process touches the GPU."""
+    B, steps = 4, 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29733",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
+           "--dist-backend", "nccl", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == steps and out["config"]["dist_backend"] == "nccl"
+    assert out["config"]["batches_in_flight"] == 2 and out["config"]["slots_bit_identical_to_single_batch"] is True
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - B) < 1e-6 * B
+    assert abs(out["single_batch"]["value"] * out["single_batch"]["ms_per_step"] / 1e3 - B) < 1e-6 * B
+    assert "backend nccl" in r.stderr

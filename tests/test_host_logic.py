@@ -71,6 +71,14 @@ def test_header_declares_what_library_exports():
     lib = C.CDLL(engine.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
+    assert lib.sonic_abi_version() == engine.ABI_VERSION == int(re.search(r"#define SONIC_ABI_VERSION (\d+)", hdr).group(1))
+    # the dynamic symbol table is the C ABI and nothing else (-fvisibility=hidden + csrc/exports.map): no mangled launchers, no kernel stubs
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", engine.LIB_PATH], capture_output=True, text=True).stdout
+        exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+        assert exported == declared, sorted(set(exported) ^ set(declared))[:10]
 
 
 def test_library_refuses_without_gpu_or_bad_args():
