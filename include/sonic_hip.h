@@ -81,6 +81,11 @@ typedef struct {
     int32_t decode_steps;
     float enc_gemm_ms;      /* summed duration of ALL encoder-layer GEMM launches (QKV, o, fc1, fc2) of the last run */
     double enc_gemm_flops;  /* ... and their algorithmic FLOPs (SURVEY.md 8d "encoder GEMM MFMA utilisation") */
+    /* host side of the same run (wall clock of the calling / worker thread): enqueueing everything up to the first token, time inside the
+     * decode loop's hipGraphLaunch calls, time blocked on the pipelined early-stop checks, and how many chunk launches that was */
+    float host_prefill_enqueue_ms, host_decode_launch_ms, host_decode_wait_ms;
+    int32_t host_decode_launches;
+    int32_t decode_lookahead;   /* chunks the decode loop kept queued beyond the early-stop check it was waiting for (adapts: 1 on a host that keeps up) */
 } sonic_timings;
 
 /* ---- lifetime ---- */
@@ -218,7 +223,8 @@ SONIC_API int sonic_debug_read(sonic_engine* e, const char* name, int index, flo
  * "ktrace" = layer index is set: out[slot][block < 512][8 points], slots 0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down */
 SONIC_API int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n);
 /* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
- * "no_graph" (eager decode loop), "decode_chunk" (token steps per hipGraph launch = granularity of the early-stop check, default 4), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
+ * "no_graph" (eager decode loop), "decode_chunk" (token steps per hipGraph launch = granularity of the early-stop check, default 4),
+ * "decode_lookahead" (start value of the adaptive queue depth of the decode loop, in chunks), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
  * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table) */
 SONIC_API int sonic_set_option(sonic_engine* e, const char* key, int value);
 

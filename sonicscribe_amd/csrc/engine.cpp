@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -21,6 +22,8 @@
 #include "kernels.h"
 
 #define T_PAD_ALIGN 64
+#define CHK_RING 64            // check events / pinned n_active words of the decode loop
+#define CHK_MAX_AHEAD 32       // deepest lookahead in chunks (a host that is frozen for tens of ms at a time - CPU quota, a busy event loop)
 
 static thread_local std::string g_create_err;
 
@@ -100,7 +103,12 @@ struct sonic_engine {
     int* force_d = nullptr; int force_ld = 0, force_R = 0;   // teacher forcing for the next runs (sonic_set_forced_ids)
     std::vector<int> last_qlen, last_maxnew;
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;        // (rows, token steps) -> captured chunk of the decode loop
-    hipEvent_t chk_ev[2]{};                                        // the pipelined early-stop check: n_active copied out behind chunk k while chunk k+1 is already queued
+    // the pipelined early-stop check: behind every chunk the device's count of running rows is copied to n_active_h[chunk % CHK_RING] and an
+    // event is recorded; the host reads check k only when chunk k + lookahead is already queued (run_decode_steps)
+    hipEvent_t chk_ev[CHK_RING]{};
+    bool run_starved = false;                                      // the current batch saw the queue run dry (lookahead grew)
+    int lookahead = 1;                                             // chunks queued beyond the one whose check the host waits for; adapts (1..CHK_MAX_AHEAD)
+    int* plan_h = nullptr; size_t plan_cap = 0;                    // pinned staging of a batch's prompt plan (no stream synchronise between encoder and prefill)
 
     // Slots (sonic_slot_create): further in-flight batches on ONE weight copy.  A slot is an engine of its own in every respect - stream, activation
     // buffers, KV cache, PCM staging, decode graphs, lock, options - except that its weight / constant pointers are the owner's.
@@ -116,6 +124,7 @@ struct sonic_engine {
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
+    double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
     int opt_decode_chunk = 4;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
     int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
@@ -510,7 +519,9 @@ static int alloc_state(sonic_engine* e) {
         int iota[64]; for (int i = 0; i < 64; ++i) iota[i] = i;
         if (h2d(e, e->seq_iota, iota, sizeof iota) != hipSuccess) { e->err = "memcpy failed"; return SONIC_ERR_HIP; }
     }
-    if (hipHostMalloc((void**)&e->n_active_h, 64, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+    if (hipHostMalloc((void**)&e->n_active_h, (CHK_RING + 1) * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+    e->plan_cap = 3 * tc + 8 * 64;
+    if (hipHostMalloc((void**)&e->plan_h, e->plan_cap * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
     for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->gemm_ev.resize(8 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));   // per layer: [start, end] of the QKV, o, fc1, fc2 GEMM launches
     for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
@@ -611,6 +622,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->taps) (void)hipFree(e->taps);
     if (e->feats_f32) (void)hipFree(e->feats_f32);
     if (e->n_active_h) (void)hipHostFree(e->n_active_h);
+    if (e->plan_h) (void)hipHostFree(e->plan_h);
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->chk_ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
@@ -1232,20 +1244,26 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     const sonic_dims& d = e->d;
     const int D = d.dec_d, M = hp.n_tok, dt = e->dt;
     const QGroup grp{e->tok_seq, 1, R};        // one reference call = the prompt rows of one request
-    HIPC(e, hipMemcpyAsync(e->src, hp.src.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->tok_seq, hp.tok_seq.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->tok_pos_pf, hp.tok_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->q_off, hp.q_off.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->q_len, hp.q_len.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->kv_len, hp.q_len.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->last_row, hp.last_row.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipMemcpyAsync(e->max_new_d, hp.max_new.data(), (size_t)R * 4, hipMemcpyHostToDevice, e->st));
+    // The plan goes through pinned memory, so the copies are truly asynchronous and nothing here waits for the encoder that is still running
+    // on this stream (a pageable source forced a stream synchronise between encoder and prefill: a host-dependent bubble in every batch).
+    // plan_h is free again: the previous run of this engine ended with a stream synchronise.
+    {
+        int* h = e->plan_h; size_t o = 0;
+        auto put = [&](int* dst, const int* srcv, size_t n) -> hipError_t {
+            if (o + n > e->plan_cap) return hipErrorInvalidValue;
+            memcpy(h + o, srcv, n * 4);
+            hipError_t r = hipMemcpyAsync(dst, h + o, n * 4, hipMemcpyHostToDevice, e->st);
+            o += n; return r;
+        };
+        HIPC(e, put(e->src, hp.src.data(), (size_t)M)); HIPC(e, put(e->tok_seq, hp.tok_seq.data(), (size_t)M)); HIPC(e, put(e->tok_pos_pf, hp.tok_pos.data(), (size_t)M));
+        HIPC(e, put(e->q_off, hp.q_off.data(), (size_t)R)); HIPC(e, put(e->q_len, hp.q_len.data(), (size_t)R)); HIPC(e, put(e->kv_len, hp.q_len.data(), (size_t)R));
+        HIPC(e, put(e->last_row, hp.last_row.data(), (size_t)R)); HIPC(e, put(e->max_new_d, hp.max_new.data(), (size_t)R));
+        HIPC(e, put(e->n_active, &R, 1));
+    }
     launch_fill_i32(e->n_new, 0, 64, e->st);
     if (e->amax_att) { launch_fill_i32((int*)e->amax_att, 0, 64 * 4, e->st); launch_fill_i32((int*)e->amax_act, 0, 64 * 4, e->st); launch_fill_i32(e->big_att, 0, 64 * 4, e->st); }   // (partials nobody writes stay 0)
     launch_fill_i32(e->finished, 0, 64, e->st);
     launch_fill_i32(e->step_ctr, 0, 64, e->st);
-    HIPC(e, hipMemcpyAsync(e->n_active, &R, 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipStreamSynchronize(e->st));   // host vectors go out of scope with the caller; tiny copies
     launch_assemble_embeds(e->src, e->embed, e->pe, e->dx, M, D, e->st);
     e->last_ntok = M;
     if (e->taps_on) {
@@ -1312,7 +1330,11 @@ static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, co
             const int w0 = req_win ? req_win[r] : r, w1 = req_win ? req_win[r + 1] : r + 1;
             for (int w = w0; w < w1 && w < 64; ++w) wr[w] = r;
         }
-        if (e->i8) HIPC(e, h2d(e, e->win_req, wr.data(), 64 * 4));
+        if (e->i8) {                                           // (pinned: the last 64 words of plan_h, beyond what run_prefill uses)
+            int* h = e->plan_h + e->plan_cap - 64;
+            memcpy(h, wr.data(), 64 * 4);
+            HIPC(e, hipMemcpyAsync(e->win_req, h, 64 * 4, hipMemcpyHostToDevice, e->st));
+        }
     }
     TRY(run_encoder(e, e->W, nullptr, nullptr, R));
     (void)hipEventRecord(e->ev[2], e->st);
@@ -1342,20 +1364,36 @@ static int chunk_graph(sonic_engine* e, int R, int n, hipGraphExec_t* out) {
 }
 
 // up to n_steps further token steps of the staged batch (HF:generation/utils.py:2876-2943), in chunks of `decode_chunk` steps: one hipGraph
-// launch per chunk (eager under teacher forcing / when the step logits are wanted).  Ragged termination: behind every chunk the device's
-// count of running rows is copied to pinned memory; the host reads the copy of chunk k only after it has queued chunk k+1, so the stream
-// never runs dry while the host looks (a host that is late by less than a chunk costs nothing), and the loop stops one chunk after every row
-// hit EOS / its budget (finished rows are frozen: the extra steps rewrite their own cache slot and emit nothing).
+// launch per chunk (eager under teacher forcing / when the step logits are wanted; a launch costs the host ~4 us, tools/host_cost.py).
+// Ragged termination without a host round trip on the critical path: behind every chunk the device's count of running rows is copied to
+// pinned memory and an event is recorded; the host reads check k only when chunk k + lookahead is already queued, so the stream never runs
+// dry while the host looks, and the loop stops `lookahead` chunks after every row hit EOS / its budget (finished rows are frozen: the
+// queued steps rewrite their own cache slot and emit nothing).  lookahead ADAPTS: it is 1 on a host that keeps up (waste at a stop: one
+// chunk) and doubles whenever the host, coming back to launch the next chunk, finds the previous one already complete - the queue had run
+// dry: a host that is descheduled for tens of milliseconds at a time (CPU quota shared with other work, a busy event loop) -
+// up to CHK_MAX_AHEAD chunks; a batch without such an observation takes one chunk off again.
 static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
     const int R = e->R, left = e->max_steps - 1 - e->steps_run;
     if (n_steps > left) n_steps = left;
     const bool want_logits = e->run_logits;
     const bool use_graph = !want_logits && !e->opt_no_graph && !e->force_d;
     const int C = e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1;
-    int done = 0, slot = 0, prev = -1;
-    bool all_stopped = false;
+    int done = 0;
+    int launched = 0, checked = 0, last_grow = 0;   // chunks queued with a check behind them / checks the host has read
+    bool all_stopped = false, starved = false;
+    typedef std::chrono::steady_clock clk;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    auto read_check = [&](bool block) -> int {  // 1: read (all_stopped updated), 0: not complete yet, < 0: error
+        const int i = checked % CHK_RING;
+        if (!block) { const hipError_t q = hipEventQuery(e->chk_ev[i]); if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; } if (q != hipSuccess) return -1; }
+        else { const auto t_w = clk::now(); if (hipEventSynchronize(e->chk_ev[i]) != hipSuccess) return -1; e->host_wait_ms += ms_since(t_w); }
+        if (e->n_active_h[i] <= 0) all_stopped = true;
+        ++checked;
+        return 1;
+    };
     while (done < n_steps && !all_stopped) {
         const int n = n_steps - done < C ? n_steps - done : C;
+        const auto t_l = clk::now();
         if (use_graph) {
             hipGraphExec_t gx = nullptr;
             TRY(chunk_graph(e, R, n, &gx));
@@ -1363,21 +1401,33 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
         } else {
             for (int i = 0; i < n; ++i) decode_step(e, R, want_logits);
         }
+        e->host_launch_ms += ms_since(t_l); e->host_launches += 1;
         done += n; e->steps_run += n; e->greedy_calls += n;
-        if (e->steps_run + 1 < e->max_steps) {                 // more steps may follow (in this call or the next): leave a check behind this chunk
-            HIPC(e, hipMemcpyAsync(e->n_active_h + slot, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
-            HIPC(e, hipEventRecord(e->chk_ev[slot], e->st));
-            if (prev >= 0) {
-                HIPC(e, hipEventSynchronize(e->chk_ev[prev]));
-                if (e->n_active_h[prev] <= 0) all_stopped = true;
+        if (e->steps_run + 1 >= e->max_steps) break;           // the budget is exhausted: nothing left to stop early
+        const int slot = launched % CHK_RING;
+        HIPC(e, hipMemcpyAsync(e->n_active_h + slot, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+        HIPC(e, hipEventRecord(e->chk_ev[slot], e->st));
+        ++launched;
+        (void)hipGetLastError();
+        while (!all_stopped && checked < launched) {           // read what is there; block only for checks older than the lookahead
+            const int r = read_check(launched - checked > e->lookahead);
+            if (r < 0) return fail(e, SONIC_ERR_HIP, "decode loop: check event failed: %s", hipGetErrorString(hipGetLastError()));
+            if (r == 0) break;
+        }
+        // every chunk queued so far is already complete, the one queued a moment ago included: the device ran dry while this thread was away
+        // (on a host that keeps up, the newest chunk is at most running when its predecessor's check comes back)
+        if (!all_stopped && checked == launched && done < n_steps) {
+            if (launched - last_grow > e->lookahead && e->lookahead < CHK_MAX_AHEAD) {      // (the deeper queue gets `lookahead` launches to show before it grows again)
+                e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
+                last_grow = launched;
             }
-            prev = slot; slot ^= 1;
+            starved = true;
         }
     }
-    if (!all_stopped && prev >= 0 && done >= n_steps && e->steps_run + 1 < e->max_steps) {
-        // the caller asked for fewer steps than the budget (sonic_decode_step): its own synchronise follows, look at the last check now
-        HIPC(e, hipEventSynchronize(e->chk_ev[prev]));
-        if (e->n_active_h[prev] <= 0) all_stopped = true;
+    e->run_starved = e->run_starved || starved;
+    if (!all_stopped && done >= n_steps && e->steps_run + 1 < e->max_steps) {
+        // the caller asked for fewer steps than the budget (sonic_decode_step) and synchronises next: read the outstanding checks now
+        while (!all_stopped && checked < launched) if (read_check(true) < 0) return fail(e, SONIC_ERR_HIP, "decode loop: check event failed");
     }
     if (all_stopped) e->steps_run = e->max_steps - 1;
     if (done_out) *done_out = done;
@@ -1387,7 +1437,10 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
 static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                    const int32_t* max_new, bool want_logits) {
     const sonic_dims& d = e->d;
+    const auto t_host0 = std::chrono::steady_clock::now();
     TRY(run_to_first_token(e, req_win, R, prompt_ids, prompt_off, max_new, want_logits));
+    const double host_enqueue_first = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    e->host_launch_ms = e->host_wait_ms = 0; e->host_launches = 0; e->run_starved = false;
     int steps_done = 0;
     TRY(run_decode_steps(e, e->max_steps - 1, &steps_done));
     (void)hipEventRecord(e->ev[4], e->st);
@@ -1409,6 +1462,9 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
         t.enc_gemm_flops += 2.0 * MT * C * (3 * C) + 2.0 * MT * C * C + 4.0 * MT * F * C;      // QKV, o, fc1, fc2
     }
     t.decode_steps = steps_done;
+    t.host_prefill_enqueue_ms = (float)host_enqueue_first; t.host_decode_launch_ms = (float)e->host_launch_ms; t.host_decode_wait_ms = (float)e->host_wait_ms;
+    t.host_decode_launches = e->host_launches; t.decode_lookahead = e->lookahead;
+    if (!e->run_starved && e->lookahead > 1) e->lookahead -= 1;       // a batch whose queue never ran dry: one chunk less ahead next time
     return SONIC_OK;
 }
 
@@ -1713,10 +1769,10 @@ extern "C" int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active
     if (e->R < 1 || e->greedy_calls < 1) return fail(e, SONIC_ERR_INVALID, "sonic_decode_step needs a batch that went through sonic_prefill");
     int done = 0;
     TRY(run_decode_steps(e, n_steps, &done));
-    HIPC(e, hipMemcpyAsync(e->n_active_h, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+    HIPC(e, hipMemcpyAsync(e->n_active_h + CHK_RING, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
     HIPC(e, hipStreamSynchronize(e->st));
     HIPC(e, hipGetLastError());
-    if (n_active_out) *n_active_out = *e->n_active_h;
+    if (n_active_out) *n_active_out = e->n_active_h[CHK_RING];
     if (steps_done_out) *steps_done_out = done;
     return SONIC_OK;
 }
@@ -2088,6 +2144,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
+    if (!strcmp(key, "decode_lookahead")) { e->lookahead = value < 1 ? 1 : (value > CHK_MAX_AHEAD ? CHK_MAX_AHEAD : value); return SONIC_OK; }   // start value (it adapts)
     if (!strcmp(key, "decode_chunk")) { e->opt_decode_chunk = value > 0 ? (value > 64 ? 64 : value) : 1; return SONIC_OK; }   // token steps per graph launch / early-stop check
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
     if (!strcmp(key, "no_fused_rope")) { e->opt_no_fused_rope = value; return SONIC_OK; }  // encoder RoPE as its own pass (A/B against the fused epilogue)

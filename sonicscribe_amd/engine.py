@@ -52,6 +52,8 @@ class SonicTimings(C.Structure):
         ("mel_ms", C.c_float), ("encoder_ms", C.c_float), ("prefill_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
         ("gemm_ms", C.c_float), ("gemm_launches", C.c_int32), ("gemm_flops", C.c_double), ("decode_steps", C.c_int32),
         ("enc_gemm_ms", C.c_float), ("enc_gemm_flops", C.c_double),
+        ("host_prefill_enqueue_ms", C.c_float), ("host_decode_launch_ms", C.c_float), ("host_decode_wait_ms", C.c_float), ("host_decode_launches", C.c_int32),
+        ("decode_lookahead", C.c_int32),
     ]
 
 

@@ -136,8 +136,9 @@ def test_decode_chunk_sizes_and_pipelined_early_stop():
         e2.set_option("decode_chunk", c)
         got, _ = e2.transcribe_batch(segs, prompts, [200] * 4)
         assert all(np.array_equal(a, b) for a, b in zip(got, ref)), c
-        steps = e2.timings()["decode_steps"]
-        assert steps <= max(len(x) for x in ref) - 1 + 2 * c + 1, (c, steps)    # at most the detection chunk plus the one queued behind it
+        t = e2.timings()
+        steps, ahead = t["decode_steps"], t["decode_lookahead"]
+        assert steps <= max(len(x) for x in ref) - 1 + (ahead + 1) * c + 1, (c, steps, ahead)    # at most the detection chunk plus the `lookahead` queued behind it
         assert steps < 199
     e2.close()
 
