@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the multi-rank run (nccl == RCCL; gloo for boxes "
                     "with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="ranks use device LOCAL_RANK mod device count (exercise the N-rank path on fewer GPUs; not a scaling measurement)")
-    ap.add_argument("--slots", type=int, default=2, help="batches of --batch segments in flight per GPU on one engine / one weight copy (sonic_slot_create); 1 = rounds 1-3's definition")
+    ap.add_argument("--slots", type=int, default=3, help="batches of --batch segments in flight per GPU on one engine / one weight copy (sonic_slot_create); 1 = rounds 1-3's definition")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects int8_b64 / streaming / pcie_inclusive of the N=1 line")
     a = ap.parse_args()
     if a.cpu_baseline_worker:

@@ -22,7 +22,7 @@ def test_two_ranks_share_one_gpu_through_torchrun():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
-           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--slots", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -44,7 +44,7 @@ def test_rccl_branch_at_world_size_one():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29733",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
-           "--dist-backend", "nccl", "--no-cpu-baseline"]
+           "--dist-backend", "nccl", "--no-cpu-baseline", "--slots", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
