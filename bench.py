@@ -235,7 +235,8 @@ def streaming_measure(a):
     dims = replace(base, eos_ids=())
     S = a.sessions
     dev = "cuda:*" if a.gpus > 1 else "cuda:" + ",".join(["0"] * max(1, a.replicas_per_gpu))     # several replicas on one GPU fill each other's decode bubbles
-    model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512, slots=getattr(a, "slots", 2))
+    model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512, slots=getattr(a, "slots", 2),
+                                    continuous=getattr(a, "continuous", False))
     n_rep = len(model.models)
     speech = SEG_SECONDS * 16000
     wire = [synth.synth_pcm(i, speech) for i in range(S)]                          # int16, as the WebSocket delivers it
@@ -321,7 +322,7 @@ def streaming_measure(a):
         "dtype": "int8" if a.mode == "int8" else "bf16", "sessions": S, "wall_s": wall,
         "partial_latency_ms": {"p50": pct(lat["partial"], 50), "p99": pct(lat["partial"], 99), "max": pct(lat["partial"], 100), "n": len(lat["partial"])},
         "final_latency_ms": {"p50": pct(lat["final"], 50), "p99": pct(lat["final"], 99), "max": pct(lat["final"], 100), "n": len(lat["final"])},
-        "device_batches_per_replica": batches, "slots": model.slots, **single,
+        "device_batches_per_replica": batches, "slots": model.slots, "continuous": model.continuous, **single,
         "ingest": {"kind": a.ingest, "appends": n_app, "mean_append_us": (append_s / n_app * 1e6) if n_app else None, "max_event_lateness_ms": late * 1e3},
         "config": {"workload": "BASELINE config 5 call pattern, one process, requests through ASRModel.submit() (dispatch.Dispatcher: no linger, "
                                "step-class buckets, session -> replica)" + ("; every 64 ms wire chunk appended to the session's device ring as it "
@@ -345,6 +346,7 @@ def main():
     ap.add_argument("--streaming", action="store_true", help="BASELINE config 5: real-time session simulation (partial / final latency), one process")
     ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="--streaming on one GPU: engine replicas sharing it (DESIGN.md 4: concurrent decode chains)")
+    ap.add_argument("--continuous", action="store_true", help="--streaming: row-level scheduling (the engine decodes forever over its rows, slots prefill; dispatch._ContinuousReplica)")
     ap.add_argument("--single", action="store_true", help="--streaming: also time B=1 transcribe() calls of 5 s / 20 s first (BASELINE config 1's call shape)")
     ap.add_argument("--ingest", default="host", choices=["host", "ring"], help="--streaming: decodes hand over host tensors (the reference's call) or name chunk "
                     "ranges of per-session device rings fed chunk by chunk (SURVEY 8 f2)")

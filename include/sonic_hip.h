@@ -161,6 +161,24 @@ SONIC_API int sonic_wait(sonic_engine* e, int block, int32_t* busy_out);
 SONIC_API int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                   const int32_t* max_new, int want_step_logits);
 SONIC_API int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32_t* steps_done_out);
+/* Continuous decoding: one handle decodes forever over its max_batch rows; requests join and leave ROW BY ROW instead of batch by batch.  The
+ * reference awaits one transcribe() at a time per connection and blocks its event loop inside it (backend/connection_manager.py:127-245,
+ * backend/transcription_manager.py:58); a batch engine makes a request wait for the running batch and pads every batch to its slowest row.
+ *   sonic_service_begin(d)      d's rows become a pool (all free), its chunk graph is captured; d takes no batch calls until sonic_service_end
+ *   sonic_prefill(p, ...)       on ANOTHER handle of the same weights (a slot): log-mel, encoder, prompt forward, first token of R requests
+ *   sonic_splice_rows(d, p, n, src_rows, dst_rows, &seq)   rows src_rows[] of p (KV cache, control words, next-step input) -> free rows
+ *                               dst_rows[] of d, queued on d's stream between two chunks; p may start its next prefill at once (it waits for the
+ *                               copies on the device).  seq = chunks d had queued before: checks with a larger number describe the new occupants
+ *   sonic_service_step(d, k, finished[64], n_new[64], &seq, &n_active)   queue k more chunks (k * decode_chunk token steps for every row) and
+ *                               return the newest completed check: finished[r] = 1 once row r hit EOS / its budget (or is free), n_new[r] its tokens
+ *   sonic_fetch_row(d, row, n, ids)   the n tokens of a finished row; the row is free again
+ * A request's tokens are the same bits as in a solo run (rows are independent in every decode kernel; tests/test_gpu_continuous.py). */
+SONIC_API int sonic_service_begin(sonic_engine* d);
+SONIC_API int sonic_service_end(sonic_engine* d);
+SONIC_API int sonic_splice_rows(sonic_engine* d, sonic_engine* p, int n, const int32_t* src_rows, const int32_t* dst_rows, int64_t* seq_out);
+SONIC_API int sonic_service_step(sonic_engine* d, int n_chunks, int32_t* finished_out, int32_t* n_new_out, int64_t* seq_out, int32_t* n_active_out);
+SONIC_API int sonic_fetch_row(sonic_engine* d, int row, int n, int32_t* out_ids);
+
 /* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as
  * 2048-byte chunks in a host dict (backend/audio_manager.py:21-33, fed from backend/main.py:813-842) and concatenates on the host for
  * every partial / final decode (audio_manager.py:99-123).  A decode names sample ranges of rings instead of handing over host buffers;

@@ -34,6 +34,9 @@ from .spec import FULL, ModelDims
 # Batches in flight per replica on ONE weight copy (engine slots, include/sonic_hip.h sonic_slot_create).  The reference's file mode keeps up to
 # three decodes in flight on its one model object (backend/main.py:429-445); here they overlap on the device instead of serialising.
 DEFAULT_SLOTS = 2
+# Row-level scheduling (dispatch._ContinuousReplica): the replica's engine decodes forever over its rows, the slot prefills; requests join and
+# leave row by row.  False: batch by batch (dispatch._Replica), every slot runs whole batches.
+DEFAULT_CONTINUOUS = False
 
 
 # --------------------------------------------------------------------------------------- prompts
@@ -174,7 +177,7 @@ class AudioStream:
 class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
                  cpu_threads: Optional[int] = None, cpu_interop_threads: Optional[int] = None,
-                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, _dims: Optional[ModelDims] = None,
+                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, continuous: bool = DEFAULT_CONTINUOUS, _dims: Optional[ModelDims] = None,
                  _synthetic_seed: Optional[int] = None, _allow_synthetic_prompt: bool = False):
         if mode not in ["native", "int8"]:
             raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
@@ -224,9 +227,10 @@ class ASRModel:
                     raise RuntimeError(f"could not load the processor / tokenizer from {self.checkpoint_dir}: {ex}") from ex
                 self.prompt = SyntheticPrompt(self.dims)
         self.model = self.models[0]                  # main.py:84-86 checks and deletes `.model`
-        self.slots = max(1, int(slots))
+        self.continuous = bool(continuous)
+        self.slots = max(2 if self.continuous else 1, int(slots))
         self._slot_engines = [[eng.slot() for _ in range(self.slots - 1)] for eng in self.models]     # same weights, further batches in flight
-        self._dispatcher = Dispatcher(self.models, slots=self._slot_engines)
+        self._dispatcher = Dispatcher(self.models, slots=self._slot_engines, continuous=self.continuous)
         print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
               f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s), {self.slots} batch slot(s) each)")
 
@@ -311,7 +315,7 @@ class ASRModel:
             segs.extend(wins)
             req_win.append(len(segs))
             prompts.append(self.prompt.build(instruction, n_audio))
-        if len(self.models) == 1:
+        if len(self.models) == 1 and not self.continuous:
             ids, _ = self.model.transcribe_batch(segs, prompts, mn, req_win=req_win)
         else:            # independent segments: spread over the replicas (least-loaded placement), results in input order
             futs = [self._dispatcher.submit(segs[req_win[i]:req_win[i + 1]], prompts[i], mn[i]) for i in range(len(audios))]
@@ -327,7 +331,7 @@ class ASRModel:
         v = di["hip_runtime_version"]
         info.update({"cuda_version": f"HIP {v // 10000000}.{(v // 100000) % 100}.{v % 100000}", "gpu_name": di["name"],
                      "gpu_memory_total_mb": di["total_bytes"] / 1024 ** 2})
-        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])), "slots_per_replica": self.__dict__.get("slots", 1),
+        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])), "slots_per_replica": self.__dict__.get("slots", 1), "continuous": self.__dict__.get("continuous", False),
                      "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0})
         return info
 

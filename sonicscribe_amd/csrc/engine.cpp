@@ -23,6 +23,7 @@
 
 #define T_PAD_ALIGN 64
 #define CHK_RING 64            // check events / pinned n_active words of the decode loop
+#define SVC_WORDS 132           // per check of the continuous loop: finished[64], n_new[64], n_active, padding
 #define CHK_MAX_AHEAD 32       // deepest lookahead in chunks (a host that is frozen for tens of ms at a time - CPU quota, a busy event loop)
 
 static thread_local std::string g_create_err;
@@ -115,6 +116,15 @@ struct sonic_engine {
     sonic_engine* owner = nullptr;                                 // slot: whose weights these are (never a slot itself)
     std::vector<sonic_engine*> slots;                              // owner: its slots (destroyed with it at the latest)
     std::mutex rings_mu;                                           // owner: guards `rings` (the registry every slot stages from)
+
+    // continuous decoding (sonic_service_*): this engine's rows are a pool - requests prefilled on another handle of the same weights are spliced
+    // into free rows between chunks of an endless greedy loop, finished rows are fetched and freed one by one
+    bool svc_on = false;
+    int64_t svc_launched = 0, svc_checked = 0;                     // chunks queued / checks read since sonic_service_begin
+    int* svc_h = nullptr;                                          // pinned ring [CHK_RING][SVC_WORDS]: finished[64] | n_new[64] | n_active
+    int svc_fin[64]{}, svc_nn[64]{}, svc_active = 0; int64_t svc_seq = 0;   // the newest check read: state after chunk number svc_seq
+    hipStream_t st_io = nullptr;                                   // row fetches (a finished row's ids are stable: no ordering against the queued chunks needed)
+    hipEvent_t xfer_ev = nullptr, splice_ev = nullptr, wait_ev = nullptr; bool wait_pending = false;   // cross-handle ordering of a splice
 
     // sonic_run_staged_async / sonic_wait: a worker thread of the engine's own runs the batch, the caller's thread returns at once
     struct AsyncJob { std::vector<int32_t> req_win, prompt_ids, max_new; std::vector<int64_t> prompt_off; int R = 0; bool has_rw = false; int want_logits = 0; } a_job;
@@ -520,6 +530,9 @@ static int alloc_state(sonic_engine* e) {
         if (h2d(e, e->seq_iota, iota, sizeof iota) != hipSuccess) { e->err = "memcpy failed"; return SONIC_ERR_HIP; }
     }
     if (hipHostMalloc((void**)&e->n_active_h, (CHK_RING + 1) * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+    if (hipHostMalloc((void**)&e->svc_h, (size_t)CHK_RING * SVC_WORDS * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&e->st_io, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return SONIC_ERR_HIP; }
+    if (hipEventCreateWithFlags(&e->xfer_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->splice_ev, hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->plan_cap = 3 * tc + 8 * 64;
     if (hipHostMalloc((void**)&e->plan_h, e->plan_cap * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
     for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
@@ -623,6 +636,10 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->feats_f32) (void)hipFree(e->feats_f32);
     if (e->n_active_h) (void)hipHostFree(e->n_active_h);
     if (e->plan_h) (void)hipHostFree(e->plan_h);
+    if (e->svc_h) (void)hipHostFree(e->svc_h);
+    if (e->st_io) { (void)hipStreamSynchronize(e->st_io); (void)hipStreamDestroy(e->st_io); }
+    if (e->xfer_ev) (void)hipEventDestroy(e->xfer_ev);
+    if (e->splice_ev) (void)hipEventDestroy(e->splice_ev);
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->chk_ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
@@ -1304,6 +1321,11 @@ static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, co
     const sonic_dims& d = e->d;
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
     if (e->W < 1) return fail(e, SONIC_ERR_INVALID, "no PCM staged");
+    if (e->svc_on) return fail(e, SONIC_ERR_INVALID, "this handle is decoding continuously (sonic_service_begin): prefill on another slot and splice the rows in");
+    if (e->wait_pending) {                                  // rows of the previous batch were spliced into another handle: its copy kernels read this
+        HIPC(e, hipStreamWaitEvent(e->st, e->wait_ev, 0));  // engine's KV cache and row state, which this run is about to overwrite
+        e->wait_pending = false;
+    }
     HostPlan hp;
     TRY(plan_requests(e, req_win, R, prompt_ids, prompt_off, max_new, hp));
     if (e->force_d && (e->force_R != R || e->force_ld < hp.max_steps))
@@ -1683,6 +1705,177 @@ extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, 
     if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
     ENTER(e);
     return run_all(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0);
+}
+
+// ---- continuous decoding (VERDICT r3 item 8 "row refill", generalised): one handle decodes forever over a pool of Bm rows, requests join and
+// leave row by row.  The reference serialises every decode of every session (backend/connection_manager.py:127-245 awaits one transcribe() at a
+// time per connection, backend/transcription_manager.py:58 blocks the event loop); a batch engine makes a request wait for the running batch to
+// end and pads every batch to its slowest row.  Here a request is prefilled on ANOTHER handle of the same weights (sonic_prefill on a slot: log-mel,
+// encoder, prompt forward, first token), its row - KV cache, control words, next-step input - is copied into a free row of the decoding handle
+// between two chunks of its greedy loop, and the row is handed back the moment it hits EOS / its budget.  Rows are independent in every decode
+// kernel and sum in a fixed order (batch invariance up to 32 rows), so a request's tokens are the same bits as in a solo run.
+struct SpliceArgs {
+    const bf16_t *Ks, *Vs; bf16_t *Kd, *Vd; int layers, Bm, Hkv, ctx, hd;
+    int src[64], dst[64];
+    const int *kv_len_s, *tok_pos_s, *n_new_s, *fin_s, *max_new_s, *out_s; int out_ld;
+    int *kv_len_d, *tok_pos_d, *n_new_d, *fin_d, *max_new_d, *out_d, *n_active_d;
+    const bf16_t *sx_s, *shn_s; bf16_t *sx_d, *shn_d; int D;
+    const int8_t* hq_s; int8_t* hq_d; const float *sca_s, *ov_s; float *sca_d, *ov_d; const int *oc_s, *ol_s; int *oc_d, *ol_d;   // int8 mode: layer 0's quantised input row
+};
+__global__ __launch_bounds__(256) void splice_kv_kernel(SpliceArgs a) {
+    const int i = blockIdx.x, lh = blockIdx.y, s = a.src[i], d = a.dst[i];
+    const int len = min(max(a.kv_len_s[s], 1), a.ctx);
+    const long blk = (long)a.ctx * a.hd;
+    const long so = ((long)(lh / a.Hkv) * a.Bm + s) * a.Hkv + lh % a.Hkv, dd = ((long)(lh / a.Hkv) * a.Bm + d) * a.Hkv + lh % a.Hkv;
+    const uint4* ks = (const uint4*)(a.Ks + so * blk); uint4* kd = (uint4*)(a.Kd + dd * blk);
+    const uint4* vs = (const uint4*)(a.Vs + so * blk); uint4* vd = (uint4*)(a.Vd + dd * blk);
+    const int n16 = len * a.hd / 8;
+    for (int j = threadIdx.x; j < n16; j += 256) { kd[j] = ks[j]; vd[j] = vs[j]; }
+}
+__global__ __launch_bounds__(256) void splice_state_kernel(SpliceArgs a) {
+    const int i = blockIdx.x, s = a.src[i], d = a.dst[i], t = threadIdx.x;
+    for (int j = t; j < a.D / 8; j += 256) {
+        ((uint4*)(a.sx_d + (long)d * a.D))[j] = ((const uint4*)(a.sx_s + (long)s * a.D))[j];
+        ((uint4*)(a.shn_d + (long)d * a.D))[j] = ((const uint4*)(a.shn_s + (long)s * a.D))[j];
+    }
+    if (a.hq_s) {
+        for (int j = t; j < a.D / 16; j += 256) ((uint4*)(a.hq_d + (long)d * a.D))[j] = ((const uint4*)(a.hq_s + (long)s * a.D))[j];
+        const int cnt = a.oc_s[s];
+        for (int j = t; j < cnt; j += 256) { a.ol_d[(long)d * a.D + j] = a.ol_s[(long)s * a.D + j]; a.ov_d[(long)d * a.D + j] = a.ov_s[(long)s * a.D + j]; }
+        if (t == 0) { a.sca_d[d] = a.sca_s[s]; a.oc_d[d] = cnt; }
+    }
+    if (t == 0) {
+        const int fin = a.fin_s[s];
+        a.out_d[(long)d * a.out_ld] = a.out_s[(long)s * a.out_ld];            // the first token came out of the prefill
+        a.kv_len_d[d] = a.kv_len_s[s]; a.tok_pos_d[d] = a.tok_pos_s[s]; a.n_new_d[d] = a.n_new_s[s]; a.max_new_d[d] = a.max_new_s[s];
+        a.fin_d[d] = fin;
+        if (!fin) atomicAdd(a.n_active_d, 1);
+    }
+}
+// a fetched row goes back to the pool: it stays `finished` (frozen: it emits nothing) and looks at one key only until it is reused
+__global__ void release_row_kernel(int* kv_len, int* tok_pos, int* finished, int row) { kv_len[row] = 1; tok_pos[row] = 0; finished[row] = 1; }
+__global__ void service_reset_kernel(int* kv_len, int* tok_pos, int* n_new, int* finished, int* max_new, int* n_active) {
+    const int b = threadIdx.x;
+    if (b < 64) { kv_len[b] = 1; tok_pos[b] = 0; n_new[b] = 0; finished[b] = 1; max_new[b] = 1; }
+    if (b == 0) *n_active = 0;
+}
+
+extern "C" int sonic_service_begin(sonic_engine* e) {
+    if (!e) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
+    if (e->svc_on) return SONIC_OK;
+    HIPC(e, hipStreamSynchronize(e->st));
+    hipLaunchKernelGGL(service_reset_kernel, dim3(1), dim3(64), 0, e->st, e->kv_len, e->tok_pos, e->n_new, e->finished, e->max_new_d, e->n_active);
+    if (e->force_d) return fail(e, SONIC_ERR_INVALID, "teacher forcing is set: clear it before continuous decoding");
+    hipGraphExec_t gx = nullptr;                            // the chunk graph exists before the first splice: nothing captures on this stream later
+    TRY(chunk_graph(e, e->Bm, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx));
+    HIPC(e, hipStreamSynchronize(e->st));
+    e->svc_launched = e->svc_checked = 0; e->svc_seq = 0; e->svc_active = 0;
+    for (int b = 0; b < 64; ++b) { e->svc_fin[b] = 1; e->svc_nn[b] = 0; }
+    e->R = 0; e->greedy_calls = 0;
+    e->svc_on = true;
+    return SONIC_OK;
+}
+extern "C" int sonic_service_end(sonic_engine* e) {
+    if (!e) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->svc_on) return SONIC_OK;
+    HIPC(e, hipStreamSynchronize(e->st));
+    e->svc_on = false;
+    return SONIC_OK;
+}
+// n rows of `p` (requests 0 .. R-1 of its last sonic_prefill) -> rows dst_rows[] of the continuously decoding handle `d` (free rows: never
+// spliced, or fetched since).  Queued on d's stream behind p's prefill; p's next run waits for the copies on the device.  *seq_out = chunks d
+// had queued before the splice: checks with a larger sequence number (sonic_service_step) describe the new occupants of these rows.
+extern "C" int sonic_splice_rows(sonic_engine* d, sonic_engine* p, int n, const int32_t* src_rows, const int32_t* dst_rows, int64_t* seq_out) {
+    if (!d || !p || !src_rows || !dst_rows || d == p) return SONIC_ERR_INVALID;
+    std::unique_lock<std::mutex> l1(d->mu, std::defer_lock), l2(p->mu, std::defer_lock);
+    std::lock(l1, l2);
+    (void)hipGetLastError();
+    HIPC(d, hipSetDevice(d->device)); g_opts = d->opts;
+    if (!d->svc_on) return fail(d, SONIC_ERR_INVALID, "sonic_splice_rows: the destination is not decoding continuously (sonic_service_begin)");
+    if ((d->owner ? d->owner : d) != (p->owner ? p->owner : p)) return fail(d, SONIC_ERR_INVALID, "sonic_splice_rows: the handles do not share weights");
+    if (d->Bm != p->Bm || d->max_ctx != p->max_ctx) return fail(d, SONIC_ERR_INVALID, "sonic_splice_rows: the handles differ in max_batch / max_ctx");
+    if (n < 1 || n > 64 || p->greedy_calls < 1 || n > p->R) return fail(d, SONIC_ERR_INVALID, "sonic_splice_rows: %d rows, the source has %d prefilled requests", n, p->greedy_calls < 1 ? 0 : p->R);
+    SpliceArgs a{};
+    for (int i = 0; i < n; ++i) {
+        if (src_rows[i] < 0 || src_rows[i] >= p->R || dst_rows[i] < 0 || dst_rows[i] >= d->Bm) return fail(d, SONIC_ERR_INVALID, "sonic_splice_rows: row out of range");
+        for (int j = 0; j < i; ++j) if (dst_rows[j] == dst_rows[i]) return fail(d, SONIC_ERR_INVALID, "sonic_splice_rows: destination row %d named twice", dst_rows[i]);
+        a.src[i] = src_rows[i]; a.dst[i] = dst_rows[i];
+    }
+    const sonic_dims& dm = d->d;
+    a.Ks = p->Kc; a.Vs = p->Vc; a.Kd = d->Kc; a.Vd = d->Vc; a.layers = dm.dec_layers; a.Bm = d->Bm; a.Hkv = dm.dec_kv_heads; a.ctx = d->max_ctx; a.hd = dm.dec_head_dim;
+    a.kv_len_s = p->kv_len; a.tok_pos_s = p->tok_pos; a.n_new_s = p->n_new; a.fin_s = p->finished; a.max_new_s = p->max_new_d; a.out_s = p->out_ids; a.out_ld = d->out_cap;
+    a.kv_len_d = d->kv_len; a.tok_pos_d = d->tok_pos; a.n_new_d = d->n_new; a.fin_d = d->finished; a.max_new_d = d->max_new_d; a.out_d = d->out_ids; a.n_active_d = d->n_active;
+    a.sx_s = p->sx; a.shn_s = p->shn; a.sx_d = d->sx; a.shn_d = d->shn; a.D = dm.dec_d;
+    if (d->i8) { a.hq_s = p->hn_q; a.hq_d = d->hn_q; a.sca_s = p->sca_hn; a.sca_d = d->sca_hn; a.oc_s = p->oc_hn; a.oc_d = d->oc_hn; a.ol_s = p->ol_hn; a.ol_d = d->ol_hn; a.ov_s = p->ov_hn; a.ov_d = d->ov_hn; }
+    HIPC(d, hipEventRecord(p->xfer_ev, p->st));
+    HIPC(d, hipStreamWaitEvent(d->st, p->xfer_ev, 0));
+    hipLaunchKernelGGL(splice_kv_kernel, dim3(n, dm.dec_layers * dm.dec_kv_heads), dim3(256), 0, d->st, a);
+    hipLaunchKernelGGL(splice_state_kernel, dim3(n), dim3(256), 0, d->st, a);
+    HIPC(d, hipEventRecord(d->splice_ev, d->st));
+    p->wait_ev = d->splice_ev; p->wait_pending = true;
+    HIPC(d, hipGetLastError());
+    if (seq_out) *seq_out = d->svc_launched;
+    return SONIC_OK;
+}
+// queue n_chunks more chunks of the endless greedy loop over all Bm rows and return the newest check the device has completed: finished[64]
+// (1 = the row hit EOS / its budget, or is free), n_new[64] (tokens the row holds), *seq_out = number of the chunk that check followed (0:
+// none yet), *n_active_out = rows still running then.  Blocks only while more than `lookahead` chunks are unchecked (adaptive, as the batch loop).
+extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int32_t* finished_out, int32_t* n_new_out, int64_t* seq_out, int32_t* n_active_out) {
+    if (!e || n_chunks < 0) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->svc_on) return fail(e, SONIC_ERR_INVALID, "sonic_service_step needs sonic_service_begin");
+    const int C = e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1;
+    auto read_check = [&](bool block) -> int {
+        const int i = (int)(e->svc_checked % CHK_RING);
+        if (!block) { const hipError_t q = hipEventQuery(e->chk_ev[i]); if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; } if (q != hipSuccess) return -1; }
+        else if (hipEventSynchronize(e->chk_ev[i]) != hipSuccess) return -1;
+        const int* w = e->svc_h + (size_t)i * SVC_WORDS;
+        memcpy(e->svc_fin, w, 64 * 4); memcpy(e->svc_nn, w + 64, 64 * 4); e->svc_active = w[128];
+        e->svc_seq = ++e->svc_checked;
+        return 1;
+    };
+    for (int c = 0; c <= n_chunks; ++c) {
+        if (c < n_chunks) {
+            hipGraphExec_t gx = nullptr;
+            TRY(chunk_graph(e, e->Bm, C, &gx));
+            HIPC(e, hipGraphLaunch(gx, e->st));
+            const int slot = (int)(e->svc_launched % CHK_RING);
+            int* w = e->svc_h + (size_t)slot * SVC_WORDS;
+            HIPC(e, hipMemcpyAsync(w, e->finished, 64 * 4, hipMemcpyDeviceToHost, e->st));
+            HIPC(e, hipMemcpyAsync(w + 64, e->n_new, 64 * 4, hipMemcpyDeviceToHost, e->st));
+            HIPC(e, hipMemcpyAsync(w + 128, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+            HIPC(e, hipEventRecord(e->chk_ev[slot], e->st));
+            ++e->svc_launched;
+        }
+        while (e->svc_checked < e->svc_launched) {
+            const int r = read_check(e->svc_launched - e->svc_checked > e->lookahead);
+            if (r < 0) return fail(e, SONIC_ERR_HIP, "continuous decode loop: check event failed: %s", hipGetErrorString(hipGetLastError()));
+            if (r == 0) break;
+        }
+        if (c < n_chunks && e->svc_checked == e->svc_launched && e->svc_active > 0 && e->lookahead < CHK_MAX_AHEAD) e->lookahead *= 2;   // the device ran dry with rows running
+    }
+    if (finished_out) memcpy(finished_out, e->svc_fin, 64 * 4);
+    if (n_new_out) memcpy(n_new_out, e->svc_nn, 64 * 4);
+    if (seq_out) *seq_out = e->svc_seq;
+    if (n_active_out) *n_active_out = e->svc_active;
+    return SONIC_OK;
+}
+// the n tokens of a finished row (n from sonic_service_step's n_new), then the row is free for the next splice
+extern "C" int sonic_fetch_row(sonic_engine* e, int row, int n, int32_t* out_ids) {
+    if (!e || !out_ids) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->svc_on) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_row needs sonic_service_begin");
+    if (row < 0 || row >= e->Bm || n < 0 || n > e->out_cap) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_row: row %d / %d tokens out of range", row, n);
+    if (n > 0) {
+        HIPC(e, hipMemcpyAsync(out_ids, e->out_ids + (size_t)row * e->out_cap, (size_t)n * 4, hipMemcpyDeviceToHost, e->st_io));
+        HIPC(e, hipStreamSynchronize(e->st_io));
+    }
+    hipLaunchKernelGGL(release_row_kernel, dim3(1), dim3(1), 0, e->st, e->kv_len, e->tok_pos, e->finished, row);
+    HIPC(e, hipGetLastError());
+    return SONIC_OK;
 }
 
 // ---- asynchronous form: the batch runs on a worker thread of the engine's own; the caller's thread returns at once and may drive other slots.

@@ -30,6 +30,7 @@ EXPORTS = [
     "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
     "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info", "sonic_release_pool",
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
+    "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row",
 ]
 ABI_VERSION = 4
 
@@ -136,6 +137,11 @@ def load_library():
     lib.sonic_slot_count.argtypes = [vp]
     lib.sonic_run_staged_async.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
     lib.sonic_wait.argtypes = [vp, C.c_int, ip]
+    lib.sonic_service_begin.argtypes = [vp]
+    lib.sonic_service_end.argtypes = [vp]
+    lib.sonic_splice_rows.argtypes = [vp, vp, C.c_int, vp, vp, i64p]
+    lib.sonic_service_step.argtypes = [vp, C.c_int, vp, vp, i64p, ip]
+    lib.sonic_fetch_row.argtypes = [vp, C.c_int, C.c_int, vp]
     for name in EXPORTS:
         getattr(lib, name)
     if lib.sonic_abi_version() != ABI_VERSION:
@@ -437,6 +443,33 @@ class Engine:
         rc = self.lib.sonic_run_staged_async(self.h, _p(rw), len(mn), _p(ids), _p(poffs), _p(mn), 0)
         if rc != 0:
             raise SonicError((self.lib.sonic_last_error(None) or b"").decode() or f"sonic_run_staged_async failed with status {rc}")
+
+    # -- continuous decoding (sonic_service_*): this engine's rows are a pool, requests prefilled on a slot are spliced in row by row
+    def service_begin(self):
+        self._check(self.lib.sonic_service_begin(self.h))
+
+    def service_end(self):
+        self._check(self.lib.sonic_service_end(self.h))
+
+    def splice_rows(self, src: "Engine", src_rows: Sequence[int], dst_rows: Sequence[int]) -> int:
+        """rows src_rows of `src` (requests of its last prefill()) -> free rows dst_rows of this engine; returns the chunk sequence number
+        after which service_step()'s flags describe the new occupants"""
+        a = np.ascontiguousarray(src_rows, dtype=np.int32); b = np.ascontiguousarray(dst_rows, dtype=np.int32)
+        seq = C.c_int64(0)
+        self._check(self.lib.sonic_splice_rows(self.h, src.h, len(a), _p(a), _p(b), C.byref(seq)))
+        return int(seq.value)
+
+    def service_step(self, n_chunks: int = 1):
+        """queue n_chunks more chunks; returns (finished[64], n_new[64], seq, n_active) of the newest completed check"""
+        fin = np.zeros(64, np.int32); nn = np.zeros(64, np.int32)
+        seq, na = C.c_int64(0), C.c_int32(0)
+        self._check(self.lib.sonic_service_step(self.h, int(n_chunks), _p(fin), _p(nn), C.byref(seq), C.byref(na)))
+        return fin, nn, int(seq.value), int(na.value)
+
+    def fetch_row(self, row: int, n: int) -> np.ndarray:
+        out = np.zeros(max(1, int(n)), np.int32)
+        self._check(self.lib.sonic_fetch_row(self.h, int(row), int(n), _p(out)))
+        return out[:n].copy()
 
     def wait(self, block: bool = True) -> bool:
         """Collect the asynchronous run (raises its error).  block=False: returns False while it is still running."""

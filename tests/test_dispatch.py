@@ -209,3 +209,124 @@ def test_text_future_propagates_cancellation_to_the_queued_request():
     assert ok.result(timeout=5) == "48 2 15"
     assert len(e.batches) == 2
     d.close()
+
+
+# ------------------------------------------------------------------------------------------ continuous (row-level) replica
+class StubPool:
+    """Duck-typed pair of handles for dispatch._ContinuousReplica: `StubPool.decoder` decodes over n_rows rows (4 steps per chunk), the
+    prefill handles compute a request's whole token list up front ([sum(pcm) % 1000, len(prompt)] + range(max_new - 2)) and hand it over row by row."""
+
+    class Prefill:
+        def __init__(self, pool, max_batch):
+            self.pool, self.max_batch, self.staged, self.rows, self.batches = pool, max_batch, None, [], []
+
+        def stage_pcm(self, segs, req_win=None):
+            self.staged = (list(segs), list(req_win))
+
+        def prefill(self, prompts, max_new, req_win=None):
+            segs, rw = self.staged
+            rows = []
+            for r in range(len(prompts)):
+                w = segs[rw[r]:rw[r + 1]]
+                if any(len(x) == 13 for x in w):
+                    raise ValueError("Audio features and audio tokens do not match")
+                toks = ([int(sum(int(x.sum()) for x in w)) % 1000, len(prompts[r])] + list(range(max_new[r])))[:max_new[r]]
+                rows.append(toks)
+            time.sleep(self.pool.prefill_delay)
+            self.rows = rows
+            self.batches.append(list(max_new))
+
+    class Decoder:
+        def __init__(self, pool, n_rows):
+            self.pool, self.max_batch = pool, n_rows
+            self.rows = [None] * n_rows                  # [tokens, emitted]
+            self.seq, self.on, self.max_occupied = 0, False, 0
+
+        def service_begin(self):
+            self.on = True
+
+        def service_end(self):
+            self.on = False
+
+        def splice_rows(self, src, src_rows, dst_rows):
+            for s, d in zip(src_rows, dst_rows):
+                assert self.rows[d] is None, "spliced into an occupied row"
+                self.rows[d] = [src.rows[s], 1]
+            self.max_occupied = max(self.max_occupied, sum(r is not None for r in self.rows))
+            return self.seq
+
+        def service_step(self, n_chunks=1):
+            time.sleep(self.pool.step_delay)
+            self.seq += n_chunks
+            fin, nn = np.ones(64, np.int32), np.zeros(64, np.int32)
+            for i, r in enumerate(self.rows):
+                if r is not None:
+                    r[1] = min(len(r[0]), r[1] + 4 * n_chunks)
+                    fin[i], nn[i] = int(r[1] >= len(r[0])), r[1]
+            return fin, nn, self.seq, int(sum(1 for r in self.rows if r is not None and r[1] < len(r[0])))
+
+        def fetch_row(self, row, n):
+            toks, self.rows[row] = self.rows[row][0], None
+            assert n == len(toks)
+            return np.asarray(toks, np.int32)
+
+    def __init__(self, n_rows=4, prefill_batch=4, n_prefill=1, prefill_delay=0.0, step_delay=0.001):
+        self.prefill_delay, self.step_delay = prefill_delay, step_delay
+        self.decoder = StubPool.Decoder(self, n_rows)
+        self.prefills = [StubPool.Prefill(self, prefill_batch) for _ in range(n_prefill)]
+
+
+def want_tokens(v, prompt_len, max_new, n=16):
+    return ([(n * v) % 1000, prompt_len] + list(range(max_new)))[:max_new]
+
+
+def test_continuous_replica_rows_join_and_leave_one_by_one():
+    pool = StubPool(n_rows=4, prefill_batch=4, prefill_delay=0.002)
+    d = Dispatcher([pool.decoder], slots=[pool.prefills], continuous=True)
+    budgets = [15, 150, 40, 15, 150, 7, 1, 150, 15, 15, 64, 2]           # partials, finals and a one-token request mixed: no class buckets
+    futs = [d.submit([seg(i)], [1, 2, 3], mn) for i, mn in enumerate(budgets)]
+    res = [f.result(timeout=10) for f in futs]
+    for i, (r, mn) in enumerate(zip(res, budgets)):
+        assert r.tolist() == want_tokens(i, 3, mn), i
+    assert pool.decoder.max_occupied <= 4 and all(r is None for r in pool.decoder.rows)       # never more rows than the pool has; all handed back
+    assert any(len(set(b)) > 1 for b in pool.prefills[0].batches)        # a prefill batch mixed budgets
+    # a short request that arrives while long ones decode does not wait for them
+    long_f = [d.submit([seg(50 + i)], [1], 150) for i in range(3)]
+    time.sleep(0.01)
+    t0 = time.perf_counter(); short = d.submit([seg(99)], [1], 3); short.result(timeout=5); dt_short = time.perf_counter() - t0
+    assert not all(f.done() for f in long_f) and dt_short < 0.05
+    [f.result(timeout=10) for f in long_f]
+    d.close()
+    assert not pool.decoder.on
+
+
+def test_continuous_replica_errors_cancel_and_close():
+    pool = StubPool(n_rows=2, prefill_batch=4, n_prefill=2, prefill_delay=0.005)
+    d = Dispatcher([pool.decoder], slots=[pool.prefills], continuous=True)
+    good = [d.submit([seg(i)], [1, 2], 20) for i in range(6)]
+    bad = d.submit([seg(1, n=13)], [1, 2], 20)                          # the stub raises for this request only
+    too_big = d.submit([seg(1)] * 5, [1], 20)                           # more windows than a prefill batch
+    with pytest.raises(ValueError):
+        bad.result(timeout=10)
+    with pytest.raises(ValueError):
+        too_big.result(timeout=10)
+    assert [f.result(timeout=10).tolist() for f in good] == [want_tokens(i, 2, 20) for i in range(6)]
+    assert pool.decoder.max_occupied <= 2
+    assert d.replicas[0].load() == 0
+    d.close()
+    with pytest.raises(RuntimeError):
+        d.submit([seg(0)], [1], 5)
+
+    class Broken(StubPool.Decoder):
+        def service_step(self, n_chunks=1):
+            raise RuntimeError("HIP error: device lost")
+    pool2 = StubPool(n_rows=2)
+    pool2.decoder = Broken(pool2, 2)
+    d2 = Dispatcher([pool2.decoder], slots=[pool2.prefills], continuous=True)
+    f = d2.submit([seg(0)], [1], 20)
+    with pytest.raises(RuntimeError):
+        f.result(timeout=10)
+    time.sleep(0.05)
+    with pytest.raises(RuntimeError):
+        d2.submit([seg(0)], [1], 20)                                      # a failed engine refuses new work instead of hanging it
+    d2.close()

@@ -1,0 +1,145 @@
+"""Continuous decoding (include/sonic_hip.h sonic_service_* / sonic_splice_rows; dispatch._ContinuousReplica): requests join and leave a running
+greedy loop ROW BY ROW.  The reference awaits one transcribe() per connection at a time (backend/connection_manager.py:127-245); a batch
+engine pads every batch to its slowest row.  What must hold: whatever rows a request is spliced into, whoever else is decoding, however
+often the row was used before - its tokens are those of its solo run (HF generate(do_sample=False) semantics, restated by the engine's own
+batch path, which tests/test_gpu_parity.py / test_gpu_benchsize.py pin against the oracle and the reference fixtures)."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from sonicscribe_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+SEED = 20260128
+
+
+def prompt_for(d, n_samples):
+    return [1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(n_samples)) + [7, 301, 302, 303, 9, 11]
+
+
+def make(d, max_batch, mode=0, max_ctx=512):
+    from sonicscribe_amd.engine import Engine
+    e = Engine(d, 0, mode, max_batch=max_batch, max_ctx=max_ctx)
+    e.load_synthetic(SEED)
+    return e
+
+
+def drain(dec, rows, limit=2000):
+    """step the decoding handle until every row in `rows` (row -> valid_after) is finished; returns {row: ids}"""
+    out = {}
+    for _ in range(limit):
+        fin, nn, seq, _ = dec.service_step(1)
+        for r, va in list(rows.items()):
+            if seq > va and fin[r]:
+                out[r] = dec.fetch_row(r, int(nn[r]))
+                del rows[r]
+        if not rows:
+            return out
+    raise AssertionError("rows did not finish")
+
+
+FULLW = replace(spec.FULL, enc_layers=2, dec_layers=2, eos_ids=())
+
+
+@pytest.mark.parametrize("dims,mode", [(replace(spec.TINY, eos_ids=()), 0), (FULLW, 0), (replace(spec.TINY, eos_ids=()), 1)], ids=["tiny", "fullwidth", "tiny-int8"])
+def test_spliced_rows_equal_solo_runs(dims, mode):
+    dec = make(dims, 16, mode)
+    pre = dec.slot()
+    segs = [synth.synth_pcm(500 + i, 16000 * (2 + (i * 5) % 9)) for i in range(10)]
+    prompts = [prompt_for(dims, len(s)) for s in segs]
+    budgets = [9, 40, 15, 3, 27, 1, 15, 33, 8, 21]
+    solo = [dec.transcribe_batch([segs[i]], [prompts[i]], [budgets[i]])[0][0] for i in range(10)]      # the batch path, one request at a time
+    dec.service_begin()
+    with pytest.raises(RuntimeError):
+        dec.transcribe_batch([segs[0]], [prompts[0]], [4])               # a continuously decoding handle takes no batch calls
+    # wave 1: four requests prefilled together, spliced into scattered rows
+    pre.stage_pcm(segs[:4]); pre.prefill(prompts[:4], budgets[:4])
+    seq = dec.splice_rows(pre, [0, 1, 2, 3], [5, 0, 15, 9])
+    rows = {5: seq, 0: seq, 15: seq, 9: seq}
+    who = {5: 0, 0: 1, 15: 2, 9: 3}
+    got = {}
+    # let them run a little, then wave 2 joins the running loop (the slot prefills while the rows decode)
+    for _ in range(2):
+        fin, nn, s_, _ = dec.service_step(1)
+    pre.stage_pcm(segs[4:7]); pre.prefill(prompts[4:7], budgets[4:7])
+    seq2 = dec.splice_rows(pre, [0, 1, 2], [1, 2, 3])
+    rows.update({1: seq2, 2: seq2, 3: seq2}); who.update({1: 4, 2: 5, 3: 6})
+    for r, ids in drain(dec, rows).items():
+        got[who[r]] = ids
+    # wave 3 reuses rows that were fetched (5 held request 0 before) while nothing else runs
+    pre.stage_pcm(segs[7:]); pre.prefill(prompts[7:], budgets[7:])
+    seq3 = dec.splice_rows(pre, [0, 1, 2], [5, 9, 0])
+    who3 = {5: 7, 9: 8, 0: 9}
+    for r, ids in drain(dec, {5: seq3, 9: seq3, 0: seq3}).items():
+        got[who3[r]] = ids
+    for i in range(10):
+        assert len(got[i]) == budgets[i] and np.array_equal(got[i], solo[i]), i
+    dec.service_end()
+    again, _ = dec.transcribe_batch([segs[2]], [prompts[2]], [budgets[2]])   # and the handle is a batch engine again
+    assert np.array_equal(again[0], solo[2])
+    dec.close()
+
+
+def test_rows_that_stop_at_eos_are_refilled():
+    """rows that hit EOS early hand their slot to queued requests while the long rows keep decoding; refilled rows are
+    bit-identical to solo runs (an engineered EOS set, as tests/test_gpu_benchsize.py::test_eos_stop_vs_oracle does)."""
+    base = replace(spec.TINY, eos_ids=())
+    probe = make(base, 4)
+    segs = [synth.synth_pcm(700 + i, 16000 * (2 + i % 5)) for i in range(12)]
+    prompts = [prompt_for(base, len(s)) for s in segs]
+    free_run = [probe.transcribe_batch([segs[i]], [prompts[i]], [60])[0][0] for i in range(12)]
+    probe.close()
+    eos = tuple(sorted({int(free_run[i][2 + i % 4]) for i in range(0, 12, 2)}))[:8]      # ids some rows emit early become EOS
+    d2 = replace(spec.TINY, eos_ids=eos)
+    dec = make(d2, 4)
+    pre = dec.slot()
+    solo = [dec.transcribe_batch([segs[i]], [prompts[i]], [60])[0][0] for i in range(12)]
+    assert min(len(x) for x in solo) < 10 and len({len(x) for x in solo}) > 1            # ragged: some stop early
+    dec.service_begin()
+    pending = list(range(12))
+    occupied, got = {}, {}
+    free = [0, 1, 2, 3]
+    while pending or occupied:
+        if pending and free:                                                              # refill every free row at once
+            take = pending[:len(free)]; pending = pending[len(take):]
+            pre.stage_pcm([segs[i] for i in take]); pre.prefill([prompts[i] for i in take], [60] * len(take))
+            dst = [free.pop(0) for _ in take]
+            seq = dec.splice_rows(pre, list(range(len(take))), dst)
+            for i, r in zip(take, dst):
+                occupied[r] = (i, seq)
+        fin, nn, s_, _ = dec.service_step(1)
+        for r, (i, va) in list(occupied.items()):
+            if s_ > va and fin[r]:
+                got[i] = dec.fetch_row(r, int(nn[r])); del occupied[r]; free.append(r)
+    for i in range(12):
+        assert np.array_equal(got[i], solo[i]), (i, got[i], solo[i])
+    dec.close()
+
+
+def test_asrmodel_continuous_equals_batch_model():
+    """the façade with continuous=True: mixed partial / final budgets from many sessions, host tensors and device rings; every transcript
+    equals the batch-by-batch model's"""
+    from sonicscribe_amd.asr import ASRModel
+    d = replace(spec.TINY, eos_ids=())
+    ref = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=1)
+    con = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=2, continuous=True)
+    assert con.get_model_info()["continuous"] is True and con.model.weight_bytes() == ref.model.weight_bytes()
+    wavs = [synth.synth_pcm(900 + i, 16000 * (2 + i % 4)).astype(np.float32) / 32768.0 for i in range(30)]
+    budgets = [15 if i % 3 else 60 for i in range(30)]
+    want = [ref.transcribe(w[None], 16000, max_new_tokens=b) for w, b in zip(wavs, budgets)]
+    futs = [con.submit(w[None], 16000, b, session=f"c{i}") for i, (w, b) in enumerate(zip(wavs, budgets))]
+    assert [f.result(timeout=120) for f in futs] == want
+    assert con.transcribe(wavs[0][None], 16000, max_new_tokens=60) == want[0]
+    assert con.transcribe_batch(wavs[:5], max_new_tokens=[20] * 5) == ref.transcribe_batch(wavs[:5], max_new_tokens=[20] * 5)
+    long = synth.synth_pcm(77, 16000 * 36).astype(np.float32) / 32768.0                    # two windows behind one prompt
+    assert con.transcribe(long[None], 16000, max_new_tokens=12) == ref.transcribe(long[None], 16000, max_new_tokens=12)
+    st = con.open_stream("ring-0")
+    wire = np.clip(np.rint(wavs[3] * 32768.0), -32768, 32767).astype(np.int16)
+    wire = wire[:(len(wire) // 1024) * 1024].tobytes()
+    for j in range(0, len(wire), 2048):
+        st.add_audio_chunk(wire[j:j + 2048])
+    got = st.submit_chunks(0, st.next_chunk_id - 1, 30).result(timeout=60)
+    assert got == ref.transcribe((np.frombuffer(wire, np.int16).astype(np.float32) / np.float32(32768.0))[None], 16000, max_new_tokens=30)
+    st.close()
+    ref.close(); con.close()
