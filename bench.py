@@ -236,7 +236,7 @@ def streaming_measure(a):
     S = a.sessions
     dev = "cuda:*" if a.gpus > 1 else "cuda:" + ",".join(["0"] * max(1, a.replicas_per_gpu))     # several replicas on one GPU fill each other's decode bubbles
     model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512, slots=getattr(a, "slots", 2),
-                                    continuous=getattr(a, "continuous", False))
+                                    continuous=getattr(a, "continuous", False), _options=dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in getattr(a, "opt", []) or []))
     n_rep = len(model.models)
     speech = SEG_SECONDS * 16000
     wire = [synth.synth_pcm(i, speech) for i in range(S)]                          # int16, as the WebSocket delivers it

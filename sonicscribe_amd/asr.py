@@ -178,7 +178,7 @@ class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
                  cpu_threads: Optional[int] = None, cpu_interop_threads: Optional[int] = None,
                  *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, continuous: bool = DEFAULT_CONTINUOUS, _dims: Optional[ModelDims] = None,
-                 _synthetic_seed: Optional[int] = None, _allow_synthetic_prompt: bool = False):
+                 _synthetic_seed: Optional[int] = None, _allow_synthetic_prompt: bool = False, _options: Optional[Dict[str, int]] = None):
         if mode not in ["native", "int8"]:
             raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
         dev = str(device)
@@ -226,6 +226,9 @@ class ASRModel:
                 if not _allow_synthetic_prompt:
                     raise RuntimeError(f"could not load the processor / tokenizer from {self.checkpoint_dir}: {ex}") from ex
                 self.prompt = SyntheticPrompt(self.dims)
+        for eng in self.models:                      # experiment knobs (sonic_set_option) before the slots copy them
+            for k, v in (_options or {}).items():
+                eng.set_option(k, int(v))
         self.model = self.models[0]                  # main.py:84-86 checks and deletes `.model`
         self.continuous = bool(continuous)
         self.slots = max(2 if self.continuous else 1, int(slots))

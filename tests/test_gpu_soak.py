@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["native", "int8"])
-def test_randomised_concurrency_soak(mode):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "6", "6", mode], capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("mode,sched", [("native", "batch"), ("int8", "batch"), ("native", "continuous"), ("int8", "continuous")])
+def test_randomised_concurrency_soak(mode, sched):
+    """two replicas x two slots each; batch: every slot runs whole batches; continuous: rows join and leave a running greedy loop"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "6", "6", mode, "tiny", sched], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "errors: 0" in r.stdout
 

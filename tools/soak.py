@@ -1,7 +1,8 @@
 """Randomised concurrency soak of the facade (run on the GPU box): T threads fire transcribe() / submit() / stream requests of random
 length (0.1 - 40 s: one or two 30 s windows), budget and hotwords at a multi-replica ASRModel; every transcript must equal the one the
 same model gave for that request alone beforehand (a segment's result does not depend on what it is batched with, bit for bit).
-  python tools/soak.py [seconds] [threads] [mode] [tiny|full]"""
+  python tools/soak.py [seconds] [threads] [mode] [tiny|full] [batch|continuous]
+(batch: two replicas x two batch slots each; continuous: row-level scheduling, dispatch._ContinuousReplica)"""
 import sys, os, time, threading, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +13,8 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 mode = sys.argv[3] if len(sys.argv) > 3 else "native"
 full = len(sys.argv) > 4 and sys.argv[4] == "full"
-m = ASRModel.from_synthetic(spec.FULL if full else spec.TINY, device="cuda:0,0", mode=mode, max_batch=8, max_ctx=1024)
+continuous = len(sys.argv) > 5 and sys.argv[5] == "continuous"
+m = ASRModel.from_synthetic(spec.FULL if full else spec.TINY, device="cuda:0,0", mode=mode, max_batch=8, max_ctx=1024, slots=2, continuous=continuous)
 rng = random.Random(1234)
 HOT = [None, ["alpha"], ["Beta", "gamma delta"], ["x"] * 3]
 cases = []
