@@ -42,7 +42,7 @@ def test_128_sessions_gate_to_ring_decodes(dims_name):
     events = []
     for t in range(n_ticks):
         for s in range(S):
-            g.add_audio_chunk(s, wire[s][t * CHUNK:(t + 1) * CHUNK].tobytes())
+            g.add_audio_chunk(s, wire[s][t * CHUNK:(t + 1) * CHUNK].tobytes(), timestamp=1000.0 + 0.064 * (t + 1))
         events.extend(g.tick(energy_vad, now=1000.0 + 0.064 * (t + 1)))
     finals = [e for e in events if e["type"] == "final"]
     partials = [e for e in events if e["type"] == "partial"]
@@ -54,7 +54,10 @@ def test_128_sessions_gate_to_ring_decodes(dims_name):
     for e in (finals[::9] + partials[::41] if full else finals + partials[::7]):
         s = int(e["session"].split("-")[1])
         a, n = e["first_sample"], e["n_samples"]
-        max_new = 15 if e["type"] == "partial" else min(50 + int(n / 16000 * 5), 200)
+        # a final's budget follows segment_duration = min(audio length, timestamp span of the segment) (connection_manager.py:186-192)
+        max_new = 15 if e["type"] == "partial" else min(50 + int(e["seconds"] * 5), 200)
+        if e["type"] == "final":
+            assert 0 < e["seconds"] <= n / 16000
         want = m.transcribe(frontend.pcm_bytes_to_float(wire[s][a:a + n].tobytes()), 16000, max_new_tokens=max_new)
         assert e["future"].result(timeout=120) == want, (e["type"], s)
         checked += 1
@@ -72,7 +75,7 @@ def test_queued_max_length_request_survives_appends():
     """A 30 s final that waits in the queue while 64 ms chunks keep arriving (8 s of them here) must still find its oldest samples:
     the ring is larger than the visible buffer by a margin (asr.AudioStream)."""
     from sonicscribe_amd.asr import ASRModel
-    m = ASRModel.from_synthetic(spec.TINY, device="cuda:0", max_batch=4, max_ctx=1024)
+    m = ASRModel.from_synthetic(spec.TINY, device="cuda:0", max_batch=4, max_ctx=1024, slots=1)      # (one slot: the request below must queue behind the blocker)
     st = m.open_stream("c", buffer_seconds=30.0)
     raw = synth.synth_pcm(77, 38 * 16000)
     for i in range(0, 30 * 16000, CHUNK):
