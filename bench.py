@@ -578,14 +578,17 @@ def main():
                     out[key] = {"value": None, "note": f"not measured: {ex!r}"}
             # BASELINE config 5's call pattern at its per-GPU share (128 sessions / 8 GPUs = 16), real-time schedule, device-resident ingest
             try:
-                sa = argparse.Namespace(dims="full", sessions=16, gpus=1, replicas_per_gpu=1, mode="native", batch=BATCH, ingest="ring", slots=a.slots, single=True)
+                # continuous scheduling (dispatch._ContinuousReplica: the engine decodes forever over its rows, one slot prefills), decode chunks of 2 steps
+                sa = argparse.Namespace(dims="full", sessions=16, gpus=1, replicas_per_gpu=1, mode="native", batch=BATCH, ingest="ring", slots=2, single=True,
+                                        continuous=True, opt=["decode_chunk=2"])
                 st = streaming_measure(sa)
-                out["streaming"] = {k: st[k] for k in ("sessions", "partial_latency_ms", "final_latency_ms", "value", "unit", "wall_s", "ingest", "device_batches_per_replica", "slots")}
+                out["streaming"] = {k: st[k] for k in ("sessions", "partial_latency_ms", "final_latency_ms", "value", "unit", "wall_s", "ingest", "device_batches_per_replica", "slots", "continuous")}
                 for k in ("single_5s", "single_20s"):            # BASELINE config 1's call shape, measured on the same model object
                     if k in st:
                         out[k] = st[k]
                 out["streaming"]["note"] = ("BASELINE config 5 call pattern: 16 sessions (128 / 8 GPUs) x (64 ms chunks into device rings, 1 s partials of 1.28 s / 15 "
-                                            "tokens, one 20 s final / 150 tokens), real-time schedule through ASRModel.submit(); latency = submit -> transcript")
+                                            "tokens, one 20 s final / 150 tokens), real-time schedule through ASRModel.submit(); latency = submit -> transcript; row-level "
+                                            "scheduling (ASRModel(continuous=True)): requests join and leave a running greedy loop row by row")
             except Exception as ex:
                 out["streaming"] = {"value": None, "note": f"not measured: {ex!r}"}
             _quiet.__exit__(None, None, None)

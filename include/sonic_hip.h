@@ -26,8 +26,7 @@
  *   sonic_device_info          torch.version.cuda / torch.cuda.get_device_name() / get_device_properties(0).total_memory
  *                              in ASRModel.get_model_info                   asr.py:501-506
  *   sonic_memory_info          torch.cuda.memory_allocated() / memory_reserved() in the debug dict  asr.py:453-457
- *   sonic_release_pool         (part of) torch.cuda.empty_cache() after `del asr_model.model`  backend/main.py:84-90
- *   sonic_destroy              `del asr_model.model`                      backend/main.py:84-86
+ *   sonic_destroy              `del asr_model.model` + torch.cuda.empty_cache(): every device byte goes back   backend/main.py:84-90
  *   sonic_last_error           the exception text re-raised at            asr.py:469-481
  */
 #ifndef SONIC_HIP_H
@@ -96,15 +95,9 @@ SONIC_API void sonic_destroy(sonic_engine* e);
 SONIC_API const char* sonic_last_error(sonic_engine* e); /* e may be NULL: error of the last failed sonic_create on this thread */
 /* name (NUL-terminated, truncated to name_cap), total / currently free device memory, hipRuntimeGetVersion(); any output may be NULL */
 SONIC_API int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_bytes, int64_t* free_bytes, int32_t* hip_runtime_version);
-/* allocated: bytes of this engine's live device allocations; reserved: allocated + the uncached blocks destroyed engines left in the
- * process-wide pool of this engine's device (sonic_destroy parks them, the next engine that needs the same size takes them) */
+/* allocated: bytes of this handle's live device allocations (a slot: its own buffers; the weights are its owner's); reserved = allocated
+ * (no caching allocator under the engine: sonic_destroy returns everything to the driver) */
 SONIC_API int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes);
-/* frees the pooled uncached blocks of device_id (< 0: every device) after a device synchronise and a system-scope cache write-back +
- * invalidate; returns the bytes freed, 0 while an engine is still alive on the device.  The pool only holds the per-step activation
- * buffers (tens of MB per engine shape; weights and the KV cache are ordinary allocations that sonic_destroy frees), and it is NOT
- * released automatically: on this stack, memory recycled from uncached to ordinary allocations came back with stale cache lines
- * (DESIGN.md 4).  Call it only when the process will not allocate device memory again, or to measure. */
-SONIC_API int64_t sonic_release_pool(int device_id);
 
 /* Another batch in flight on the SAME weight copy.  The reference keeps up to three decodes in flight on its one model object in file
  * mode (backend/main.py:429-445, asyncio.Semaphore(3) + run_in_executor at :616-624) and serialises them on the device; here a slot is a

@@ -51,9 +51,8 @@ struct sonic_engine {
     std::mutex mu;
     std::string err;
     std::vector<void*> allocs;
-    std::vector<std::pair<void*, size_t>> uc_allocs;     // uncached blocks: returned to the process-wide pool, never to hipFree
     int64_t weight_bytes = 0, alloc_bytes = 0;      // alloc_bytes: every live device allocation of this engine (sonic_memory_info)
-    bool finalized = false, registered = false;
+    bool finalized = false;
 
     std::map<std::string, DevTensor> raw;
     // packed weights
@@ -199,88 +198,15 @@ template <typename Tt> static int dalloc(sonic_engine* e, Tt** p, size_t n, bool
     *p = (Tt*)q;
     return SONIC_OK;
 }
-// Uncached (MTYPE UC) allocations for everything the decode graph streams exactly once per token step or hands from one kernel to the
-// next: the per-step activation buffers (x, slabs, partials - a few MB written by one kernel and read by the next), the fragment-tiled
-// weight copies and the KV cache.  Nothing of theirs then sits in (or has to be written back from) an XCD's L2 at a kernel boundary,
-// and the L2 keeps the X images the blocks of a kernel share.  Measured on the 149-step decode of the bench: 208.1 -> 204.8 ms with
-// the activation buffers alone, a further -1.8 ms with the KV cache and -0.6 ms with the tiled weights.  Falls back to hipMalloc.
-//
-// Uncached blocks are NEVER handed back to hipFree: sonic_destroy parks them in a process-wide pool and later engines reuse them (exact
-// size, same device).  Round 2 found that memory recycled between uncached and ordinary allocations comes back with stale data at
-// cache-line granularity: with engines and test buffers created and destroyed in one process, ordinary buffers that reused formerly
-// uncached pages read back wrong rows (test_gemm256_path: 3 of 5 full-suite runs failed, 0 of 6 with uncached allocations disabled).
-// A production process creates its engines once, so it never recycled; the pool makes the test processes safe as well.
-static std::mutex g_uc_mu;
-static std::multimap<std::pair<int, size_t>, void*> g_uc_pool;
-static std::map<int, int> g_live_engines;                      // engines alive per device (under g_uc_mu)
-static int64_t uc_pooled_bytes(int dev) {
-    std::lock_guard<std::mutex> lk(g_uc_mu);
-    int64_t b = 0;
-    for (auto& it : g_uc_pool) if (it.first.first == dev) b += (int64_t)it.first.second;
-    return b;
-}
-static void* uc_take(int dev, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_uc_mu);
-    auto it = g_uc_pool.find({dev, bytes});
-    if (it == g_uc_pool.end()) return nullptr;
-    void* p = it->second; g_uc_pool.erase(it); return p;
-}
-static void uc_give(int dev, size_t bytes, void* p) { std::lock_guard<std::mutex> lk(g_uc_mu); g_uc_pool.insert({{dev, bytes}, p}); }
-// System-scope release + acquire on every CU: writes back and invalidates the vector caches and every XCD's L2, so no cache holds a line
-// (clean or dirty) of memory that is about to change owner and cacheability.
-__global__ void cache_flush_kernel() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, ""); }
-// Frees the pooled uncached blocks of a device (dev < 0: all).  Only while no engine lives there: the blocks of a live engine are not in
-// the pool, but a purge in the middle of another engine's run would put a device synchronise into it.
-extern "C" int64_t sonic_release_pool(int device_id) {
-    std::vector<std::pair<int, void*>> blocks;
-    int64_t bytes = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_uc_mu);
-        for (auto it = g_uc_pool.begin(); it != g_uc_pool.end();) {
-            const int dev = it->first.first;
-            if ((device_id < 0 || dev == device_id) && g_live_engines[dev] <= 0) { blocks.push_back({dev, it->second}); bytes += (int64_t)it->first.second; it = g_uc_pool.erase(it); }
-            else ++it;
-        }
-    }
-    if (blocks.empty()) return 0;
-    int cur = 0; (void)hipGetDevice(&cur);
-    int last = -1;
-    for (auto& b : blocks) {
-        if (b.first != last) {
-            (void)hipSetDevice(b.first);
-            (void)hipDeviceSynchronize();
-            hipLaunchKernelGGL(cache_flush_kernel, dim3(4096), dim3(64), 0, 0);
-            (void)hipDeviceSynchronize();
-            last = b.first;
-        }
-        (void)hipFree(b.second);
-    }
-    (void)hipSetDevice(cur);
-    (void)hipGetLastError();
-    return bytes;
-}
-template <typename Tt> static int dalloc_uc(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
-    const size_t bytes = ((n ? n : 1) * sizeof(Tt) + 3) / 4 * 4;
-    void* q = getenv("SONIC_NO_UC") ? nullptr : uc_take(e->device, bytes);
-    if (!q) {
-        if (getenv("SONIC_NO_UC") || hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return dalloc(e, p, n, zero); }
-    }
-    e->uc_allocs.push_back({q, bytes}); e->alloc_bytes += (int64_t)bytes;
-    if (zero) zero_fill(e, q, bytes);
-    *p = (Tt*)q;
-    return SONIC_OK;
-}
-template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) { return dalloc_uc(e, p, n, true); }
-// The big once-per-step streams (KV cache, fragment-tiled weight copies; GiB) are ORDINARY allocations since round 3: pooled uncached
-// blocks are never returned to the driver (see above), so a model reload with other sizes kept the old KV cache and weight copies -
-// and releasing the pool with the last engine brought the stale-line corruption straight back (tests/test_gpu_int8.py failed in the
-// first full-suite run with the release enabled, although tools/uc_recycle_repro.hip reproduces neither of the two mechanisms tried).
-// Uncached + pooled stays for the per-step activation buffers only (tens of MB per engine shape).  Cost measured with bench.py: the
-// uncached KV cache / weights were worth 2.4 ms of a 311 ms step in round 2.  SONIC_UC_BIG=1 restores them for A/B runs.
-template <typename Tt> static int dalloc_big(sonic_engine* e, Tt** p, size_t n, bool zero = true) {
-    if (getenv("SONIC_UC_BIG")) return dalloc_uc(e, p, n, zero);
-    return dalloc(e, p, n, zero);
-}
+// Every device buffer is an ordinary hipMalloc allocation that sonic_destroy hands back to the driver (`del asr_model.model` is expected to
+// return the VRAM: backend/main.py:84-90).  Rounds 2-3 kept the per-step activation buffers (and, in round 2, the KV cache and the tiled
+// weights) in uncached (MTYPE UC) memory, parked in a process-wide pool that was never freed, because memory recycled between uncached and
+// ordinary allocations came back with stale cache lines on this stack (tests/test_gemm256_path failed in 3 of 5 full-suite runs; root cause
+// never found, tools/uc_recycle_repro.hip excludes two mechanisms).  Round 4 measured what the uncached buffers were still worth: nothing
+// (bench.py, one box, SONIC_NO_UC=1 vs default: 126.27 vs 126.17 segments/s with two slots, 103.3 vs 103.6 one batch at a time - inside the
+// run-to-run spread), so the uncached path, its pool and sonic_release_pool are gone rather than kept alive for an unmeasurable gain.
+template <typename Tt> static int dalloc_act(sonic_engine* e, Tt** p, size_t n) { return dalloc(e, p, n, true); }
+template <typename Tt> static int dalloc_big(sonic_engine* e, Tt** p, size_t n, bool zero = true) { return dalloc(e, p, n, zero); }
 #define TRY(x) do { int _s = (x); if (_s != SONIC_OK) return _s; } while (0)
 // every locked C-ABI entry: serialise on the engine, select its device, and hand its experiment knobs to the launchers
 // (hipGetLastError first: the slot is per thread and sticky, so a failure some earlier call of this thread ignored would otherwise
@@ -564,7 +490,6 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     if (s == SONIC_OK) s = build_constants(e);
     if (s == SONIC_OK && hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
     if (s != SONIC_OK) { g_create_err = e->err; sonic_destroy(e); return s; }
-    { std::lock_guard<std::mutex> lk(g_uc_mu); g_live_engines[device_id] += 1; e->registered = true; }
     *out = e;
     return SONIC_OK;
 }
@@ -598,7 +523,6 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     e->opt_decode_chunk = root->opt_decode_chunk; e->opt_svc_priority = root->opt_svc_priority;
     e->weight_bytes = 0; e->finalized = true; e->owner = root;
     root->slots.push_back(e);
-    { std::lock_guard<std::mutex> lk2(g_uc_mu); g_live_engines[e->device] += 1; e->registered = true; }
     *out = e;
     return SONIC_OK;
 }
@@ -629,9 +553,6 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     e->rings.clear();
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : e->allocs) (void)hipFree(p);
-    for (auto& u : e->uc_allocs) uc_give(e->device, u.second, u.first);
-    bool last_on_device = false;
-    if (e->registered) { std::lock_guard<std::mutex> lk(g_uc_mu); last_on_device = --g_live_engines[e->device] <= 0; }
     if (e->dump) (void)hipFree(e->dump);
     if (e->force_d) (void)hipFree(e->force_d);
     if (e->taps) (void)hipFree(e->taps);
@@ -648,11 +569,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->st) (void)hipStreamDestroy(e->st);
     if (e->st_lo && e->st_lo != e->st) (void)hipStreamDestroy(e->st_lo);
     if (e->st_hi && e->st_hi != e->st) (void)hipStreamDestroy(e->st_hi);
-    const int dev = e->device;
     delete e;
-    // The pooled (small, per-step activation) blocks are NOT released here: recycling uncached memory through hipFree corrupts later
-    // allocations on this stack (dalloc_big above).  SONIC_RELEASE_POOL=1 releases them with the last engine of a device, for experiments.
-    if (last_on_device && getenv("SONIC_RELEASE_POOL")) (void)sonic_release_pool(dev);
 }
 
 extern "C" int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n) {
@@ -691,14 +608,14 @@ extern "C" int sonic_device_info(int device_id, char* name, int name_cap, int64_
     if (hip_runtime_version) { int v = 0; if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; } *hip_runtime_version = v; }
     return SONIC_OK;
 }
-// ... and what the debug dict of transcribe() reads from the caching allocator (asr.py:453-457): allocated = bytes in this engine's live
-// device allocations (weights, activations, KV cache, rings excluded), reserved = allocated + the uncached blocks parked in the process-wide
-// pool of its device (held by the process, handed to the next engine that asks for the same size)
+// ... and what the debug dict of transcribe() reads from the caching allocator (asr.py:453-457): allocated = bytes in this handle's live
+// device allocations (weights, activations, KV cache; rings excluded; a slot: its own buffers, the weights are its owner's); there is no
+// caching layer under the engine, so reserved = allocated
 extern "C" int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes) {
     if (!e) return SONIC_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (allocated_bytes) *allocated_bytes = e->alloc_bytes;
-    if (reserved_bytes) *reserved_bytes = e->alloc_bytes + uc_pooled_bytes(e->device);
+    if (reserved_bytes) *reserved_bytes = e->alloc_bytes;
     return SONIC_OK;
 }
 

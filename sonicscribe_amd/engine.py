@@ -28,7 +28,7 @@ EXPORTS = [
     "sonic_test_attention", "sonic_test_decode_attention", "sonic_test_layernorm", "sonic_bench_gemm", "sonic_bench_skinny", "sonic_set_option", "sonic_debug_read", "sonic_debug_ktrace", "sonic_test_skinny_gu",
     "sonic_set_forced_ids", "sonic_test_greedy", "sonic_test_linear_int8",
     "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
-    "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info", "sonic_release_pool",
+    "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info",
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
     "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row",
 ]
@@ -128,8 +128,6 @@ def load_library():
     lib.sonic_decode_step.argtypes = [vp, C.c_int, ip, ip]
     lib.sonic_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, i64p, i64p, ip]
     lib.sonic_memory_info.argtypes = [vp, i64p, i64p]
-    lib.sonic_release_pool.argtypes = [C.c_int]
-    lib.sonic_release_pool.restype = C.c_int64
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.sonic_test_linear_int8.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -420,7 +418,7 @@ class Engine:
         return int(na.value), int(done.value)
 
     def memory_info(self):
-        """(allocated, reserved) bytes: the engine's live device allocations / plus the uncached blocks pooled for its device."""
+        """(allocated, reserved) bytes of this handle's live device allocations (equal: there is no caching layer under the engine)."""
         a, r = C.c_int64(0), C.c_int64(0)
         self._check(self.lib.sonic_memory_info(self.h, C.byref(a), C.byref(r)))
         return int(a.value), int(r.value)
@@ -615,12 +613,6 @@ def device_info(device_id: int = 0) -> dict:
     if lib.sonic_device_info(int(device_id), name, 256, C.byref(tot), C.byref(fr), C.byref(ver)) != 0:
         raise RuntimeError((lib.sonic_last_error(None) or b"").decode())
     return {"name": name.value.decode(), "total_bytes": int(tot.value), "free_bytes": int(fr.value), "hip_runtime_version": int(ver.value)}
-
-
-def release_pool(device_id: int = -1) -> int:
-    """Hand the uncached blocks parked by destroyed engines back to the driver (all devices when device_id < 0); returns the bytes freed.
-    Refused (returns 0) while an engine is alive on the device."""
-    return int(load_library().sonic_release_pool(int(device_id)))
 
 
 def device_count() -> int:
