@@ -234,7 +234,7 @@ SONIC_API int sonic_debug_read(sonic_engine* e, const char* name, int index, flo
  * "ktrace" = layer index is set: out[slot][block < 512][8 points], slots 0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down */
 SONIC_API int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n);
 /* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
- * "no_graph" (eager decode loop), "decode_chunk" (token steps per hipGraph launch = granularity of the early-stop check, default 4),
+ * "no_graph" (eager decode loop), "decode_chunk" (token steps per hipGraph launch = granularity of the early-stop check and of row splices, default 2),
  * "decode_lookahead" (start value of the adaptive queue depth of the decode loop, in chunks), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
  * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table) */
 SONIC_API int sonic_set_option(sonic_engine* e, const char* key, int value);

@@ -36,7 +36,7 @@ from .spec import FULL, ModelDims
 DEFAULT_SLOTS = 2
 # Row-level scheduling (dispatch._ContinuousReplica): the replica's engine decodes forever over its rows, the slot prefills; requests join and
 # leave row by row.  False: batch by batch (dispatch._Replica), every slot runs whole batches.
-DEFAULT_CONTINUOUS = False
+DEFAULT_CONTINUOUS = True
 
 
 # --------------------------------------------------------------------------------------- prompts

@@ -58,6 +58,7 @@ struct LaunchOpts {
     int skinny_variant = 0;    // 0: shared-X kernel where the shape allows, else one-shot; 2: one-shot nt; 3: one-shot plain loads; 9: read floor (bench only)
     int gemm_force128 = 0;     // route every GEMM to the 128x128 kernel
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
+    int no_fused_gu64 = 0;     // ... only for batches of 33 .. 64 rows (round 3's path there; A/B)
     int no_skinny768 = 0;      // decode skinny GEMM: never the 768-deep K slices (A/B)
     int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)
     int no_skinny_i8_wide = 0; // int8 decode skinny GEMM: always 32 rows x 1024 per block (A/B)

@@ -136,7 +136,7 @@ struct sonic_engine {
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
     int opt_svc_priority = 1;      // continuous decoding runs on a high-priority stream: its small latency-bound kernels go ahead of the prefill slots' GEMM tiles
-    int opt_decode_chunk = 4;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
+    int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
     int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
     std::vector<struct sonic_ring*> rings;          // rings created on this engine and not yet destroyed (freed with the engine at the latest)
@@ -2253,6 +2253,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "skinny_variant")) { e->opts.skinny_variant = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "no_fused_gu64")) { e->opts.no_fused_gu64 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "i8_no_lnq")) { e->opt_i8_no_lnq = value; return SONIC_OK; }      // int8 encoder: LayerNorm does not quantise its rows (A/B)
     if (!strcmp(key, "i8_no_qkv_fuse")) { e->opt_i8_no_qkv_fuse = value; return SONIC_OK; }   // int8 encoder: RoPE and V^T as their own passes (A/B)

@@ -545,7 +545,10 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
 // with the VALU work instead of queueing every load first and normalising with the memory pipe idle.
 struct GuNorm { const float* SS; int nblk; const float* w; float eps; };   // SS[nblk / 4][32][4] partials, norm weight w
 
-template <int MB, int KS8, int TPB, bool NORM>
+// NP = 2 (33 .. 64 rows): the block makes a second pass over rows 32 .. 63 - X image staged into the same LDS, the W fragments are still in
+// registers - so W is streamed once for all 64 rows and every row sees exactly the arithmetic of the one-pass kernel (same k order, same
+// reduction tree): a request's result does not depend on whether its batch has 8, 32 or 64 rows.
+template <int MB, int KS8, int TPB, bool NORM, int NP = 1>
 __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* act, int ff, GuNorm nm) {
     constexpr int K = KS8 * 256, NKB = K / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048, WTOT = TPB * KS8;
     static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
@@ -723,6 +726,80 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         if (m < a.M) act[(long)m * ff + blockIdx.x * NC + c] = f2bf(rbf(silu_f(rbf(gs))) * rbf(us));
     }
     KT(a, 6);
+    if constexpr (NP == 2) {
+        // ---- second pass: rows 32 .. 63.  No load is in flight any more (W landed in pass one), so plain waits do.
+        const int M2 = a.M - 32;                                        // > 0 by the launcher
+        __syncthreads();                                                // the epilogue above is done with the LDS image
+        float rl_scale = 0.f;
+        if (NORM) {
+            const int rl = lane & 31;
+            const float* sp = nm.SS + (long)(K / 64) * 128 + ((long)(lane >> 5) * SSN * 32 + rl) * 4;      // region of rows 32 .. 63
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < SSN; ++i) { const f32x4 v = *(const f32x4*)(sp + (long)i * 128); t += v[0]; t += v[1]; t += v[2]; t += v[3]; }
+            t = t + __shfl_xor(t, 32, 64);
+            rl_scale = 1.0f / sqrtf(t / (float)K + nm.eps);
+        }
+#pragma unroll
+        for (int t = 0; t < PW; ++t) {
+            const int ii = wk * PW + t, kblock = ii / RG, rg = ii % RG;
+            int row = rg * 8 + lr; row = row < M2 ? row : M2 - 1;
+            const bf16_t* src = a.X + (long)(32 + row) * a.ldx + kblock * 64 + lc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NORM) {
+            // every lane rewrites the 16 bytes its own DMA deposited (as in pass one); nw still holds this wave's norm weights
+#pragma unroll
+            for (int tt = 0; tt < PW; ++tt) {
+                const int ii = wk * PW + tt, rg = ii % RG, kb = tt / RG;
+                int row = rg * 8 + lr; row = row < M2 ? row : M2 - 1;
+                const float rr = __shfl(rl_scale, row, 64);
+                bf16x8* px = (bf16x8*)(smem + ii * 1024 + lane * 16);
+                const bf16x8 xv = *px;
+                const f32x4 w0 = nw[kb * 2], w1 = nw[kb * 2 + 1];
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = f2bf(w0[j] * rbf(bf2f(xv[j]) * rr)); o[4 + j] = f2bf(w1[j] * rbf(bf2f(xv[4 + j]) * rr)); }
+                *px = o;
+            }
+        }
+        if constexpr (KS8 < 2) __syncthreads();                          // (a wave reads other waves' pieces only when its K eighth is half a K block)
+        f32x4 acc2[TPB][MB];
+#pragma unroll
+        for (int j = 0; j < TPB; ++j)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc2[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KS8; ++u) {
+            const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mb * 16 + r;
+                const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < TPB; ++j) acc2[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xf, acc2[j][mb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPB; ++j)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) red[((wk * TPB + j) * MB + mb) * 64 + lane] = acc2[j][mb];
+        __syncthreads();
+        for (int o = tid; o < NC * mpad; o += 512) {
+            const int m = o / NC, c = o % NC, j = c >> 3, cc = c & 7, mb = m >> 4;
+            const int lg = (cc >> 2) * 16 + (m & 15), lu = lg + 32, e = cc & 3;
+            float gs = 0.f, us = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gs += red[((k * TPB + j) * MB + mb) * 64 + lg][e];
+                us += red[((k * TPB + j) * MB + mb) * 64 + lu][e];
+            }
+            if (m < M2) act[(long)(32 + m) * ff + blockIdx.x * NC + c] = f2bf(rbf(silu_f(rbf(gs))) * rbf(us));
+        }
+    }
 }
 
 // skinny_o_kernel: decode-step o_proj with the residual add fused (modeling_llama.py:306-309).  Like skinny_gu_kernel the block sees the
@@ -796,30 +873,32 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
         float t = 0.f;
 #pragma unroll
         for (int c = 0; c < 16; ++c) t += sq[tid * 16 + c];
-        SS[((long)(blockIdx.x >> 2) * 32 + row0 + tid) * 4 + (blockIdx.x & 3)] = t;      // [block / 4][32 rows][4], see skinny_gu_kernel
+        // [row0 / 32][block / 4][32 rows][4]: one region per 32 rows (the consumer stages 32 rows per pass), see skinny_gu_kernel
+        SS[((long)(row0 >> 5) * (gridDim.x >> 2) * 32 + (long)(blockIdx.x >> 2) * 32 + (row0 & 31) + tid) * 4 + (blockIdx.x & 3)] = t;
     }
     KT(a, 5);
 }
 
-template <int MB, int KS8, int TPB, bool NORM> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
+template <int MB, int KS8, int TPB, bool NORM, int NP = 1> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
     const size_t lds = (size_t)(KS8 * 4) * MB * 2048;               // X image
     const size_t redb = (size_t)8 * TPB * MB * 1024;
     const size_t need = lds > redb ? lds : redb;
-    if (need > 65536) ensure_dyn_lds((const void*)skinny_gu_kernel<MB, KS8, TPB, NORM>, (int)need);
-    hipLaunchKernelGGL((skinny_gu_kernel<MB, KS8, TPB, NORM>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, act, a.N / 2, nm);
+    if (need > 65536) ensure_dyn_lds((const void*)skinny_gu_kernel<MB, KS8, TPB, NORM, NP>, (int)need);
+    hipLaunchKernelGGL((skinny_gu_kernel<MB, KS8, TPB, NORM, NP>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, act, a.N / 2, nm);
 }
 // true if the fused kernel handles this shape (else: skinny GEMM + swiglu_slab_kernel)
 bool skinny_gu_eligible(int M, int N, int K) {
     if (g_opts.no_fused_gu) return false;
     const int mb = (M + 15) / 16;
-    if (mb > 2 || N % 32 || N / 32 < 128) return false;
+    if (mb > 4 || N % 32 || N / 32 < 128 || (mb > 2 && g_opts.no_fused_gu64)) return false;
     return K == 256 || K == 512 || K == 1024 || K == 2048;
 }
 template <bool NORM> static void launch_gu_any(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
     const int mb = (a.M + 15) / 16;
     const bool t3 = (a.N / 16) % 3 == 0;                             // 3 tiles per block where the tile count allows (768 tiles -> 256 blocks)
 #define GU(KS8) do { if (mb <= 1) { if (t3) launch_gu_v<1, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<1, KS8, 2, NORM>(a, act, nm, s); } \
-                     else { if (t3) launch_gu_v<2, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM>(a, act, nm, s); } } while (0)
+                     else if (mb <= 2) { if (t3) launch_gu_v<2, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM>(a, act, nm, s); } \
+                     else { if (t3) launch_gu_v<2, KS8, 3, NORM, 2>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM, 2>(a, act, nm, s); } } while (0)   /* 33 .. 64 rows: two passes of 32 */
     switch (a.K) { case 256: GU(1); break; case 512: GU(2); break; case 1024: GU(4); break; default: GU(8); break; }
 #undef GU
 }
@@ -837,7 +916,7 @@ template <int KS8> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ld
 }
 bool skinny_o_eligible(int M, int N, int K) {
     if (g_opts.no_fused_gu) return false;
-    if (M > 32 || N % 16) return false;
+    if (M > 64 || N % 16 || (M > 32 && g_opts.no_fused_gu64)) return false;
     return K == 256 || K == 512 || K == 1024 || K == 2048;
 }
 void launch_skinny_o(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
