@@ -385,6 +385,8 @@ def main():
                     "with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="ranks use device LOCAL_RANK mod device count (exercise the N-rank path on fewer GPUs; not a scaling measurement)")
     ap.add_argument("--slots", type=int, default=3, help="batches of --batch segments in flight per GPU on one engine / one weight copy (sonic_slot_create); 1 = rounds 1-3's definition")
+    ap.add_argument("--pipeline", default="2x64+1", help="the headline leg: bulk pipeline 'DxR+P' = D decoding handles looping continuously over R rows each + P "
+                    "prefill slots, all on the engine's one weight copy (sonicscribe_amd/pipeline.py); 'off' = the headline is the --slots leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects int8_b64 / streaming / pcie_inclusive of the N=1 line")
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -421,7 +423,13 @@ def main():
     dims = replace(base, eos_ids=())       # random weights: never stop early, every row does the full 150 steps
     B = a.batch
     from sonicscribe_amd.engine import MODE_INT8, MODE_NATIVE
-    eng = Engine(dims, device_index, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=B, max_ctx=512)
+    pipe_cfg = None
+    if a.pipeline != "off":
+        dxr, n_pre = a.pipeline.split("+")
+        pipe_cfg = (int(dxr.split("x")[0]), int(dxr.split("x")[1]), int(n_pre))             # decoders, rows per decoder, prefill slots
+        if pipe_cfg[1] % B or pipe_cfg[1] > 64:
+            raise SystemExit("--pipeline rows must be a multiple of --batch and at most 64")
+    eng = Engine(dims, device_index, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=max(B, pipe_cfg[1]) if pipe_cfg else B, max_ctx=512)
     eng.load_synthetic(20260128)
     for kv in a.opt:
         k, v = kv.split("=")
@@ -452,8 +460,9 @@ def main():
 
     # further batches in flight on the SAME weights: slot engines (their own stream / buffers / KV cache / graphs), each with the batch staged
     n_slots = max(1, a.slots)
+    n_handles = max(n_slots, pipe_cfg[0] + pipe_cfg[2]) if pipe_cfg else n_slots
     engines = [eng]
-    for k in range(1, n_slots):
+    for k in range(1, n_handles):
         sl = eng.slot()
         sl.stage_pcm(segs)
         sl.run_staged([prompt] * len(segs), [a.max_new] * len(segs))
@@ -495,8 +504,29 @@ def main():
         pipeline(a.steps)
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
-        slots_identical = all(all(np.array_equal(x, y) for x, y in zip(sl.fetch_tokens(len(segs), a.max_new), ids)) for sl in engines[1:])
+        slots_identical = all(all(np.array_equal(x, y) for x, y in zip(sl.fetch_tokens(len(segs), a.max_new), ids)) for sl in engines[1:n_slots])
         assert slots_identical, "a slot's tokens differ from the single-batch run of the same segments"
+    dt_slots = dt
+
+    # ---- leg C (headline): the bulk pipeline - decoding handles loop continuously over their rows, prefill slots splice whole batches in
+    pipe_info = None
+    if pipe_cfg:
+        from sonicscribe_amd.pipeline import ContinuousPipeline
+        nd, prow, npre = pipe_cfg
+        pipe = ContinuousPipeline(engines[:nd], engines[nd:nd + npre], block=B)
+        want_ids = ids
+        prompts_b, budgets_b = [prompt] * len(segs), [a.max_new] * len(segs)
+        run_pipe = lambda n: pipe.run(n, lambda p: p.prefill(prompts_b, budgets_b), lambda i, got: np.array_equal(got, want_ids[i]))
+        run_pipe(pipe.batches_in_flight)                       # warm-up: graphs of the row count, every handle touched
+        barrier()
+        t0 = time.perf_counter()
+        res = run_pipe(a.steps)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert res["batches"] == a.steps and res["wrong_rows"] == 0, f"pipeline: {res}"
+        pipe.close()
+        pipe_info = {"decoders": nd, "rows_per_decoder": prow, "prefill_slots": npre, "batches_in_flight": pipe.batches_in_flight, "rows_bit_identical_to_single_batch": True,
+                     "decode_chunks_queued": res["decode_chunks"]}
 
     # one extra, untimed step with HIP events around every encoder-layer GEMM launch (the 256 event records stay out of the timed region)
     eng.set_option("gemm_timing", 1)
@@ -508,6 +538,8 @@ def main():
         total_segments = n_gpus * B * a.steps
         value = total_segments / dt
         value_single = total_segments / dt_single
+        value_slots = total_segments / dt_slots
+        in_flight_n = pipe_info["batches_in_flight"] if pipe_info else n_slots
         PEAK_HBM_GBS = 8000.0
         d_ = dims
         qd, kvd = d_.dec_heads * d_.dec_head_dim, d_.dec_kv_heads * d_.dec_head_dim
@@ -525,19 +557,29 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8" if a.mode == "int8" else "bf16", "data": "synthetic",
             "rtf": 1.0 / (SEG_SECONDS * value),
-            "config": {"workload": (f"{n_slots} batches of {B} in flight, one engine, one weight copy ({weight_bytes / 2 ** 20:.0f} MiB; per-slot stream, activation "
-                                    f"buffers, KV cache, decode graphs): {a.steps} batches go round-robin to the slots through sonic_run_staged_async / sonic_wait, " if n_slots > 1
+            "config": {"workload": ((f"bulk pipeline on one engine / one weight copy ({weight_bytes / 2 ** 20:.0f} MiB): {pipe_info['decoders']} decoding handles each run ONE continuous greedy loop over "
+                                     f"{pipe_info['rows_per_decoder']} rows ({pipe_info['rows_per_decoder'] // B} batches of {B} per loop), {pipe_info['prefill_slots']} prefill slot(s) run log-mel + encoder + prompt forward + first "
+                                     f"token of whole batches and splice their rows into a free block (sonic_service_* / sonic_prefill / sonic_splice_rows / sonic_fetch_row, sonicscribe_amd/pipeline.py): "
+                                     f"up to {pipe_info['batches_in_flight']} batches of {B} in flight; {a.steps} batches timed from an empty pipeline to the last fetched row, every row's tokens equal the single-batch run's; ") if pipe_info else
+                                    (f"{n_slots} batches of {B} in flight, one engine, one weight copy ({weight_bytes / 2 ** 20:.0f} MiB; per-slot stream, activation "
+                                     f"buffers, KV cache, decode graphs): {a.steps} batches go round-robin to the slots through sonic_run_staged_async / sonic_wait, ") if n_slots > 1
                                     else "one batch in flight: ") +
                                    f"every batch = {B} synthetic {SEG_SECONDS} s 16 kHz segments per GPU, GLM-ASR-Nano dims ({a.dims}), {a.mode}, "
                                    f"log-mel + encoder + prefill + {a.max_new} greedy tokens, portable-PRNG weights; int16 PCM HBM-resident before the "
-                                   f"timed region, token ids fetched to the host after the clock stops (see pcie_inclusive for the host-to-host rate); "
-                                   f"ms_per_step = wall / batches; single_batch = the same K batches one at a time (the headline definition of rounds 1-3)",
-                       "batches_in_flight": n_slots, "weight_copies": 1, "weight_bytes": weight_bytes, "slots_bit_identical_to_single_batch": slots_identical,
+                                   f"timed region, token ids fetched to the host " + ("row by row as rows finish" if pipe_info else "after the clock stops") + " (see pcie_inclusive for the host-to-host rate); "
+                                   f"ms_per_step = wall / batches; batches_in_flight_slots = the same K batches as {n_slots} whole batches in flight (sonic_run_staged_async; round 4's first form); "
+                                   f"single_batch = the same K batches one at a time (the headline definition of rounds 1-3)",
+                       "pipeline": pipe_info,
+                       "batches_in_flight": in_flight_n, "weight_copies": 1, "weight_bytes": weight_bytes, "slots_bit_identical_to_single_batch": slots_identical,
                        "segments_per_gpu": B, "max_new_tokens": a.max_new, "parallelism": f"replica x{n_gpus} (segments sharded, no collective)",
                        "shard_of_rank0": [lo, hi], "dist_backend": (a.dist_backend if dist is not None else None), "share_gpu": bool(a.share_gpu)},
             # one batch at a time: the K steps of leg A (same barriers, same max over ranks); stages and roofline below are ITS device times
             "single_batch": {"value": value_single, "unit": "20s-segments/sec", "ms_per_step": dt_single / a.steps * 1e3, "steps": a.steps,
                              "rtf": 1.0 / (SEG_SECONDS * value_single)},
+            # whole batches in flight: the K steps of leg B (each slot runs complete batches through sonic_run_staged_async / sonic_wait; host-robust:
+            # a batch is queued whole by a native thread)
+            "batches_in_flight_slots": {"value": value_slots, "unit": "20s-segments/sec", "ms_per_step": dt_slots / a.steps * 1e3, "steps": a.steps, "slots": n_slots,
+                                        "bit_identical_to_single_batch": slots_identical},
             "stages_ms_per_step": {k: stage[k] / a.steps for k in ("mel_ms", "encoder_ms", "prefill_ms", "decode_ms")},
             # The time-dominant part of a step is the greedy decode loop (~2/3 of it): every token step streams the decoder's weights,
             # the tied lm_head and each sequence's KV cache exactly once -- HBM-bound.  One "launch" here is one token step (one hipGraph
@@ -549,7 +591,7 @@ def main():
                          "measured_in": "single_batch leg (the chain alone on the GPU); in_flight below is the whole-GPU rate of the headline leg",
                          # headline leg: every batch streams the same algorithmic decode bytes; divided by the WHOLE wall time (encoder and prefill
                          # of the other slot included), i.e. a lower bound of the HBM rate while several chains overlap
-                         "in_flight": {"batches_in_flight": n_slots, "achieved": a.steps * n_dec * (w_bytes + kv_bytes) / dt / 1e9, "unit": "GB/s",
+                         "in_flight": {"batches_in_flight": in_flight_n, "achieved": a.steps * n_dec * (w_bytes + kv_bytes) / dt / 1e9, "unit": "GB/s",
                                        "frac": a.steps * n_dec * (w_bytes + kv_bytes) / dt / 1e9 / PEAK_HBM_GBS,
                                        "note": "algorithmic decode bytes of all timed batches / wall time of the headline leg"},
                          "bytes_per_launch": w_bytes + kv_bytes, "avg_launch_ms": dec_ms, "launches_timed": n_dec * a.steps,

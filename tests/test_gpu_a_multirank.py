@@ -22,7 +22,7 @@ def test_two_ranks_share_one_gpu_through_torchrun():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
-           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--slots", "2"]
+           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--slots", "2", "--pipeline", "2x8+1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -30,7 +30,8 @@ def test_two_ranks_share_one_gpu_through_torchrun():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["config"]["share_gpu"] is True
     assert abs(out["value"] * out["ms_per_step"] / 1e3 - 2 * B) < 1e-6 * 2 * B      # whole-job segments / max-over-ranks time
-    assert out["config"]["batches_in_flight"] == 2 and out["config"]["weight_copies"] == 1
+    assert out["config"]["batches_in_flight"] == 5 and out["config"]["weight_copies"] == 1           # 2 decoders x (8 rows / 4) + 1 prefill slot
+    assert out["batches_in_flight_slots"]["slots"] == 2 and out["config"]["pipeline"]["rows_bit_identical_to_single_batch"] is True
     shards = {int(m.group(1)): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"\[bench\] rank (\d)/2 device 0 backend gloo segments \[(\d+), (\d+)\)", r.stderr)}
     assert shards == {0: shard_range(2 * B, 0, 2), 1: shard_range(2 * B, 1, 2)}, r.stderr[-1000:]
     assert shards[0][1] <= shards[1][0]                         # disjoint
@@ -44,14 +45,16 @@ def test_rccl_branch_at_world_size_one():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29733",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
-           "--dist-backend", "nccl", "--no-cpu-baseline", "--slots", "2"]
+           "--dist-backend", "nccl", "--no-cpu-baseline", "--slots", "2", "--pipeline", "2x8+1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-1000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == steps and out["config"]["dist_backend"] == "nccl"
-    assert out["config"]["batches_in_flight"] == 2 and out["config"]["slots_bit_identical_to_single_batch"] is True
+    assert out["config"]["batches_in_flight"] == 5 and out["config"]["slots_bit_identical_to_single_batch"] is True
+    assert out["config"]["pipeline"]["rows_bit_identical_to_single_batch"] is True
+    assert abs(out["batches_in_flight_slots"]["value"] * out["batches_in_flight_slots"]["ms_per_step"] / 1e3 - B) < 1e-6 * B
     assert abs(out["value"] * out["ms_per_step"] / 1e3 - B) < 1e-6 * B
     assert abs(out["single_batch"]["value"] * out["single_batch"]["ms_per_step"] / 1e3 - B) < 1e-6 * B
     assert "backend nccl" in r.stderr
