@@ -451,6 +451,11 @@ def main():
         for en in engines:
             en.lib.sonic_synchronize(en.h)
 
+    def cpu_s():                                               # user + system CPU seconds of this process (all threads, the engine's native ones included)
+        import resource
+        r = resource.getrusage(resource.RUSAGE_SELF)
+        return r.ru_utime + r.ru_stime
+
     def max_over_ranks(dt):
         if dist is None:
             return dt
@@ -475,6 +480,7 @@ def main():
         eng.rerun_staged()
     barrier()
     stage = {"mel_ms": 0.0, "encoder_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0}
+    c0 = cpu_s()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         eng.rerun_staged()                                     # synchronous: returns after the stream drained
@@ -482,6 +488,7 @@ def main():
         for k in stage:
             stage[k] += t[k]
     barrier()
+    host_cpu = {"single_batch": (cpu_s() - c0) / (time.perf_counter() - t0)}
     dt_single = max_over_ranks(time.perf_counter() - t0)
     ids = eng.fetch_tokens(len(segs), a.max_new)
     assert all(len(x) == a.max_new for x in ids)
@@ -500,9 +507,11 @@ def main():
                     engines[started % n_slots].run_staged_async(); started += 1
         pipeline(max(n_slots, min(a.warmup, 2 * n_slots)))   # warm-up in the same pattern
         barrier()
+        c0 = cpu_s()
         t0 = time.perf_counter()
         pipeline(a.steps)
         barrier()
+        host_cpu["batches_in_flight_slots"] = (cpu_s() - c0) / (time.perf_counter() - t0)
         dt = max_over_ranks(time.perf_counter() - t0)
         slots_identical = all(all(np.array_equal(x, y) for x, y in zip(sl.fetch_tokens(len(segs), a.max_new), ids)) for sl in engines[1:n_slots])
         assert slots_identical, "a slot's tokens differ from the single-batch run of the same segments"
@@ -516,12 +525,14 @@ def main():
         pipe = ContinuousPipeline(engines[:nd], engines[nd:nd + npre], block=B)
         want_ids = ids
         prompts_b, budgets_b = [prompt] * len(segs), [a.max_new] * len(segs)
-        run_pipe = lambda n: pipe.run(n, lambda p: p.prefill(prompts_b, budgets_b), lambda i, got: np.array_equal(got, want_ids[i]))
+        run_pipe = lambda n: pipe.run(n, lambda p: p.prefill(prompts_b, budgets_b, wait=False), lambda i, got: np.array_equal(got, want_ids[i]))
         run_pipe(pipe.batches_in_flight)                       # warm-up: graphs of the row count, every handle touched
         barrier()
+        c0 = cpu_s()
         t0 = time.perf_counter()
         res = run_pipe(a.steps)
         barrier()
+        host_cpu["pipeline"] = (cpu_s() - c0) / (time.perf_counter() - t0)
         dt = max_over_ranks(time.perf_counter() - t0)
         assert res["batches"] == a.steps and res["wrong_rows"] == 0, f"pipeline: {res}"
         pipe.close()
@@ -570,6 +581,7 @@ def main():
                                    f"ms_per_step = wall / batches; batches_in_flight_slots = the same K batches as {n_slots} whole batches in flight (sonic_run_staged_async; round 4's first form); "
                                    f"single_batch = the same K batches one at a time (the headline definition of rounds 1-3)",
                        "pipeline": pipe_info,
+                       "host_cpus_busy": host_cpu,      # CPU seconds per wall second of this process in each timed leg (rank 0): how much host the legs need
                        "batches_in_flight": in_flight_n, "weight_copies": 1, "weight_bytes": weight_bytes, "slots_bit_identical_to_single_batch": slots_identical,
                        "segments_per_gpu": B, "max_new_tokens": a.max_new, "parallelism": f"replica x{n_gpus} (segments sharded, no collective)",
                        "shard_of_rank0": [lo, hi], "dist_backend": (a.dist_backend if dist is not None else None), "share_gpu": bool(a.share_gpu)},

@@ -154,6 +154,9 @@ SONIC_API int sonic_wait(sonic_engine* e, int block, int32_t* busy_out);
 SONIC_API int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                   const int32_t* max_new, int want_step_logits);
 SONIC_API int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active_out, int32_t* steps_done_out);
+/* sonic_prefill without the closing wait: the work is queued on the handle's stream when the call returns (the splice of its rows into a
+ * continuously decoding handle orders itself behind it on the device; any other reader calls sonic_synchronize first) */
+SONIC_API int sonic_prefill_enqueue(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new);
 /* Continuous decoding: one handle decodes forever over its max_batch rows; requests join and leave ROW BY ROW instead of batch by batch.  The
  * reference awaits one transcribe() at a time per connection and blocks its event loop inside it (backend/connection_manager.py:127-245,
  * backend/transcription_manager.py:58); a batch engine makes a request wait for the running batch and pads every batch to its slowest row.

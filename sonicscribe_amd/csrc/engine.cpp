@@ -122,6 +122,7 @@ struct sonic_engine {
     int64_t svc_launched = 0, svc_checked = 0;                     // chunks queued / checks read since sonic_service_begin
     int* svc_h = nullptr;                                          // pinned ring [CHK_RING][SVC_WORDS]: finished[64] | n_new[64] | n_active
     int svc_fin[64]{}, svc_nn[64]{}, svc_active = 0; int64_t svc_seq = 0;   // the newest check read: state after chunk number svc_seq
+    hipEvent_t sync_ev = nullptr;                                  // blocking-sync event behind stream_sync()
     hipStream_t st_lo = nullptr, st_hi = nullptr;                  // st is one of these: the ordinary stream, or (continuous decoding, option "svc_priority") a high-priority one
     hipStream_t st_io = nullptr;                                   // row fetches (a finished row's ids are stable: no ordering against the queued chunks needed)
     hipEvent_t xfer_ev = nullptr, splice_ev = nullptr, wait_ev = nullptr; bool wait_pending = false;   // cross-handle ordering of a splice
@@ -165,13 +166,19 @@ static int fail(sonic_engine* e, int code, const char* fmt, ...) {
         }                                                                                                  \
     } while (0)
 
+// Wait for the engine stream WITHOUT spinning.  hipStreamSynchronize busy-waits on this runtime when the machine shows more CPUs than contexts
+// (256 visible): every waiting thread of every slot / rank burnt a CPU - 3.7 CPUs for three slots of one rank, far beyond a 16-CPU quota at eight
+// ranks, and a job that exhausts its quota has ALL its threads frozen.  An event created with hipEventBlockingSync sleeps on an
+// interrupt instead; the wake-up is slower by tens of microseconds, which the queued work hides (the decode loop keeps `lookahead` chunks ahead).
+static hipError_t stream_sync(sonic_engine* e);
+
 // Host -> device copy on the ENGINE stream, complete on return.  Never use the null-stream hipMemcpy for uploads: the
 // engine stream is non-blocking, so a null-stream copy is not ordered against work still queued on it (dalloc's zero fill
 // once wiped parts of a freshly uploaded RoPE table that way).
 static hipError_t h2d(sonic_engine* e, void* dst, const void* src, size_t bytes) {
     hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->st);
     if (r != hipSuccess) return r;
-    return hipStreamSynchronize(e->st);
+    return stream_sync(e);
 }
 
 // zero fill by a kernel on the engine stream (hipMemsetAsync on a non-blocking stream: see TmpBuf::get)
@@ -183,7 +190,12 @@ static hipError_t d2h_async(sonic_engine* e, void* dst, const void* src, size_t 
 }
 static hipError_t d2h(sonic_engine* e, void* dst, const void* src, size_t bytes) {
     hipError_t r = d2h_async(e, dst, src, bytes);
-    return r == hipSuccess ? hipStreamSynchronize(e->st) : r;
+    return r == hipSuccess ? stream_sync(e) : r;
+}
+static hipError_t stream_sync(sonic_engine* e) {
+    if (!e->sync_ev) return hipStreamSynchronize(e->st);
+    hipError_t r = hipEventRecord(e->sync_ev, e->st);
+    return r == hipSuccess ? hipEventSynchronize(e->sync_ev) : r;
 }
 static void zero_fill(sonic_engine* e, void* q, size_t bytes) {
     size_t left = bytes / 4; int* w = (int*)q;
@@ -324,7 +336,7 @@ static int build_constants(sonic_engine* e) {
     HIPC(e, hipMemcpyAsync(dlo, lo.data(), nm * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(dcnt, cnt.data(), nm * 4, hipMemcpyHostToDevice, e->st));
     HIPC(e, hipMemcpyAsync(doff, off.data(), nm * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     e->lc = LogmelConst{dwin, dct, dst, dlo, dcnt, doff, dw};
 
     // RoPE tables: cos/sin computed in fp32 and cast to the activation dtype (modeling_glmasr.py:95-106)
@@ -396,7 +408,10 @@ extern "C" void sonic_destroy(sonic_engine* e);
 // buffers, control words, events.
 static int alloc_state(sonic_engine* e) {
     if (hipSetDevice(e->device) != hipSuccess) { e->err = "hipSetDevice failed"; return SONIC_ERR_HIP; }
+    // waits sleep instead of spinning (see stream_sync): the runtime's default (hipDeviceScheduleAuto) spins when it sees more CPUs than GPUs
+    if (!getenv("SONIC_SPIN_SYNC") && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return SONIC_ERR_HIP; }
+    if (!getenv("SONIC_SPIN_SYNC") && hipEventCreateWithFlags(&e->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e->sync_ev = nullptr; }
     const sonic_dims& d = e->d;
     const int Bm = e->Bm, max_batch = e->Bm, max_ctx = e->max_ctx;
     e->T = d.enc_T; e->Tp = (d.enc_T + T_PAD_ALIGN - 1) / T_PAD_ALIGN * T_PAD_ALIGN; e->Ta = d.enc_T / d.merge; e->hd_e = d.enc_d / d.enc_heads;
@@ -467,7 +482,7 @@ static int alloc_state(sonic_engine* e) {
     e->gemm_ev.resize(8 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));   // per layer: [start, end] of the QKV, o, fc1, fc2 GEMM launches
     for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
 #undef A
-    for (auto& v : e->chk_ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
+    for (auto& v : e->chk_ev) if (hipEventCreateWithFlags(&v, (getenv("SONIC_SPIN_SYNC") ? 0 : hipEventBlockingSync) | hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->n_samples_h.assign(Bm, 0);
     return SONIC_OK;
 }
@@ -488,7 +503,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     e->i8 = mode == SONIC_MODE_INT8; e->dt = e->i8 ? DT_F16 : DT_BF16;
     int s = alloc_state(e);
     if (s == SONIC_OK) s = build_constants(e);
-    if (s == SONIC_OK && hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
+    if (s == SONIC_OK && stream_sync(e) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
     if (s != SONIC_OK) { g_create_err = e->err; sonic_destroy(e); return s; }
     *out = e;
     return SONIC_OK;
@@ -510,7 +525,7 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     sonic_engine* e = new sonic_engine();
     e->d = root->d; e->device = root->device; e->mode = root->mode; e->Bm = root->Bm; e->max_ctx = root->max_ctx; e->i8 = root->i8; e->dt = root->dt;
     int s = alloc_state(e);
-    if (s == SONIC_OK && hipStreamSynchronize(e->st) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
+    if (s == SONIC_OK && stream_sync(e) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
     if (s != SONIC_OK) { g_create_err = e->err; sonic_destroy(e); return s; }
     // the owner's weights and constants, by pointer (read-only on the request path)
     e->conv1w = root->conv1w; e->conv2w = root->conv2w; e->conv1b = root->conv1b; e->conv2b = root->conv2b;
@@ -548,7 +563,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
         for (sonic_engine* k : kids) { k->owner = nullptr; k->finalized = false; sonic_destroy(k); }   // slots first: they read this engine's weights
     }
     (void)hipSetDevice(e->device);
-    if (e->st) (void)hipStreamSynchronize(e->st);
+    if (e->st) (void)stream_sync(e);
     for (sonic_ring* r : e->rings) ring_free(r);       // rings the caller left behind go with their engine
     e->rings.clear();
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
@@ -565,6 +580,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->splice_ev) (void)hipEventDestroy(e->splice_ev);
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto& v : e->chk_ev) if (v) (void)hipEventDestroy(v);
+    if (e->sync_ev) (void)hipEventDestroy(e->sync_ev);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
     if (e->st) (void)hipStreamDestroy(e->st);
     if (e->st_lo && e->st_lo != e->st) (void)hipStreamDestroy(e->st_lo);
@@ -577,7 +593,7 @@ extern "C" int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n) {
     ENTER(e);
     if (!e->kt) return fail(e, SONIC_ERR_INVALID, "ktrace is off");
     const int64_t have = (int64_t)8 * KT_SLOT_BLOCKS * 8;
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, d2h(e, out, e->kt, (size_t)(n < have ? n : have) * 8));
     return SONIC_OK;
 }
@@ -586,7 +602,7 @@ extern "C" int64_t sonic_weight_bytes(sonic_engine* e) { return e ? e->weight_by
 extern "C" int sonic_synchronize(sonic_engine* e) {
     if (!e) return SONIC_ERR_INVALID;
     ENTER(e);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     return SONIC_OK;
 }
 
@@ -649,7 +665,7 @@ extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* 
         HIPC(e, hipMalloc((void**)&tmp, t->n * 4));
         hipError_t r = h2d(e, tmp, data, t->n * 4);
         // int8 mode loads the checkpoint with torch_dtype=float16 (asr.py:156): an fp32 source goes straight to fp16
-        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st, e->dt); r = hipStreamSynchronize(e->st); if (e->i8) e->raw_f16[name] = true; }
+        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st, e->dt); r = stream_sync(e); if (e->i8) e->raw_f16[name] = true; }
         (void)hipFree(tmp);
         HIPC(e, r);
     } else return fail(e, SONIC_ERR_INVALID, "dtype must be f32 or bf16");
@@ -670,7 +686,7 @@ extern "C" int sonic_load_synthetic(sonic_engine* e, uint64_t seed) {
         const uint64_t key = mix64h(seed * 0x9E3779B97F4A7C15ULL + fnv1a64h(it.name.c_str()));
         launch_synth_fill(key, (long)t->n, scale, offset, t->p, nullptr, e->st);
     }
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     return SONIC_OK;
 }
 
@@ -702,7 +718,7 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
             e->weight_bytes += (int64_t)N * K;
         }
     }
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w16) { e->allocs.erase(it); break; }
     (void)hipFree(*w16); *w16 = nullptr; e->alloc_bytes -= (int64_t)N * K * 2;
     return SONIC_OK;
@@ -806,7 +822,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
     launch_tile_weights(e->embed, e->embed_t, d.vocab, d.dec_d, e->st);
     e->weight_bytes += (int64_t)d.vocab * d.dec_d * 2;
     TRY(to_f32(e, lm + "norm.weight", &e->dec_nw));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     for (auto& kv : e->raw) if (kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; e->alloc_bytes -= (int64_t)kv.second.n * 2; }
     e->raw.clear();
     e->finalized = true;
@@ -966,7 +982,7 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
         mark(7);
         if (enc_layers_out) {
             launch_bf16_to_f32(e->x, tap, (long)M * C, e->st, dt);
-            HIPC(e, hipStreamSynchronize(e->st));
+            HIPC(e, stream_sync(e));
             for (int b = 0; b < W; ++b)
                 HIPC(e, d2h(e, enc_layers_out + ((size_t)b * d.enc_layers + l) * T * C, tap + (size_t)b * T * C, (size_t)T * C * 4));
         }
@@ -974,7 +990,7 @@ static int run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc
     launch_layernorm(e->x, e->enc_nw, e->enc_nb, e->ln, M, C, d.enc_ln_eps, e->st, dt);
     if (enc_out_host) {
         launch_bf16_to_f32(e->ln, tap, (long)M * C, e->st, dt);
-        HIPC(e, hipStreamSynchronize(e->st));
+        HIPC(e, stream_sync(e));
         HIPC(e, d2h(e, enc_out_host, tap, (size_t)M * C * 4));
     }
     if (tap) (void)hipFree(tap);
@@ -1387,7 +1403,7 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     int steps_done = 0;
     TRY(run_decode_steps(e, e->max_steps - 1, &steps_done));
     (void)hipEventRecord(e->ev[4], e->st);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     sonic_timings& t = e->tim;
     memset(&t, 0, sizeof t);
@@ -1424,7 +1440,7 @@ static int stage_pcm_locked(sonic_engine* e, const int16_t* pcm, const int64_t* 
         if (n > 0) HIPC(e, hipMemcpyAsync(e->pcm + (size_t)i * cap, pcm + offsets[i], (size_t)n * 2, hipMemcpyHostToDevice, e->st));
     }
     HIPC(e, hipMemcpyAsync(e->n_samples_d, e->n_samples_h.data(), (size_t)W * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     e->W = W;
     return SONIC_OK;
 }
@@ -1461,7 +1477,7 @@ extern "C" int sonic_ring_create(sonic_engine* e, int64_t capacity_samples, soni
         delete r; return fail(e, SONIC_ERR_HIP, "ring stream / event creation failed");
     }
     zero_fill(e, r->buf, (size_t)capacity_samples * 2);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     // rings live in the registry of the weight owner: every slot of an engine may stage from every ring of it
     sonic_engine* root = e->owner ? e->owner : e;
     r->e = root;
@@ -1594,7 +1610,7 @@ static int stage_mixed_locked(sonic_engine* e, int W, const int16_t* host_pcm, c
         launch_ring_stage(ra, W, max_n, e->st);
     }
     HIPC(e, hipMemcpyAsync(e->n_samples_d, e->n_samples_h.data(), (size_t)W * 4, hipMemcpyHostToDevice, e->st));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     e->W = W;
     return SONIC_OK;
@@ -1687,7 +1703,7 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     ENTER(e);
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
     if (e->svc_on) return SONIC_OK;
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     if (e->opt_svc_priority) {
         if (!e->st_hi) {
             int lo = 0, hi = 0;                                  // (numerically lower = higher priority)
@@ -1700,7 +1716,7 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     if (e->force_d) return fail(e, SONIC_ERR_INVALID, "teacher forcing is set: clear it before continuous decoding");
     hipGraphExec_t gx = nullptr;                            // the chunk graph exists before the first splice: nothing captures on this stream later
     TRY(chunk_graph(e, e->Bm, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     e->svc_launched = e->svc_checked = 0; e->svc_seq = 0; e->svc_active = 0;
     for (int b = 0; b < 64; ++b) { e->svc_fin[b] = 1; e->svc_nn[b] = 0; }
     e->R = 0; e->greedy_calls = 0;
@@ -1711,7 +1727,7 @@ extern "C" int sonic_service_end(sonic_engine* e) {
     if (!e) return SONIC_ERR_INVALID;
     ENTER(e);
     if (!e->svc_on) return SONIC_OK;
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     if (e->st_lo && e->st == e->st_hi) { drop_graphs_of(e); e->st = e->st_lo; }      // (graphs replay on any stream; dropped anyway so that each stream keeps its own)
     e->svc_on = false;
     return SONIC_OK;
@@ -1883,7 +1899,16 @@ extern "C" int sonic_prefill(sonic_engine* e, const int32_t* req_win, int R, con
     if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
     ENTER(e);
     TRY(run_to_first_token(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
+    HIPC(e, hipGetLastError());
+    return SONIC_OK;
+}
+// sonic_prefill without the closing wait: everything up to the first token is QUEUED on the handle's stream when the call returns.  For the
+// pipeline form: sonic_splice_rows orders its copies behind this work on the device, so the host need not come back between prefill and splice.
+extern "C" int sonic_prefill_enqueue(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new) {
+    if (!e || !prompt_ids || !prompt_off || !max_new) return SONIC_ERR_INVALID;
+    ENTER(e);
+    TRY(run_to_first_token(e, req_win, R, prompt_ids, prompt_off, max_new, false));
     HIPC(e, hipGetLastError());
     return SONIC_OK;
 }
@@ -1894,7 +1919,7 @@ extern "C" int sonic_decode_step(sonic_engine* e, int n_steps, int32_t* n_active
     int done = 0;
     TRY(run_decode_steps(e, n_steps, &done));
     HIPC(e, hipMemcpyAsync(e->n_active_h + CHK_RING, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     if (n_active_out) *n_active_out = e->n_active_h[CHK_RING];
     if (steps_done_out) *steps_done_out = done;
@@ -1909,7 +1934,7 @@ static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* 
     HIPC(e, d2h_async(e, kvl.data(), e->kv_len, 64 * 4));
     HIPC(e, d2h_async(e, tps.data(), e->tok_pos, 64 * 4));
     HIPC(e, d2h_async(e, fin.data(), e->finished, 64 * 4));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     // invariants of the greedy controller: a running row's context grows by one per launch; a finished row stopped growing with the
     // launch that finished it (kv_len = prompt + tokens - 1), so no row ever leaves its [max_ctx] cache region
     for (int r = 0; r < R && r < (int)e->last_qlen.size(); ++r) {
@@ -1931,7 +1956,7 @@ static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* 
         if (!e->dump_steps) return fail(e, SONIC_ERR_INVALID, "step logits were not requested for the last run");
         HIPC(e, d2h_async(e, step_logits, e->dump, (size_t)e->dump_steps * R * e->d.vocab * 4));
     }
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     return SONIC_OK;
 }
 
@@ -1956,7 +1981,7 @@ extern "C" int sonic_transcribe_batch(sonic_engine* e, const int16_t* pcm, const
 extern "C" int sonic_set_forced_ids(sonic_engine* e, const int32_t* ids, int R, int ld) {
     if (!e) return SONIC_ERR_INVALID;
     ENTER(e);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     if (e->force_d) { (void)hipFree(e->force_d); e->force_d = nullptr; e->force_ld = e->force_R = 0; }
     if (!ids) return SONIC_OK;
     if (R < 1 || R > e->Bm || ld < 1) return fail(e, SONIC_ERR_INVALID, "forced ids: bad shape [%d][%d]", R, ld);
@@ -1981,7 +2006,7 @@ extern "C" int sonic_logmel(sonic_engine* e, const int16_t* pcm, const int64_t* 
     ENTER(e);
     TRY(stage_pcm_locked(e, pcm, offsets, B));
     TRY(run_mel(e, B, feats_out != nullptr));
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     const sonic_dims& d = e->d;
     if (feats_out) HIPC(e, d2h(e, feats_out, e->feats_f32, (size_t)B * d.n_mels * d.n_frames * 4));
@@ -2009,7 +2034,7 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
     DT_SWITCH(e->dt, T, hipLaunchKernelGGL(feats_to_fm_kernel<T>, dim3((per + 255) / 256, B), dim3(256), 0, e->st, tmp, (T*)e->feats_fm, d.n_mels, d.n_frames));
     if (e->i8) HIPC(e, hipMemcpyAsync(e->win_req, e->seq_iota, (size_t)B * 4, hipMemcpyDeviceToDevice, e->st));   // every window its own request
     int s = run_encoder(e, B, enc_layers_out, enc_out, B);
-    hipError_t r2 = hipStreamSynchronize(e->st);
+    hipError_t r2 = stream_sync(e);
     (void)hipFree(tmp);
     TRY(s); HIPC(e, r2); HIPC(e, hipGetLastError());
     if (embeds_out) {
@@ -2017,7 +2042,7 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
         const size_t m = (size_t)B * e->Ta * d.dec_d;
         HIPC(e, hipMalloc((void**)&t2, m * 4));
         launch_bf16_to_f32(e->pe, t2, (long)m, e->st, e->dt);
-        hipError_t r3 = hipStreamSynchronize(e->st);
+        hipError_t r3 = stream_sync(e);
         if (r3 == hipSuccess) r3 = d2h(e, embeds_out, t2, m * 4);
         (void)hipFree(t2);
         HIPC(e, r3);
@@ -2063,7 +2088,7 @@ static int down_bf16(sonic_engine* e, TmpBuf& tb, const bf16_t* d, float* h, siz
     float* f = tb.get<float>(n);
     if (!f) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     launch_bf16_to_f32(d, f, (long)n, e->st, e->dt);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     HIPC(e, d2h(e, h, f, n * 4));
     return SONIC_OK;
@@ -2098,7 +2123,7 @@ extern "C" int sonic_test_skinny(sonic_engine* e, const float* X, const float* W
     launch_tile_weights(dW, dWt, N, K, e->st);
     SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.P = P; a.M = M; a.N = N; a.K = K; a.ksplit = ks; a.dt = e->dt;
     launch_skinny(a, e->st);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     std::vector<float> h((size_t)ks * mpad * N);
     HIPC(e, d2h(e, h.data(), P, h.size() * 4));
@@ -2208,7 +2233,7 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     (void)hipEventRecord(ea, e->st);
     for (int i = 0; i < iters; ++i) launch_gemm(a, epi, e->st);
     (void)hipEventRecord(eb, e->st);
-    hipError_t r = hipStreamSynchronize(e->st);
+    hipError_t r = stream_sync(e);
     float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     HIPC(e, r); HIPC(e, hipGetLastError());
@@ -2236,7 +2261,7 @@ extern "C" int sonic_bench_skinny(sonic_engine* e, int M, int N, int K, int vari
     (void)hipEventRecord(ea, e->st);
     for (int i = 0; i < iters; ++i) { a.W = dW + (size_t)(i % copies) * N * K; launch_skinny(a, e->st); }
     (void)hipEventRecord(eb, e->st);
-    hipError_t r = hipStreamSynchronize(e->st);
+    hipError_t r = stream_sync(e);
     float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     g_opts = e->opts;
@@ -2360,7 +2385,7 @@ extern "C" int sonic_test_greedy(sonic_engine* e, const float* slabs, int ksplit
     g.out_ids = ids; g.out_ld = 1; g.n_new = st; g.finished = st + 64; g.kv_len = st + 128; g.tok_pos = st + 192; g.max_new = st + 256;
     g.n_active = st + 512; g.n_eos = 0; g.pad_id = 0; g.logits_dump = dump; g.dump_stride_step = (long)B * V; g.step_counter = dump ? st + 320 : nullptr;
     launch_greedy(g, e->st);
-    HIPC(e, hipStreamSynchronize(e->st));
+    HIPC(e, stream_sync(e));
     HIPC(e, hipGetLastError());
     std::vector<int> out(64);
     HIPC(e, d2h(e, out.data(), ids, 64 * 4));

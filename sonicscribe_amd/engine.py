@@ -30,7 +30,7 @@ EXPORTS = [
     "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
     "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info",
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
-    "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row",
+    "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_prefill_enqueue",
 ]
 ABI_VERSION = 4
 
@@ -126,6 +126,7 @@ def load_library():
     lib.sonic_test_skinny_gu.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.sonic_prefill.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
     lib.sonic_decode_step.argtypes = [vp, C.c_int, ip, ip]
+    lib.sonic_prefill_enqueue.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.sonic_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, i64p, i64p, ip]
     lib.sonic_memory_info.argtypes = [vp, i64p, i64p]
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -404,11 +405,15 @@ class Engine:
         self._run_cache = (ids, poffs, mn, rw)
         self._check(self.lib.sonic_run_staged(self.h, _p(rw), len(prompts), _p(ids), _p(poffs), _p(mn), int(want_logits)))
 
-    def prefill(self, prompts: Sequence[Sequence[int]], max_new: Sequence[int], req_win: Optional[Sequence[int]] = None, want_logits: bool = False):
-        """Stage entry point: everything up to and including the first greedy token of the staged batch (sonic_prefill)."""
+    def prefill(self, prompts: Sequence[Sequence[int]], max_new: Sequence[int], req_win: Optional[Sequence[int]] = None, want_logits: bool = False, wait: bool = True):
+        """Stage entry point: everything up to and including the first greedy token of the staged batch (sonic_prefill).  wait=False: the
+        work is only queued when the call returns (sonic_prefill_enqueue; a following splice_rows orders itself behind it on the device)."""
         ids, poffs = self._pack_prompts(prompts)
         mn = np.ascontiguousarray(max_new, dtype=np.int32)
         rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+        if not wait:
+            self._check(self.lib.sonic_prefill_enqueue(self.h, _p(rw), len(prompts), _p(ids), _p(poffs), _p(mn)))
+            return
         self._check(self.lib.sonic_prefill(self.h, _p(rw), len(prompts), _p(ids), _p(poffs), _p(mn), int(want_logits)))
 
     def decode_step(self, n_steps: int = 1):

@@ -9,7 +9,7 @@ summ() { tail -1 | python3 -c '
 import json,sys
 d=json.loads(sys.stdin.read())
 print(json.dumps({"value": d["value"], "ms_per_step": d["ms_per_step"], "batches_in_flight_slots": d.get("batches_in_flight_slots", {}).get("value"), "single_batch": d["single_batch"]["value"], "decode_ms": d["stages_ms_per_step"]["decode_ms"], "batches_in_flight": d["config"]["batches_in_flight"]}))'; }
-B="python3 bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-extras --slots ${SLOTS:-3}"
+B="python3 bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-extras --slots ${SLOTS:-3} ${EXTRA:-}"
 echo "box: $(nproc) CPUs visible, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)" >> $OUT
 echo "idle host:      $($B 2>/dev/null | summ)" >> $OUT
 PIDS=""

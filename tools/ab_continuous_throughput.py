@@ -32,7 +32,7 @@ decs = [dec] + [dec.slot() for _ in range(n_dec - 1)]
 for p in pre:
     p.stage_pcm(segs)                                                       # PCM stays staged on the slot
 pipe = ContinuousPipeline(decs, pre, block=B)
-run = lambda n: pipe.run(n, lambda p: p.prefill([prompt] * B, [max_new] * B), lambda i, ids: np.array_equal(ids, want[i]))
+run = lambda n: pipe.run(n, lambda p: p.prefill([prompt] * B, [max_new] * B, wait=False), lambda i, ids: np.array_equal(ids, want[i]))
 for tag, nb in (("warm-up", pipe.batches_in_flight), ("timed", n_batches)):
     r = run(nb)
     print(f"{tag}: {n_dec} decoder(s) x {rows} rows, prefill slots {n_prefill}, chunk {chunk} ({pipe.batches_in_flight} batches in flight): {nb} batches of {B} in "
