@@ -181,38 +181,48 @@ class _Handover:
 
 
 class _ContinuousReplica:
-    """Row-level scheduling on one weight copy (include/sonic_hip.h sonic_service_*): the replica's engine decodes FOREVER over its max_batch
-    rows; its slots only prefill.  A request goes: queue -> a prefill slot takes whatever is queued (no linger, any mix of step classes, as
-    many requests as there are free rows) -> log-mel, encoder, prompt forward, first token -> its row is spliced into a free row of the
-    decoding engine between two chunks -> it leaves the moment it hits EOS / its budget.  Nobody waits for a running batch to end and no row
-    idles until the slowest row of its batch is done - what the reference's per-connection `await transcribe()` (connection_manager.py:127-245)
-    turns into when every session shares one device.  Tokens equal the solo run's bit for bit (decode rows are independent)."""
+    """Row-level scheduling on one weight copy (include/sonic_hip.h sonic_service_*): the replica's engine (and, with decoders > 1, that many
+    of its slots) decodes FOREVER over its max_batch rows; the remaining slots only prefill.  A request goes: queue -> a prefill slot takes
+    whatever is queued (no linger, any mix of step classes, as many requests as the emptiest decoder has free rows) -> log-mel, encoder,
+    prompt forward, first token (queued, not waited for) -> its row is spliced into a free row of that decoder between two chunks (the copies
+    order themselves behind the prefill on the device) -> it leaves the moment it hits EOS / its budget.  Nobody waits for a running batch to
+    end and no row idles until the slowest row of its batch is done - what the reference's per-connection `await transcribe()`
+    (connection_manager.py:127-245) turns into when every session shares one device.  Tokens equal the solo run's bit for bit (decode rows are
+    independent)."""
 
-    def __init__(self, engine, index: int, slots: Sequence[Any]):
-        if not slots:
-            raise ValueError("continuous decoding needs at least one slot per replica (the slot prefills, the engine decodes)")
-        self.engine, self.index, self.prefill_engines = engine, index, list(slots)
+    def __init__(self, engine, index: int, slots: Sequence[Any], decoders: int = 1):
+        decoders = max(1, int(decoders))
+        if len(slots) < decoders:
+            raise ValueError("continuous decoding needs at least one prefill slot per replica beside its decoding handles")
+        self.engine, self.index = engine, index
+        self.decoders = [engine] + list(slots[:decoders - 1])
+        self.prefill_engines = list(slots[decoders - 1:])
         self.engines = [engine] + list(slots)
         self.q: List[Request] = []
         self.cv = threading.Condition()
         self.stop = False
         self.n_rows = engine.max_batch
-        self.free_rows = self.n_rows                     # rows neither occupied nor reserved by a prefill in flight
-        self.rows: List[Optional[Request]] = [None] * self.n_rows
-        self.valid_after = [0] * self.n_rows
-        self.handovers: List[_Handover] = []
+        self.free = [self.n_rows] * len(self.decoders)   # per decoder: rows neither occupied nor reserved by a prefill in flight
+        self.rows: List[List[Optional[Request]]] = [[None] * self.n_rows for _ in self.decoders]
+        self.valid_after = [[0] * self.n_rows for _ in self.decoders]
+        self.handovers: List[List[_Handover]] = [[] for _ in self.decoders]
         self.batches = 0                                 # prefill batches
         self.steps = 0                                   # decode chunks queued
         self.failed: Optional[BaseException] = None
-        engine.service_begin()
-        self.threads = [threading.Thread(target=self._decode_loop, name=f"sonic-decode-{index}", daemon=True)]
-        self.threads += [threading.Thread(target=self._prefill_loop, args=(k,), name=f"sonic-prefill-{index}.{k}", daemon=True) for k in range(len(slots))]
+        for d in self.decoders:
+            d.service_begin()
+        self.threads = [threading.Thread(target=self._decode_loop, args=(k,), name=f"sonic-decode-{index}.{k}", daemon=True) for k in range(len(self.decoders))]
+        self.threads += [threading.Thread(target=self._prefill_loop, args=(k,), name=f"sonic-prefill-{index}.{k}", daemon=True) for k in range(len(self.prefill_engines))]
         for t in self.threads:
             t.start()
 
+    @property
+    def free_rows(self) -> int:
+        return sum(self.free)
+
     def load(self) -> int:
         with self.cv:
-            return (self.n_rows - self.free_rows) + sum(len(r.windows) for r in self.q)
+            return (self.n_rows * len(self.decoders) - sum(self.free)) + sum(len(r.windows) for r in self.q)
 
     def put(self, req: Request):
         with self.cv:
@@ -226,26 +236,27 @@ class _ContinuousReplica:
     _finish = staticmethod(_Replica._finish)
 
     # ---- prefill side
-    def _take(self, cap: int) -> List[Request]:
+    def _take(self, cap: int):
         with self.cv:
-            while not self.stop and (not self.q or self.free_rows <= 0):
+            while not self.stop and (not self.q or max(self.free) <= 0):
                 self.cv.wait()
             if self.stop and not self.q:
-                return []
+                return [], 0
             self.q = [r for r in self.q if not r.future.cancelled()]
+            k = max(range(len(self.free)), key=self.free.__getitem__)        # the emptiest decoder takes the whole prefill batch
             batch, used, rest = [], 0, []
             for r in self.q:                             # oldest first, whatever fits the slot's windows and the free rows; classes mix
                 if len(r.windows) > cap:
                     if r.future.set_running_or_notify_cancel():
                         r.future.set_exception(ValueError(f"audio spans {len(r.windows)} windows, engine max_batch is {cap}"))
-                elif len(batch) < self.free_rows and used + len(r.windows) <= cap and not rest:
+                elif len(batch) < self.free[k] and used + len(r.windows) <= cap and not rest:
                     if r.future.set_running_or_notify_cancel():
                         batch.append(r); used += len(r.windows)
                 else:
                     rest.append(r)
             self.q = rest
-            self.free_rows -= len(batch)                 # reserved until the rows are fetched (or the prefill fails)
-            return batch
+            self.free[k] -= len(batch)                   # reserved until the rows are fetched (or the prefill fails)
+            return batch, k
 
     def _prefill(self, eng, batch: List[Request]):
         segs, req_win = [], [0]
@@ -253,21 +264,26 @@ class _ContinuousReplica:
             segs.extend(r.windows)
             req_win.append(len(segs))
         eng.stage_pcm(segs, req_win)
-        eng.prefill([r.prompt for r in batch], [r.max_new for r in batch], req_win)
+        eng.prefill([r.prompt for r in batch], [r.max_new for r in batch], req_win, wait=False)   # queued; the splice orders itself behind it on the device
 
-    def _hand(self, eng, batch: List[Request]):
+    def _hand(self, eng, batch: List[Request], k: int):
         h = _Handover(eng, batch)
         with self.cv:
-            self.handovers.append(h)
+            self.handovers[k].append(h)
             self.cv.notify_all()
         while not h.taken.wait(0.5):                     # the slot's rows are the splice's source until the decode thread has queued it
             if self.failed is not None:
                 return
 
-    def _prefill_loop(self, k: int):
-        eng = self.prefill_engines[k]
+    def _release(self, k: int, n: int):
+        with self.cv:
+            self.free[k] += n
+            self.cv.notify_all()
+
+    def _prefill_loop(self, j: int):
+        eng = self.prefill_engines[j]
         while True:
-            batch = self._take(eng.max_batch)
+            batch, k = self._take(eng.max_batch)
             if not batch:
                 if self.stop:
                     return
@@ -277,7 +293,6 @@ class _ContinuousReplica:
             try:
                 self._prefill(eng, batch)
             except BaseException as ex:                  # a per-request validation error must not poison its neighbours: one by one
-                ok = []
                 for r in batch:
                     try:
                         if len(batch) == 1:
@@ -285,54 +300,51 @@ class _ContinuousReplica:
                         self._prefill(eng, [r])
                     except BaseException as ex2:
                         self._finish(r, error=ex2)
-                        with self.cv:
-                            self.free_rows += 1
-                            self.cv.notify_all()
+                        self._release(k, 1)
                     else:
-                        self._hand(eng, [r])
+                        self._hand(eng, [r], k)
                 continue
-            self._hand(eng, batch)
+            self._hand(eng, batch, k)
 
     # ---- decode side
-    def _decode_loop(self):
-        d = self.engine
+    def _decode_loop(self, k: int):
+        d, rows, valid_after = self.decoders[k], self.rows[k], self.valid_after[k]
         occupied = 0
         try:
             while True:
                 with self.cv:
-                    while not self.handovers and occupied == 0 and not self.stop:
+                    while not self.handovers[k] and occupied == 0 and not self.stop:
                         self.cv.wait()
-                    hs, self.handovers = self.handovers, []
+                    hs, self.handovers[k] = self.handovers[k], []
                     if self.stop and not hs and occupied == 0:
                         return
                 for h in hs:
-                    free = [i for i, r in enumerate(self.rows) if r is None][:len(h.reqs)]
+                    free = [i for i, r in enumerate(rows) if r is None][:len(h.reqs)]
                     seq = d.splice_rows(h.engine, list(range(len(h.reqs))), free)
                     for i, r in zip(free, h.reqs):
-                        self.rows[i], self.valid_after[i] = r, seq
+                        rows[i], valid_after[i] = r, seq
                     occupied += len(h.reqs)
                     h.taken.set()
                 if occupied == 0:
                     continue
                 fin, nn, seq, _ = d.service_step(1)
                 self.steps += 1
-                done = [i for i, r in enumerate(self.rows) if r is not None and seq > self.valid_after[i] and fin[i]]
+                done = [i for i, r in enumerate(rows) if r is not None and seq > valid_after[i] and fin[i]]
                 for i in done:
                     ids = d.fetch_row(i, int(nn[i]))
-                    r, self.rows[i] = self.rows[i], None
+                    r, rows[i] = rows[i], None
                     occupied -= 1
                     self._finish(r, ids)
                 if done:
-                    with self.cv:
-                        self.free_rows += len(done)
-                        self.cv.notify_all()
+                    self._release(k, len(done))
         except BaseException as ex:                      # the engine failed: nothing queued or in flight can complete
             with self.cv:
                 self.failed = ex
                 pending, self.q = self.q, []
-                hs, self.handovers = self.handovers, []
+                hs = [h for lst in self.handovers for h in lst]
+                self.handovers = [[] for _ in self.decoders]
                 self.cv.notify_all()
-            for r in [x for x in self.rows if x is not None] + [x for h in hs for x in h.reqs] + pending:
+            for r in [x for rr in self.rows for x in rr if x is not None] + [x for h in hs for x in h.reqs] + pending:
                 try:
                     self._finish(r, error=ex)
                 except BaseException:
@@ -346,24 +358,26 @@ class _ContinuousReplica:
             self.cv.notify_all()
         for t in self.threads:
             t.join(timeout=30)
-        try:
-            self.engine.service_end()
-        except BaseException:
-            pass
+        for d in self.decoders:
+            try:
+                d.service_end()
+            except BaseException:
+                pass
         for r in self.q:
             if not r.future.done():
                 r.future.set_exception(RuntimeError("ASR engine is closed"))
 
 
 class Dispatcher:
-    def __init__(self, engines: Sequence[Any], slots: Optional[Sequence[Sequence[Any]]] = None, continuous: bool = False):
+    def __init__(self, engines: Sequence[Any], slots: Optional[Sequence[Sequence[Any]]] = None, continuous: bool = False, decoders: int = 1):
         """engines: one per replica (its own weights).  slots[i]: further engine handles that share replica i's weights (Engine.slot()).
-        continuous: row-level scheduling (_ContinuousReplica: the engine decodes forever, its slots prefill) instead of batch by batch."""
+        continuous: row-level scheduling (_ContinuousReplica: the engine - and decoders - 1 of its slots - decode forever, the other slots
+        prefill) instead of batch by batch."""
         if not engines:
             raise ValueError("at least one engine")
         self.continuous = bool(continuous)
         if continuous:
-            self.replicas = [_ContinuousReplica(e, i, slots[i] if slots else ()) for i, e in enumerate(engines)]
+            self.replicas = [_ContinuousReplica(e, i, slots[i] if slots else (), decoders) for i, e in enumerate(engines)]
         else:
             self.replicas = [_Replica(e, i, slots[i] if slots else ()) for i, e in enumerate(engines)]
 

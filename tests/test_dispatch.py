@@ -223,7 +223,7 @@ class StubPool:
         def stage_pcm(self, segs, req_win=None):
             self.staged = (list(segs), list(req_win))
 
-        def prefill(self, prompts, max_new, req_win=None):
+        def prefill(self, prompts, max_new, req_win=None, wait=True):
             segs, rw = self.staged
             rows = []
             for r in range(len(prompts)):
@@ -298,6 +298,20 @@ def test_continuous_replica_rows_join_and_leave_one_by_one():
     [f.result(timeout=10) for f in long_f]
     d.close()
     assert not pool.decoder.on
+
+
+def test_continuous_replica_two_decoders_share_the_prefill_slot():
+    pool = StubPool(n_rows=3, prefill_batch=4, prefill_delay=0.001)
+    dec2 = StubPool.Decoder(pool, 3)
+    d = Dispatcher([pool.decoder], slots=[[dec2] + pool.prefills], continuous=True, decoders=2)
+    budgets = [30 + (i * 7) % 40 for i in range(20)]
+    futs = [d.submit([seg(i)], [1, 2, 3], mn) for i, mn in enumerate(budgets)]
+    for i, (f, mn) in enumerate(zip(futs, budgets)):
+        assert f.result(timeout=10).tolist() == want_tokens(i, 3, mn), i
+    assert pool.decoder.max_occupied <= 3 and dec2.max_occupied <= 3 and dec2.max_occupied > 0       # both pools were used, neither overfilled
+    assert d.replicas[0].load() == 0
+    d.close()
+    assert not pool.decoder.on and not dec2.on
 
 
 def test_continuous_replica_errors_cancel_and_close():

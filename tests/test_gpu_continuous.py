@@ -151,3 +151,24 @@ def test_asrmodel_continuous_equals_batch_model():
     assert got == ref.transcribe((np.frombuffer(wire, np.int16).astype(np.float32) / np.float32(32768.0))[None], 16000, max_new_tokens=30)
     st.close()
     ref.close(); con.close()
+
+
+def test_asrmodel_two_decoders_of_64_rows_bulk_shape():
+    """the bulk shape of the facade (bench.py's pipeline through dispatch._ContinuousReplica): two decoding handles over 64 rows each + one prefill
+    slot on one weight copy; 150 requests of mixed length and budget from the caller's threads, every transcript equal to the one-slot batch model's"""
+    from sonicscribe_amd.asr import ASRModel
+    d = replace(spec.TINY, eos_ids=())
+    ref = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=1, continuous=False)
+    bulk = ASRModel.from_synthetic(d, device="cuda:0", max_batch=64, max_ctx=512, slots=3, continuous=True, decoders=2)
+    info = bulk.get_model_info()
+    assert info["continuous"] is True and info["slots_per_replica"] == 3 and bulk.model.slot_count() == 3
+    rep = bulk._dispatcher.replicas[0]
+    assert len(rep.decoders) == 2 and len(rep.prefill_engines) == 1
+    wavs = [synth.synth_pcm(1200 + i, 16000 * (1 + i % 5)).astype(np.float32) / 32768.0 for i in range(50)]
+    budgets = [8 + (i * 11) % 40 for i in range(50)]
+    want = [ref.transcribe(w[None], 16000, max_new_tokens=b) for w, b in zip(wavs, budgets)]
+    futs = [bulk.submit(wavs[i % 50][None], 16000, budgets[i % 50]) for i in range(150)]
+    got = [f.result(timeout=300) for f in futs]
+    assert got == [want[i % 50] for i in range(150)]
+    assert rep.load() == 0 and all(r is None for rows in rep.rows for r in rows)
+    ref.close(); bulk.close()
