@@ -165,14 +165,16 @@ SONIC_API int sonic_prefill_enqueue(sonic_engine* e, const int32_t* req_win, int
  *   sonic_splice_rows(d, p, n, src_rows, dst_rows, &seq)   rows src_rows[] of p (KV cache, control words, next-step input) -> free rows
  *                               dst_rows[] of d, queued on d's stream between two chunks; p may start its next prefill at once (it waits for the
  *                               copies on the device).  seq = chunks d had queued before: checks with a larger number describe the new occupants
- *   sonic_service_step(d, k, finished[64], n_new[64], &seq, &n_active)   queue k more chunks (k * decode_chunk token steps for every row) and
- *                               return the newest completed check: finished[r] = 1 once row r hit EOS / its budget (or is free), n_new[r] its tokens
+ *   sonic_service_step(d, k, rows, finished[64], n_new[64], &seq, &n_active)   queue k more chunks (k * decode_chunk token steps for rows
+ *                               0 .. rows-1 rounded up to 16; rows = 0: all - the caller names the highest occupied row + 1, so a lightly loaded
+ *                               pool steps faster) and return the newest completed check: finished[r] = 1 once row r hit EOS / its budget (or is
+ *                               free), n_new[r] its tokens
  *   sonic_fetch_row(d, row, n, ids)   the n tokens of a finished row; the row is free again
  * A request's tokens are the same bits as in a solo run (rows are independent in every decode kernel; tests/test_gpu_continuous.py). */
 SONIC_API int sonic_service_begin(sonic_engine* d);
 SONIC_API int sonic_service_end(sonic_engine* d);
 SONIC_API int sonic_splice_rows(sonic_engine* d, sonic_engine* p, int n, const int32_t* src_rows, const int32_t* dst_rows, int64_t* seq_out);
-SONIC_API int sonic_service_step(sonic_engine* d, int n_chunks, int32_t* finished_out, int32_t* n_new_out, int64_t* seq_out, int32_t* n_active_out);
+SONIC_API int sonic_service_step(sonic_engine* d, int n_chunks, int rows, int32_t* finished_out, int32_t* n_new_out, int64_t* seq_out, int32_t* n_active_out);
 SONIC_API int sonic_fetch_row(sonic_engine* d, int row, int n, int32_t* out_ids);
 
 /* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as

@@ -327,7 +327,8 @@ class _ContinuousReplica:
                     h.taken.set()
                 if occupied == 0:
                     continue
-                fin, nn, seq, _ = d.service_step(1)
+                top = max(i for i, r in enumerate(rows) if r is not None) + 1          # rows are handed out lowest first: a light load stays in the first 16
+                fin, nn, seq, _ = d.service_step(1, top)
                 self.steps += 1
                 done = [i for i, r in enumerate(rows) if r is not None and seq > valid_after[i] and fin[i]]
                 for i in done:

@@ -139,7 +139,7 @@ def load_library():
     lib.sonic_service_begin.argtypes = [vp]
     lib.sonic_service_end.argtypes = [vp]
     lib.sonic_splice_rows.argtypes = [vp, vp, C.c_int, vp, vp, i64p]
-    lib.sonic_service_step.argtypes = [vp, C.c_int, vp, vp, i64p, ip]
+    lib.sonic_service_step.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64p, ip]
     lib.sonic_fetch_row.argtypes = [vp, C.c_int, C.c_int, vp]
     for name in EXPORTS:
         getattr(lib, name)
@@ -462,11 +462,12 @@ class Engine:
         self._check(self.lib.sonic_splice_rows(self.h, src.h, len(a), _p(a), _p(b), C.byref(seq)))
         return int(seq.value)
 
-    def service_step(self, n_chunks: int = 1):
-        """queue n_chunks more chunks; returns (finished[64], n_new[64], seq, n_active) of the newest completed check"""
+    def service_step(self, n_chunks: int = 1, rows: int = 0):
+        """queue n_chunks more chunks over rows 0 .. rows-1 (rounded up to 16; 0 = all); returns (finished[64], n_new[64], seq, n_active) of
+        the newest completed check"""
         fin = np.zeros(64, np.int32); nn = np.zeros(64, np.int32)
         seq, na = C.c_int64(0), C.c_int32(0)
-        self._check(self.lib.sonic_service_step(self.h, int(n_chunks), _p(fin), _p(nn), C.byref(seq), C.byref(na)))
+        self._check(self.lib.sonic_service_step(self.h, int(n_chunks), int(rows), _p(fin), _p(nn), C.byref(seq), C.byref(na)))
         return fin, nn, int(seq.value), int(na.value)
 
     def fetch_row(self, row: int, n: int) -> np.ndarray:

@@ -255,7 +255,8 @@ class StubPool:
             self.max_occupied = max(self.max_occupied, sum(r is not None for r in self.rows))
             return self.seq
 
-        def service_step(self, n_chunks=1):
+        def service_step(self, n_chunks=1, rows=0):
+            assert rows == 0 or all(r is None for r in self.rows[rows:]), "an occupied row lies beyond the rows the caller asked for"
             time.sleep(self.pool.step_delay)
             self.seq += n_chunks
             fin, nn = np.ones(64, np.int32), np.zeros(64, np.int32)
@@ -332,7 +333,7 @@ def test_continuous_replica_errors_cancel_and_close():
         d.submit([seg(0)], [1], 5)
 
     class Broken(StubPool.Decoder):
-        def service_step(self, n_chunks=1):
+        def service_step(self, n_chunks=1, rows=0):
             raise RuntimeError("HIP error: device lost")
     pool2 = StubPool(n_rows=2)
     pool2.decoder = Broken(pool2, 2)
