@@ -1692,6 +1692,13 @@ __global__ __launch_bounds__(256) void splice_state_kernel(SpliceArgs a) {
 }
 // a fetched row goes back to the pool: it stays `finished` (frozen: it emits nothing) and looks at one key only until it is reused
 __global__ void release_row_kernel(int* kv_len, int* tok_pos, int* finished, int row) { kv_len[row] = 1; tok_pos[row] = 0; finished[row] = 1; }
+// the pipelined check of the continuous loop: finished | n_new | n_active -> one record in pinned host memory (a kernel's stores instead of
+// three copy commands between every two chunks)
+__global__ void service_status_kernel(const int* finished, const int* n_new, const int* n_active, int* out) {
+    const int t = threadIdx.x;
+    if (t < 64) { out[t] = finished[t]; out[64 + t] = n_new[t]; }
+    if (t == 0) out[128] = *n_active;
+}
 __global__ void service_reset_kernel(int* kv_len, int* tok_pos, int* n_new, int* finished, int* max_new, int* n_active) {
     const int b = threadIdx.x;
     if (b < 64) { kv_len[b] = 1; tok_pos[b] = 0; n_new[b] = 0; finished[b] = 1; max_new[b] = 1; }
@@ -1799,9 +1806,7 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
             HIPC(e, hipGraphLaunch(gx, e->st));
             const int slot = (int)(e->svc_launched % CHK_RING);
             int* w = e->svc_h + (size_t)slot * SVC_WORDS;
-            HIPC(e, hipMemcpyAsync(w, e->finished, 64 * 4, hipMemcpyDeviceToHost, e->st));
-            HIPC(e, hipMemcpyAsync(w + 64, e->n_new, 64 * 4, hipMemcpyDeviceToHost, e->st));
-            HIPC(e, hipMemcpyAsync(w + 128, e->n_active, 4, hipMemcpyDeviceToHost, e->st));
+            hipLaunchKernelGGL(service_status_kernel, dim3(1), dim3(64), 0, e->st, e->finished, e->n_new, e->n_active, w);
             HIPC(e, hipEventRecord(e->chk_ev[slot], e->st));
             ++e->svc_launched;
         }
