@@ -340,6 +340,7 @@ static int build_constants(sonic_engine* e) {
     e->lc = LogmelConst{dwin, dct, dst, dlo, dcnt, doff, dw};
 
     // RoPE tables: cos/sin computed in fp32 and cast to the activation dtype (modeling_glmasr.py:95-106)
+    auto round_act = [&](float x) -> float { return e->dt == DT_F16 ? (float)(_Float16)x : bf16_round_host(x); };
     auto rope_table = [&](int n_pos, int rd, float theta, float** out) -> int {
         const int half = rd / 2;
         std::vector<float> t((size_t)n_pos * rd);
@@ -347,14 +348,14 @@ static int build_constants(sonic_engine* e) {
             for (int i = 0; i < half; ++i) {
                 const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)rd);
                 const float ang = inv * (float)p;
-                t[(size_t)p * rd + i] = bf16_round_host(cosf(ang));
-                t[(size_t)p * rd + half + i] = bf16_round_host(sinf(ang));
+                t[(size_t)p * rd + i] = round_act(cosf(ang));          // `cos.to(dtype=x.dtype)`: bf16 (native), fp16 (int8 / fp16 modes)
+                t[(size_t)p * rd + half + i] = round_act(sinf(ang));
             }
         TRY(dalloc(e, out, t.size()));
         HIPC(e, h2d(e, *out, t.data(), t.size() * 4));
         return SONIC_OK;
     };
-    if (!e->i8) {
+    if (e->dt == DT_BF16) {
         // GELU of every bf16 value with |x| in [2^-14, 16), computed exactly as the reference op sequence does it in fp32
         // (0.5 * x * (1 + erff(x / sqrt 2)), modeling_glmasr.py:299-300 / torch GELU(approximate="none")) and rounded to bf16 once
         std::vector<unsigned short> lut(GELU_LUT_N);
@@ -490,7 +491,7 @@ static int alloc_state(sonic_engine* e) {
 extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out) {
     if (!dims || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
+    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8 && mode != SONIC_MODE_F16) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
     g_opts = LaunchOpts{};
     TRY(check_dims(*dims, max_batch, max_ctx, mode));
     if (mode == SONIC_MODE_INT8 && (dims->dec_ff > 8192 || dims->enc_d % 128 || dims->enc_ff % 128 || (dims->dec_heads * dims->dec_head_dim) % 128))
@@ -500,7 +501,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
     sonic_engine* e = new sonic_engine();
     e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
-    e->i8 = mode == SONIC_MODE_INT8; e->dt = e->i8 ? DT_F16 : DT_BF16;
+    e->i8 = mode == SONIC_MODE_INT8; e->dt = (e->i8 || mode == SONIC_MODE_F16) ? DT_F16 : DT_BF16;
     int s = alloc_state(e);
     if (s == SONIC_OK) s = build_constants(e);
     if (s == SONIC_OK && stream_sync(e) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
@@ -665,7 +666,7 @@ extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* 
         HIPC(e, hipMalloc((void**)&tmp, t->n * 4));
         hipError_t r = h2d(e, tmp, data, t->n * 4);
         // int8 mode loads the checkpoint with torch_dtype=float16 (asr.py:156): an fp32 source goes straight to fp16
-        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st, e->dt); r = stream_sync(e); if (e->i8) e->raw_f16[name] = true; }
+        if (r == hipSuccess) { launch_f32_to_bf16(tmp, t->p, (long)t->n, e->st, e->dt); r = stream_sync(e); if (e->dt == DT_F16) e->raw_f16[name] = true; }
         (void)hipFree(tmp);
         HIPC(e, r);
     } else return fail(e, SONIC_ERR_INVALID, "dtype must be f32 or bf16");
@@ -747,7 +748,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
     const sonic_dims& d = e->d;
     const std::string at = "model.audio_tower.", pj = "model.multi_modal_projector.", lm = "model.language_model.";
     e->weight_bytes = 0;
-    if (e->i8)   // a bf16 checkpoint (or the synthetic generator's bf16 values) loaded as fp16, in place (asr.py:156 torch_dtype=float16)
+    if (e->dt == DT_F16)   // a bf16 checkpoint (or the synthetic generator's bf16 values) loaded as fp16, in place (asr.py:156 torch_dtype=float16)
         for (auto& kv : e->raw) if (kv.second.p && !e->raw_f16.count(kv.first)) launch_bf16_to_f16(kv.second.p, kv.second.p, (long)kv.second.n, e->st);
     {   // conv stem in im2col order [C][3][Ci]
         DevTensor *w1, *w2; TRY(need(e, at + "conv1.weight", &w1)); TRY(need(e, at + "conv2.weight", &w2));
@@ -812,7 +813,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         }
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
         TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
-        if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave)
+        if (e->dt == DT_BF16 && skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave; the fused decode kernels are bf16 only)
             TRY(dalloc_big(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
             launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
             e->weight_bytes += (int64_t)2 * d.dec_ff * d.dec_d * 2;
