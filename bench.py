@@ -623,8 +623,15 @@ def main():
         #   encoder GEMMs vs MFMA: all encoder-layer GEMM launches (QKV, o, fc1, fc2) with HIP events around each, from the extra step
         mel_bytes = B * (n_samples * 2 + 128 * 3000 * 2)
         mel_gbs = mel_bytes / (stage["mel_ms"] / a.steps * 1e-3) / 1e9 if stage["mel_ms"] > 0 else 0.0
+        # ... and what the kernel is actually bound by in its DFT-as-GEMM form: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak): four 100-long
+        # sums x 128 bin columns per live frame (frames in whole 32-frame tiles)
+        live_frames = ((min(n_samples, 480000) + 200 + 159) // 160 + 31) // 32 * 32
+        mel_flops = B * live_frames * 4 * 100 * 128 * 2.0
+        mel_tf = mel_flops / (stage["mel_ms"] / a.steps * 1e-3) / 1e12 if stage["mel_ms"] > 0 else 0.0
         out["mel_frontend"] = {"bound": "hbm", "achieved": mel_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": mel_gbs / PEAK_HBM_GBS,
-                               "bytes_per_step": mel_bytes, "ms_per_step": stage["mel_ms"] / a.steps}
+                               "bytes_per_step": mel_bytes, "ms_per_step": stage["mel_ms"] / a.steps,
+                               "compute": {"bound": "mfma fp32", "achieved": mel_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": mel_tf / 157.3, "flops_per_step": mel_flops,
+                                           "note": "the folded 400-point DFT runs as an exact-fp32 MFMA GEMM: by bytes the kernel is HBM-bound, in this form it is not"}}
         peak_mm = PEAK_BF16_TFLOPS * (2.0 if a.mode == "int8" else 1.0)
         if tg["enc_gemm_ms"] > 0:
             eg = tg["enc_gemm_flops"] / (tg["enc_gemm_ms"] * 1e-3) / 1e12

@@ -60,12 +60,28 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     if (t0 >= t_live) return;
     const int16_t* x = pcm + (long)b * pcm_stride;
 
-    for (int i = tid; i < LM_SMP; i += 256) {
-        int j = t0 * LM_HOP - LM_NFFT / 2 + i;
-        if (j < 0) j = -j;                                  // reflect (torch.stft center=True)
-        if (j >= n_pad) j = 2 * (n_pad - 1) - j;
-        const float v = (j < n) ? (float)x[j] * (1.0f / 32768.0f) : 0.0f;
-        smp[i + i / LM_HOP] = v;                            // skew: frame stride 161
+    // PCM window -> LDS as fp32.  16-byte loads (8 samples per lane; the window starts at a multiple of 8 samples and the segment base is 16-byte
+    // aligned) wherever the 8 samples lie inside [0, n): 3 trips instead of the 21 dependent 2-byte trips of the first form; the reflected edges
+    // (torch.stft center=True) and the zero padding behind the audio keep the per-sample path.
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int base = t0 * LM_HOP - LM_NFFT / 2;
+    const bool vec_ok = (pcm_stride & 7) == 0 && ((size_t)pcm & 15) == 0;
+    for (int v8 = tid; v8 < LM_SMP / 8; v8 += 256) {
+        const int i0 = v8 * 8, j0 = base + i0;
+        if (vec_ok && j0 >= 0 && j0 + 8 <= n) {
+            const s16x8 q = *(const s16x8*)(x + j0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + k; smp[i + i / LM_HOP] = (float)q[k] * (1.0f / 32768.0f); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k;
+                int j = base + i;
+                if (j < 0) j = -j;                              // reflect (torch.stft center=True)
+                if (j >= n_pad) j = 2 * (n_pad - 1) - j;
+                smp[i + i / LM_HOP] = (j < n) ? (float)x[j] * (1.0f / 32768.0f) : 0.0f;   // skew: frame stride 161
+            }
+        }
     }
     for (int i = tid; i < LM_NFFT; i += 256) { s_win[i] = lc.win[i]; s_cos[i] = lc.cos_t[i]; s_sin[i] = lc.sin_t[i]; }
     __syncthreads();
@@ -132,17 +148,29 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     }
     __syncthreads();
 
-    // ---- mel + log10: thread = (mel, frame half)
+    // ---- mel + log10: thread = (mel, frame half).  The filter's taps (<= ~27 of them for the 128-filter slaney bank) are fetched ONCE into registers
+    // and reused for the thread's 16 frames: the first form re-read them from global memory for every frame (432 dependent-ish loads per thread, the
+    // longest phase of the kernel); same summation order, same bits.
     float lmax = -1e30f;
+    constexpr int MT = 32;
     for (int e = tid; e < n_mels * 2; e += 256) {
         const int m = e % n_mels, fh = e / n_mels;
         const int lo = lc.mel_lo[m], cnt = lc.mel_cnt[m];
         const float* w = lc.mel_w + lc.mel_off[m];
+        float wr[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) wr[i] = i < cnt ? w[i] : 0.f;
         for (int f = fh * 16; f < fh * 16 + 16; ++f) {
             const int t = t0 + f;
             if (t >= t_live) break;
             float acc = 0.f;
-            for (int i = 0; i < cnt; ++i) acc += w[i] * pw[f * LM_PWLD + lo + i];
+            if (cnt <= MT) {
+                const float* pr = pw + f * LM_PWLD + lo;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) if (i < cnt) acc += wr[i] * pr[i];
+            } else {
+                for (int i = 0; i < cnt; ++i) acc += w[i] * pw[f * LM_PWLD + lo + i];
+            }
             const float v = log10f(fmaxf(acc, 1e-10f));
             logspec[((long)b * n_frames + t) * n_mels + m] = v;
             lmax = fmaxf(lmax, v);
