@@ -27,6 +27,14 @@
 #define LM_PWLD 225                    // power row stride (7 bin blocks of 32 = 224, +1 skew)
 
 
+// in-kernel timeline for tools/mel_timeline.hip (compiled out of the product library)
+#ifdef LM_TRACE
+__device__ long long* lm_trace;
+#define LMT(k) do { if (threadIdx.x == 0) lm_trace[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define LMT(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ int ord_enc(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord_dec(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
@@ -59,6 +67,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     const int t_live = min(n_frames, (n + LM_NFFT / 2 + LM_HOP - 1) / LM_HOP);
     if (t0 >= t_live) return;
     const int16_t* x = pcm + (long)b * pcm_stride;
+    LMT(0);
 
     // PCM window -> LDS as fp32.  16-byte loads (8 samples per lane; the window starts at a multiple of 8 samples and the segment base is 16-byte
     // aligned) wherever the 8 samples lie inside [0, n): 3 trips instead of the 21 dependent 2-byte trips of the first form; the reflected edges
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     }
     for (int i = tid; i < LM_NFFT; i += 256) { s_win[i] = lc.win[i]; s_cos[i] = lc.cos_t[i]; s_sin[i] = lc.sin_t[i]; }
     __syncthreads();
+    LMT(1);
     // fold: one (frame, n) pair per item, n = 1..199; n = 0 and n = 200 go to s_y0
     for (int i = tid; i < LM_FT * 200; i += 256) {
         const int f = i / 200, nn = i % 200;
@@ -102,6 +112,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
         }
     }
     __syncthreads();
+    LMT(2);
 
     const int fi = lane & 31, kh = lane >> 5;
     const int bin = wid * 32 + fi;
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
         ie += stp; ie = ie >= LM_NFFT ? ie - LM_NFFT : ie;
         io += stp; io = io >= LM_NFFT ? io - LM_NFFT : io;
     }
+    LMT(3);
     // y[0], y[200] of this lane's 16 frames before pw overwrites the staging area
     float cc[16];
     const float sgn = (bin & 1) ? -1.0f : 1.0f;
@@ -147,6 +159,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
         }
     }
     __syncthreads();
+    LMT(4);
 
     // ---- mel + log10: thread = (mel, frame half).  The filter's taps (<= ~27 of them for the 128-filter slaney bank) are fetched ONCE into registers
     // and reused for the thread's 16 frames: the first form re-read them from global memory for every frame (432 dependent-ish loads per thread, the
@@ -178,6 +191,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     }
     lmax = wave_max(lmax);
     if (lane == 0 && lmax > -1e29f) atomicMax(&segmax[b], ord_enc(lmax));
+    LMT(5);
 }
 
 template <typename T>
