@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
     __syncthreads();
     LMT(1);
     // fold: one (frame, n) pair per item, n = 1..199; n = 0 and n = 200 go to s_y0
-    for (int i = tid; i < LM_FT * 200; i += 256) {
+#pragma unroll 5
+    for (int i = tid; i < LM_FT * 200; i += 256) {          // 25 trips; unrolled so that five trips' LDS reads are in flight together
         const int f = i / 200, nn = i % 200;
         const float* fs = smp + f * (LM_HOP + 1);
         if (nn == 0) {
@@ -173,20 +174,39 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const int16_t* pcm, l
         float wr[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) wr[i] = i < cnt ? w[i] : 0.f;
-        for (int f = fh * 16; f < fh * 16 + 16; ++f) {
-            const int t = t0 + f;
-            if (t >= t_live) break;
-            float acc = 0.f;
-            if (cnt <= MT) {
-                const float* pr = pw + f * LM_PWLD + lo;
+        if (cnt <= MT) {
+            // taps outer, the thread's 16 frames inner: 16 independent accumulators per tap instead of one 27-long dependent FMA chain per frame
+            // (each output still sums its taps in ascending order: same bits)
+            float acc[16];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) if (i < cnt) acc += wr[i] * pr[i];
-            } else {
-                for (int i = 0; i < cnt; ++i) acc += w[i] * pw[f * LM_PWLD + lo + i];
+            for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+            const float* pr = pw + fh * 16 * LM_PWLD + lo;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (i < cnt) {
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) acc[f] += wr[i] * pr[f * LM_PWLD + i];
+                }
             }
-            const float v = log10f(fmaxf(acc, 1e-10f));
-            logspec[((long)b * n_frames + t) * n_mels + m] = v;
-            lmax = fmaxf(lmax, v);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                const int t = t0 + fh * 16 + f;
+                if (t < t_live) {
+                    const float v = log10f(fmaxf(acc[f], 1e-10f));
+                    logspec[((long)b * n_frames + t) * n_mels + m] = v;
+                    lmax = fmaxf(lmax, v);
+                }
+            }
+        } else {
+            for (int f = fh * 16; f < fh * 16 + 16; ++f) {
+                const int t = t0 + f;
+                if (t >= t_live) break;
+                float acc = 0.f;
+                for (int i = 0; i < cnt; ++i) acc += w[i] * pw[f * LM_PWLD + lo + i];
+                const float v = log10f(fmaxf(acc, 1e-10f));
+                logspec[((long)b * n_frames + t) * n_mels + m] = v;
+                lmax = fmaxf(lmax, v);
+            }
         }
     }
     lmax = wave_max(lmax);
