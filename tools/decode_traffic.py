@@ -21,6 +21,6 @@ for k in per_layer + per_step:
     rows.append({"kernel": k[0], "grid_threads": k[1], "launches_per_step": mult, "fetch_bytes_x2": f, "write_bytes": w})
     tot_f += f; tot_w += w
 print(json.dumps({"hbm_bytes_per_token_step": tot_f + tot_w, "fetch_bytes_x2": tot_f, "write_bytes": tot_w, "kernels": rows,
-                  "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --slots 1 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --max-new 30` "
+                  "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --slots 1 --pipeline off --steps 1 --warmup 1 --no-cpu-baseline --no-extras --max-new 30` "
                           "(contexts 260..289, i.e. a little less KV than the 150-token bench average of 335); FETCH_SIZE doubled (gfx950 correction)",
                   "source": [sys.argv[1], sys.argv[2]]}, indent=1))
