@@ -120,6 +120,7 @@ struct sonic_engine {
     // into free rows between chunks of an endless greedy loop, finished rows are fetched and freed one by one
     bool svc_on = false;
     int64_t svc_launched = 0, svc_checked = 0;                     // chunks queued / checks read since sonic_service_begin
+    int svc_calm = 0;                                              // chunks since the queue last ran dry (the lookahead shrinks again after 256 of them)
     int* svc_h = nullptr;                                          // pinned ring [CHK_RING][SVC_WORDS]: finished[64] | n_new[64] | n_active
     int svc_fin[64]{}, svc_nn[64]{}, svc_active = 0; int64_t svc_seq = 0;   // the newest check read: state after chunk number svc_seq
     hipEvent_t sync_ev = nullptr;                                  // blocking-sync event behind stream_sync()
@@ -565,6 +566,12 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     }
     (void)hipSetDevice(e->device);
     if (e->st) (void)stream_sync(e);
+    if (e->splice_ev) {                                // a sibling that prefilled for this handle must not wait for an event that is about to be destroyed
+        sonic_engine* root = e->owner ? e->owner : e;  // (the stream was just drained: every splice this handle queued has completed)
+        std::lock_guard<std::mutex> lk(root->mu);
+        if (root != e && root->wait_ev == e->splice_ev) root->wait_pending = false;
+        for (sonic_engine* k : root->slots) if (k != e && k->wait_ev == e->splice_ev) k->wait_pending = false;
+    }
     for (sonic_ring* r : e->rings) ring_free(r);       // rings the caller left behind go with their engine
     e->rings.clear();
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
@@ -1816,7 +1823,10 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
             if (r < 0) return fail(e, SONIC_ERR_HIP, "continuous decode loop: check event failed: %s", hipGetErrorString(hipGetLastError()));
             if (r == 0) break;
         }
-        if (c < n_chunks && e->svc_checked == e->svc_launched && e->svc_active > 0 && e->lookahead < CHK_MAX_AHEAD) e->lookahead *= 2;   // the device ran dry with rows running
+        if (c < n_chunks && e->svc_checked == e->svc_launched && e->svc_active > 0) {      // the device ran dry with rows running: keep more chunks queued
+            e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
+            e->svc_calm = 0;
+        } else if (c < n_chunks && ++e->svc_calm >= 256 && e->lookahead > 1) { e->lookahead -= 1; e->svc_calm = 0; }   // ... and fewer again after a calm stretch (a splice waits behind the queued chunks)
     }
     if (finished_out) memcpy(finished_out, e->svc_fin, 64 * 4);
     if (n_new_out) memcpy(n_new_out, e->svc_nn, 64 * 4);
