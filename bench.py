@@ -262,7 +262,7 @@ def streaming_measure(a):
     S = a.sessions
     dev = "cuda:*" if a.gpus > 1 else "cuda:" + ",".join(["0"] * max(1, a.replicas_per_gpu))     # several replicas on one GPU fill each other's decode bubbles
     model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512, slots=getattr(a, "slots", 2),
-                                    continuous=getattr(a, "continuous", False), _options=dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in getattr(a, "opt", []) or []))
+                                    continuous=getattr(a, "continuous", False), decoders=getattr(a, "decoders", 1), _options=dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in getattr(a, "opt", []) or []))
     n_rep = len(model.models)
     speech = SEG_SECONDS * 16000
     wire = [synth.synth_pcm(i, speech) for i in range(S)]                          # int16, as the WebSocket delivers it
@@ -373,6 +373,7 @@ def main():
     ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="--streaming on one GPU: engine replicas sharing it (DESIGN.md 4: concurrent decode chains)")
     ap.add_argument("--continuous", action="store_true", help="--streaming: row-level scheduling (the engine decodes forever over its rows, slots prefill; dispatch._ContinuousReplica)")
+    ap.add_argument("--decoders", type=int, default=1, help="--streaming --continuous: decoding handles per replica (each loops over --batch rows); the other slots prefill")
     ap.add_argument("--single", action="store_true", help="--streaming: also time B=1 transcribe() calls of 5 s / 20 s first (BASELINE config 1's call shape)")
     ap.add_argument("--ingest", default="host", choices=["host", "ring"], help="--streaming: decodes hand over host tensors (the reference's call) or name chunk "
                     "ranges of per-session device rings fed chunk by chunk (SURVEY 8 f2)")

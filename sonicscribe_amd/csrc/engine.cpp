@@ -120,6 +120,7 @@ struct sonic_engine {
     // into free rows between chunks of an endless greedy loop, finished rows are fetched and freed one by one
     bool svc_on = false;
     int64_t svc_launched = 0, svc_checked = 0;                     // chunks queued / checks read since sonic_service_begin
+    int64_t svc_dry = 0;                                           // launches that found the stream empty with rows running (diagnostics)
     int svc_calm = 0;                                              // chunks since the queue last ran dry (the lookahead shrinks again after 256 of them)
     int* svc_h = nullptr;                                          // pinned ring [CHK_RING][SVC_WORDS]: finished[64] | n_new[64] | n_active
     int svc_fin[64]{}, svc_nn[64]{}, svc_active = 0; int64_t svc_seq = 0;   // the newest check read: state after chunk number svc_seq
@@ -1336,9 +1337,9 @@ static int chunk_graph(sonic_engine* e, int R, int n, hipGraphExec_t* out) {
 // pinned memory and an event is recorded; the host reads check k only when chunk k + lookahead is already queued, so the stream never runs
 // dry while the host looks, and the loop stops `lookahead` chunks after every row hit EOS / its budget (finished rows are frozen: the
 // queued steps rewrite their own cache slot and emit nothing).  lookahead ADAPTS: it is 1 on a host that keeps up (waste at a stop: one
-// chunk) and doubles whenever the host, coming back to launch the next chunk, finds the previous one already complete - the queue had run
-// dry: a host that is descheduled for tens of milliseconds at a time (CPU quota shared with other work, a busy event loop) -
-// up to CHK_MAX_AHEAD chunks; a batch without such an observation takes one chunk off again.
+// chunk) and doubles whenever the host, about to launch the next chunk, finds the one it queued last already complete - the stream is empty,
+// the device idle: a host that is descheduled for tens of milliseconds at a time (CPU quota shared with other work) or simply behind (a busy
+// interpreter) - up to CHK_MAX_AHEAD chunks; a batch without such an observation takes one chunk off again.
 static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
     const int R = e->R, left = e->max_steps - 1 - e->steps_run;
     if (n_steps > left) n_steps = left;
@@ -1360,6 +1361,16 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
     };
     while (done < n_steps && !all_stopped) {
         const int n = n_steps - done < C ? n_steps - done : C;
+        // The chunk queued last is already complete as the next one is about to go out: the stream is empty, the device has been idle since -
+        // this thread is late by more than a chunk (descheduled, or behind other host work).  Keep more chunks queued.
+        if (launched > 0 && hipEventQuery(e->chk_ev[(launched - 1) % CHK_RING]) == hipSuccess) {
+            if (launched - last_grow > e->lookahead && e->lookahead < CHK_MAX_AHEAD) {      // (the deeper queue gets `lookahead` launches to show before it grows again)
+                e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
+                last_grow = launched;
+            }
+            starved = true;
+        }
+        (void)hipGetLastError();
         const auto t_l = clk::now();
         if (use_graph) {
             hipGraphExec_t gx = nullptr;
@@ -1380,15 +1391,6 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
             const int r = read_check(launched - checked > e->lookahead);
             if (r < 0) return fail(e, SONIC_ERR_HIP, "decode loop: check event failed: %s", hipGetErrorString(hipGetLastError()));
             if (r == 0) break;
-        }
-        // every chunk queued so far is already complete, the one queued a moment ago included: the device ran dry while this thread was away
-        // (on a host that keeps up, the newest chunk is at most running when its predecessor's check comes back)
-        if (!all_stopped && checked == launched && done < n_steps) {
-            if (launched - last_grow > e->lookahead && e->lookahead < CHK_MAX_AHEAD) {      // (the deeper queue gets `lookahead` launches to show before it grows again)
-                e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
-                last_grow = launched;
-            }
-            starved = true;
         }
     }
     e->run_starved = e->run_starved || starved;
@@ -1747,6 +1749,8 @@ extern "C" int sonic_service_end(sonic_engine* e) {
     ENTER(e);
     if (!e->svc_on) return SONIC_OK;
     HIPC(e, stream_sync(e));
+    if (getenv("SONIC_SVC_STATS")) fprintf(stderr, "[sonic] continuous loop: %lld chunks queued, %lld launches found the stream empty with rows running, lookahead %d at the end\n",
+                                           (long long)e->svc_launched, (long long)e->svc_dry, e->lookahead);
     if (e->st_lo && e->st == e->st_hi) { drop_graphs_of(e); e->st = e->st_lo; }      // (graphs replay on any stream; dropped anyway so that each stream keeps its own)
     e->svc_on = false;
     return SONIC_OK;
@@ -1809,6 +1813,13 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
     };
     for (int c = 0; c <= n_chunks; ++c) {
         if (c < n_chunks) {
+            // rows were running at the last check and the chunk queued last is already complete: the device has been idle waiting for this
+            // thread (late by more than a chunk: descheduled, or behind other host work - the Python side of 128 sessions is).  Queue deeper.
+            if (e->svc_launched > 0 && e->svc_active > 0 && hipEventQuery(e->chk_ev[(e->svc_launched - 1) % CHK_RING]) == hipSuccess) {
+                e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
+                e->svc_calm = 0; ++e->svc_dry;
+            } else if (++e->svc_calm >= 512 && e->lookahead > 1) { e->lookahead -= 1; e->svc_calm = 0; }   // ... and shallower again after a calm stretch (a splice waits behind the queue)
+            (void)hipGetLastError();
             hipGraphExec_t gx = nullptr;
             TRY(chunk_graph(e, R, C, &gx));
             HIPC(e, hipGraphLaunch(gx, e->st));
@@ -1823,10 +1834,6 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
             if (r < 0) return fail(e, SONIC_ERR_HIP, "continuous decode loop: check event failed: %s", hipGetErrorString(hipGetLastError()));
             if (r == 0) break;
         }
-        if (c < n_chunks && e->svc_checked == e->svc_launched && e->svc_active > 0) {      // the device ran dry with rows running: keep more chunks queued
-            e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
-            e->svc_calm = 0;
-        } else if (c < n_chunks && ++e->svc_calm >= 256 && e->lookahead > 1) { e->lookahead -= 1; e->svc_calm = 0; }   // ... and fewer again after a calm stretch (a splice waits behind the queued chunks)
     }
     if (finished_out) memcpy(finished_out, e->svc_fin, 64 * 4);
     if (n_new_out) memcpy(n_new_out, e->svc_nn, 64 * 4);

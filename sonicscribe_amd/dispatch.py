@@ -184,8 +184,7 @@ class _ContinuousReplica:
     """Row-level scheduling on one weight copy (include/sonic_hip.h sonic_service_*): the replica's engine (and, with decoders > 1, that many
     of its slots) decodes FOREVER over its max_batch rows; the remaining slots only prefill.  A request goes: queue -> a prefill slot takes
     whatever is queued (no linger, any mix of step classes, as many requests as the emptiest decoder has free rows) -> log-mel, encoder,
-    prompt forward, first token (queued, not waited for) -> its row is spliced into a free row of that decoder between two chunks (the copies
-    order themselves behind the prefill on the device) -> it leaves the moment it hits EOS / its budget.  Nobody waits for a running batch to
+    prompt forward, first token -> its row is spliced into a free row of that decoder between two chunks -> it leaves the moment it hits EOS / its budget.  Nobody waits for a running batch to
     end and no row idles until the slowest row of its batch is done - what the reference's per-connection `await transcribe()`
     (connection_manager.py:127-245) turns into when every session shares one device.  Tokens equal the solo run's bit for bit (decode rows are
     independent)."""
@@ -264,7 +263,10 @@ class _ContinuousReplica:
             segs.extend(r.windows)
             req_win.append(len(segs))
         eng.stage_pcm(segs, req_win)
-        eng.prefill([r.prompt for r in batch], [r.max_new for r in batch], req_win, wait=False)   # queued; the splice orders itself behind it on the device
+        # waited for: a splice queued behind a prefill that is still running would hold the decoder's whole stream (every running row) at the
+        # event until the prefill is done - final p50 at 128 sessions 438 -> 657 ms when the hand-over came early.  (The bulk pipeline hands over
+        # early, sonicscribe_amd/pipeline.py: its next batch is long done when a block frees up.)
+        eng.prefill([r.prompt for r in batch], [r.max_new for r in batch], req_win)
 
     def _hand(self, eng, batch: List[Request], k: int):
         h = _Handover(eng, batch)

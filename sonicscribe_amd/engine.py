@@ -475,6 +475,10 @@ class Engine:
         self._check(self.lib.sonic_fetch_row(self.h, int(row), int(n), _p(out)))
         return out[:n].copy()
 
+    def synchronize(self):
+        """block until everything queued on this handle's stream has completed (sonic_synchronize)"""
+        self._check(self.lib.sonic_synchronize(self.h))
+
     def wait(self, block: bool = True) -> bool:
         """Collect the asynchronous run (raises its error).  block=False: returns False while it is still running."""
         busy = C.c_int32(0)
