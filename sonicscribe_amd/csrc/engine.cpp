@@ -125,7 +125,6 @@ struct sonic_engine {
     int* svc_h = nullptr;                                          // pinned ring [CHK_RING][SVC_WORDS]: finished[64] | n_new[64] | n_active
     int svc_fin[64]{}, svc_nn[64]{}, svc_active = 0; int64_t svc_seq = 0;   // the newest check read: state after chunk number svc_seq
     hipEvent_t sync_ev = nullptr;                                  // blocking-sync event behind stream_sync()
-    hipStream_t st_lo = nullptr, st_hi = nullptr;                  // st is one of these: the ordinary stream, or (continuous decoding, option "svc_priority") a high-priority one
     hipStream_t st_io = nullptr;                                   // row fetches (a finished row's ids are stable: no ordering against the queued chunks needed)
     hipEvent_t xfer_ev = nullptr, splice_ev = nullptr, wait_ev = nullptr; bool wait_pending = false;   // cross-handle ordering of a splice
 
@@ -138,7 +137,6 @@ struct sonic_engine {
     LaunchOpts opts;
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
-    int opt_svc_priority = 1;      // continuous decoding runs on a high-priority stream: its small latency-bound kernels go ahead of the prefill slots' GEMM tiles
     int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
     int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
@@ -538,7 +536,7 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     e->lc = root->lc; e->enc_cs = root->enc_cs; e->dec_cs = root->dec_cs;
     e->opts = root->opts; e->opt_no_graph = root->opt_no_graph; e->opt_no_fused_rope = root->opt_no_fused_rope; e->opt_no_gelu_lut = root->opt_no_gelu_lut;
     e->opt_i8_defer_thr = root->opt_i8_defer_thr; e->opt_i8_no_xq = root->opt_i8_no_xq; e->opt_i8_no_lnq = root->opt_i8_no_lnq; e->opt_i8_no_qkv_fuse = root->opt_i8_no_qkv_fuse;
-    e->opt_decode_chunk = root->opt_decode_chunk; e->opt_svc_priority = root->opt_svc_priority;
+    e->opt_decode_chunk = root->opt_decode_chunk;
     e->weight_bytes = 0; e->finalized = true; e->owner = root;
     root->slots.push_back(e);
     *out = e;
@@ -592,8 +590,6 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->sync_ev) (void)hipEventDestroy(e->sync_ev);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
     if (e->st) (void)hipStreamDestroy(e->st);
-    if (e->st_lo && e->st_lo != e->st) (void)hipStreamDestroy(e->st_lo);
-    if (e->st_hi && e->st_hi != e->st) (void)hipStreamDestroy(e->st_hi);
     delete e;
 }
 
@@ -1654,7 +1650,6 @@ extern "C" int sonic_run_staged(sonic_engine* e, const int32_t* req_win, int R, 
     return run_all(e, req_win, R, prompt_ids, prompt_off, max_new, want_step_logits != 0);
 }
 
-static void drop_graphs_of(sonic_engine* e) { for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second); e->graphs.clear(); }
 // ---- continuous decoding (VERDICT r3 item 8 "row refill", generalised): one handle decodes forever over a pool of Bm rows, requests join and
 // leave row by row.  The reference serialises every decode of every session (backend/connection_manager.py:127-245 awaits one transcribe() at a
 // time per connection, backend/transcription_manager.py:58 blocks the event loop); a batch engine makes a request wait for the running batch to
@@ -1721,14 +1716,6 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
     if (e->svc_on) return SONIC_OK;
     HIPC(e, stream_sync(e));
-    if (e->opt_svc_priority) {
-        if (!e->st_hi) {
-            int lo = 0, hi = 0;                                  // (numerically lower = higher priority)
-            HIPC(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPC(e, hipStreamCreateWithPriority(&e->st_hi, hipStreamNonBlocking, hi));
-        }
-        if (e->st != e->st_hi) { drop_graphs_of(e); e->st_lo = e->st; e->st = e->st_hi; }
-    }
     hipLaunchKernelGGL(service_reset_kernel, dim3(1), dim3(64), 0, e->st, e->kv_len, e->tok_pos, e->n_new, e->finished, e->max_new_d, e->n_active);
     if (e->force_d) return fail(e, SONIC_ERR_INVALID, "teacher forcing is set: clear it before continuous decoding");
     hipGraphExec_t gx = nullptr;                            // the chunk graphs exist before the first splice: nothing captures on this stream later
@@ -1751,7 +1738,6 @@ extern "C" int sonic_service_end(sonic_engine* e) {
     HIPC(e, stream_sync(e));
     if (getenv("SONIC_SVC_STATS")) fprintf(stderr, "[sonic] continuous loop: %lld chunks queued, %lld launches found the stream empty with rows running, lookahead %d at the end\n",
                                            (long long)e->svc_launched, (long long)e->svc_dry, e->lookahead);
-    if (e->st_lo && e->st == e->st_hi) { drop_graphs_of(e); e->st = e->st_lo; }      // (graphs replay on any stream; dropped anyway so that each stream keeps its own)
     e->svc_on = false;
     return SONIC_OK;
 }
@@ -2325,7 +2311,6 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
-    if (!strcmp(key, "svc_priority")) { e->opt_svc_priority = value; return SONIC_OK; }     // continuous decoding on a high-priority stream (A/B)
     if (!strcmp(key, "decode_lookahead")) { e->lookahead = value < 1 ? 1 : (value > CHK_MAX_AHEAD ? CHK_MAX_AHEAD : value); return SONIC_OK; }   // start value (it adapts)
     if (!strcmp(key, "decode_chunk")) { e->opt_decode_chunk = value > 0 ? (value > 64 ? 64 : value) : 1; return SONIC_OK; }   // token steps per graph launch / early-stop check
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
