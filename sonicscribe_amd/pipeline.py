@@ -75,12 +75,13 @@ class ContinuousPipeline:
                             p, ev = ready.get(block=not occupied, timeout=0.02)
                         except queue.Empty:
                             break
-                        b = free.pop(0)
+                        free.sort()
+                        b = free.pop(0)                          # lowest free block: the loop steps only as many rows as are occupied
                         occupied[b] = d.splice_rows(p, list(range(self.block)), self.blocks[b])
                         ev.set()
                     if not occupied:
                         continue
-                    fin, nn, seq, _ = d.service_step(1)
+                    fin, nn, seq, _ = d.service_step(1, (max(occupied) + 1) * self.block)
                     steps = 1
                     for b, va in list(occupied.items()):
                         if seq > va and all(fin[r] for r in self.blocks[b]):
