@@ -60,6 +60,7 @@ struct LaunchOpts {
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
     int no_fused_gu64 = 0;     // ... only for batches of 33 .. 64 rows (round 3's path there; A/B)
     int no_skinny768 = 0;      // decode skinny GEMM: never the 768-deep K slices (A/B)
+    int gemm_small_eff = 75;   // 256x256 grids that under-fill the chip go to the 128x128 kernel, priced at this % of the big kernel's rate (0: never)
     int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)
     int no_skinny_i8_wide = 0; // int8 decode skinny GEMM: always 32 rows x 1024 per block (A/B)
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart

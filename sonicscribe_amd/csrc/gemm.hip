@@ -252,8 +252,21 @@ static void launch_tile256(const GemmArgs& a, int epi, hipStream_t s) {
 #endif
     launch_gemm256(a, epi, s);
 }
+// A 256x256 tile owns a CU, so a grid of fewer tiles than CUs leaves the rest of the chip idle for the whole GEMM (one 5 s request through
+// the encoder: 30 .. 120 tiles per linear on 256 CUs).  The 128x128 kernel cuts the same problem into four times as many tiles, two to a CU,
+// at about `gemm_small_eff` % of the big kernel's per-CU rate when both are full: it gets the GEMM whenever its tile rounds, priced that way,
+// are fewer.  Both kernels produce the same bits (tests/test_gpu_parity.py test_gemm256_path), so the choice never shows in a result.  Not the
+// q|k|v epilogue: its fused RoPE exists only on the 256x256 tile, and rotating before the bf16 rounding is not the separate pass's arithmetic.
+static bool small_grid_prefers128(const GemmArgs& a, int epi) {
+    const int eff = g_opts.gemm_small_eff;
+    if (eff <= 0 || epi == EPI_QKV_VT) return false;
+    const long cus = device_cus(), batch = a.batch > 0 ? a.batch : 1;
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * batch, t128 = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * batch;
+    const long r256 = (t256 + cus - 1) / cus, r128 = (t128 + 2 * cus - 1) / (2 * cus);
+    return r128 * 50 < r256 * eff;      // a round of 128x128 tiles is half the work per CU of a round of 256x256 tiles
+}
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if (!g_opts.gemm_force128 && gemm256_eligible(a, epi)) {
+    if (!g_opts.gemm_force128 && gemm256_eligible(a, epi) && !small_grid_prefers128(a, epi)) {
         // Wave quantisation: a 256x256 tile occupies a whole CU, so (tiles mod CUs) small means a nearly empty extra round (prefill at
         // M = 8320: 33 x 8 = 264 tiles on 256 CUs, two rounds for 1.03).  If cutting the ragged last <= 128 rows off saves a round, those
         // rows go to the 128x128 kernel instead (same math per row; rows are independent in every epilogue but QKV+V^T).
