@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -405,13 +406,40 @@ static int check_dims(const sonic_dims& d, int max_batch, int max_ctx, int mode)
 }
 
 extern "C" void sonic_destroy(sonic_engine* e);
+// The main stream of a handle.  Experiments (tools/ab_stream_partition.sh, `make SONIC_AB=1` builds only): SONIC_EXP_PRIO / SONIC_EXP_CUS are comma lists indexed by the order in
+// which this process created its handles - a stream priority (-1 high .. 1 low), or "lo-hi" = the CUs the handle's kernels may run on.
+static hipError_t create_stream(hipStream_t* st) {
+#ifdef SONIC_AB      // measured and lost (profiles/round4_stream_partition.txt): priorities change nothing, CU masks cost 19 .. 42 %
+    static std::atomic<int> created{0};
+    const int idx = created.fetch_add(1);
+    auto field = [&](const char* env, char* out, size_t cap) -> bool {
+        const char* v = getenv(env);
+        if (!v) return false;
+        for (int i = 0; i < idx && v; ++i) { v = strchr(v, ','); if (v) ++v; }
+        if (!v || !*v || *v == ',') return false;
+        size_t n = strcspn(v, ","); if (n >= cap) n = cap - 1;
+        memcpy(out, v, n); out[n] = 0; return true;
+    };
+    char buf[64];
+    if (field("SONIC_EXP_CUS", buf, sizeof buf)) {
+        int lo = 0, hi = 255;
+        if (sscanf(buf, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi >= lo && hi < 256) {
+            uint32_t mask[8] = {0};
+            for (int c = lo; c <= hi; ++c) mask[c / 32] |= 1u << (c % 32);
+            return hipExtStreamCreateWithCUMask(st, 8, mask);
+        }
+    }
+    if (field("SONIC_EXP_PRIO", buf, sizeof buf)) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, atoi(buf));
+#endif
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 // Everything an engine (or a slot) owns besides weights and constants: its stream, PCM staging, activation buffers, KV cache, decode-step
 // buffers, control words, events.
 static int alloc_state(sonic_engine* e) {
     if (hipSetDevice(e->device) != hipSuccess) { e->err = "hipSetDevice failed"; return SONIC_ERR_HIP; }
     // waits sleep instead of spinning (see stream_sync): the runtime's default (hipDeviceScheduleAuto) spins when it sees more CPUs than GPUs
     if (!getenv("SONIC_SPIN_SYNC") && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
-    if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return SONIC_ERR_HIP; }
+    if (create_stream(&e->st) != hipSuccess) { e->err = "hipStreamCreate failed"; return SONIC_ERR_HIP; }
     if (!getenv("SONIC_SPIN_SYNC") && hipEventCreateWithFlags(&e->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e->sync_ev = nullptr; }
     const sonic_dims& d = e->d;
     const int Bm = e->Bm, max_batch = e->Bm, max_ctx = e->max_ctx;
