@@ -236,7 +236,8 @@ class ASRModel:
         self.decoders = max(1, int(decoders)) if self.continuous else 0
         self.slots = max(self.decoders + 1 if self.continuous else 1, int(slots))
         self._slot_engines = [[eng.slot() for _ in range(self.slots - 1)] for eng in self.models]     # same weights, further batches in flight
-        self._dispatcher = Dispatcher(self.models, slots=self._slot_engines, continuous=self.continuous, decoders=self.decoders or 1)
+        self._dispatcher = Dispatcher(self.models, slots=self._slot_engines, continuous=self.continuous, decoders=self.decoders or 1,
+                                      adaptive_tiles="gemm_small_eff" not in (_options or {}))
         print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
               f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s), {self.slots} batch slot(s) each)")
 

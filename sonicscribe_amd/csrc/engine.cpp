@@ -2335,6 +2335,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
     if (!strcmp(key, "flash_variant")) { e->opts.flash_variant = value; return SONIC_OK; }
     if (!strcmp(key, "gemm256_persist")) { e->opts.gemm256_persist = value; return SONIC_OK; }
+    if (!strcmp(key, "gemm256_persist_cus")) { e->opts.gemm256_persist_cus = value > 0 ? value : 256; return SONIC_OK; }
     if (!strcmp(key, "gemm256_gm")) { e->opts.gemm256_gm = value > 0 ? value : 8; return SONIC_OK; }   // raster group height of the 256x256 GEMM (experiments)
     if (!strcmp(key, "i8_defer_thr")) { e->opt_i8_defer_thr = value; return SONIC_OK; }   // int8: outlier lists longer than this go to the dense side product (-1: never)
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)

@@ -248,7 +248,7 @@ static int device_cus() {
 // the 256x256 tile: persistent kernel for the 16-bit kinds (gemm256p.hip), one launch per tile round otherwise (int8 kinds, batched conv stem)
 static void launch_tile256(const GemmArgs& a, int epi, hipStream_t s) {
 #ifdef SONIC_AB      // the persistent form lost every A/B: it ships only in `make SONIC_AB=1` builds
-    if (!a.q.sca && a.batch <= 1 && g_opts.gemm256_persist) { launch_gemm256p(a, epi, device_cus(), s); return; }
+    if (!a.q.sca && a.batch <= 1 && g_opts.gemm256_persist) { launch_gemm256p(a, epi, (g_opts.gemm256_persist_cus < device_cus() ? g_opts.gemm256_persist_cus : device_cus()), s); return; }
 #endif
     launch_gemm256(a, epi, s);
 }

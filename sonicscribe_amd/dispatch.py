@@ -189,8 +189,12 @@ class _ContinuousReplica:
     (connection_manager.py:127-245) turns into when every session shares one device.  Tokens equal the solo run's bit for bit (decode rows are
     independent)."""
 
-    def __init__(self, engine, index: int, slots: Sequence[Any], decoders: int = 1):
+    def __init__(self, engine, index: int, slots: Sequence[Any], decoders: int = 1, adaptive_tiles: bool = True):
         decoders = max(1, int(decoders))
+        # A prefill beside RUNNING rows keeps the big GEMM tiles even where they under-fill the chip (engine option gemm_small_eff = 0): the
+        # idle CUs are where the decode loop's kernels run meanwhile.  Small tiles everywhere took a lone request's encoder 8.8 -> 7.2 ms but
+        # the final p50 of 128 sessions 431 -> 490 ms (profiles/round4_streaming_ab.txt).  The tile choice never changes a result's bits.
+        self.adaptive_tiles = bool(adaptive_tiles)
         if len(slots) < decoders:
             raise ValueError("continuous decoding needs at least one prefill slot per replica beside its decoding handles")
         self.engine, self.index = engine, index
@@ -262,6 +266,10 @@ class _ContinuousReplica:
         for r in batch:
             segs.extend(r.windows)
             req_win.append(len(segs))
+        if self.adaptive_tiles:
+            with self.cv:
+                busy = sum(self.n_rows - f for f in self.free) > len(batch)        # rows running or reserved besides this batch's own
+            eng.set_option("gemm_small_eff", 0 if busy else 75)
         eng.stage_pcm(segs, req_win)
         # waited for: a splice queued behind a prefill that is still running would hold the decoder's whole stream (every running row) at the
         # event until the prefill is done - final p50 at 128 sessions 438 -> 657 ms when the hand-over came early.  (The bulk pipeline hands over
@@ -372,7 +380,8 @@ class _ContinuousReplica:
 
 
 class Dispatcher:
-    def __init__(self, engines: Sequence[Any], slots: Optional[Sequence[Sequence[Any]]] = None, continuous: bool = False, decoders: int = 1):
+    def __init__(self, engines: Sequence[Any], slots: Optional[Sequence[Sequence[Any]]] = None, continuous: bool = False, decoders: int = 1,
+                 adaptive_tiles: bool = True):
         """engines: one per replica (its own weights).  slots[i]: further engine handles that share replica i's weights (Engine.slot()).
         continuous: row-level scheduling (_ContinuousReplica: the engine - and decoders - 1 of its slots - decode forever, the other slots
         prefill) instead of batch by batch."""
@@ -380,7 +389,7 @@ class Dispatcher:
             raise ValueError("at least one engine")
         self.continuous = bool(continuous)
         if continuous:
-            self.replicas = [_ContinuousReplica(e, i, slots[i] if slots else (), decoders) for i, e in enumerate(engines)]
+            self.replicas = [_ContinuousReplica(e, i, slots[i] if slots else (), decoders, adaptive_tiles) for i, e in enumerate(engines)]
         else:
             self.replicas = [_Replica(e, i, slots[i] if slots else ()) for i, e in enumerate(engines)]
 

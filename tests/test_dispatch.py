@@ -219,6 +219,10 @@ class StubPool:
     class Prefill:
         def __init__(self, pool, max_batch):
             self.pool, self.max_batch, self.staged, self.rows, self.batches = pool, max_batch, None, [], []
+            self.options = []
+
+        def set_option(self, key, value):
+            self.options.append((key, value))
 
         def stage_pcm(self, segs, req_win=None):
             self.staged = (list(segs), list(req_win))
@@ -299,6 +303,26 @@ def test_continuous_replica_rows_join_and_leave_one_by_one():
     [f.result(timeout=10) for f in long_f]
     d.close()
     assert not pool.decoder.on
+
+
+def test_continuous_replica_picks_gemm_tiles_by_what_else_is_running():
+    """A prefill on an idle replica asks for small GEMM tiles where the big ones under-fill the chip; beside running rows it leaves the idle
+    CUs to the decode loop (gemm_small_eff 75 / 0); an explicit user setting switches the rule off."""
+    pool = StubPool(n_rows=4, prefill_batch=4, prefill_delay=0.001, step_delay=0.002)
+    d = Dispatcher([pool.decoder], slots=[pool.prefills], continuous=True)
+    d.submit([seg(1)], [1], 8).result(timeout=5)
+    assert pool.prefills[0].options == [("gemm_small_eff", 75)]
+    long_f = d.submit([seg(2)], [1], 150)
+    time.sleep(0.02)
+    d.submit([seg(3)], [1], 4).result(timeout=5)
+    assert pool.prefills[0].options[1:] == [("gemm_small_eff", 75), ("gemm_small_eff", 0)]
+    long_f.result(timeout=10)
+    d.close()
+    pool = StubPool(n_rows=4, prefill_batch=4)
+    d = Dispatcher([pool.decoder], slots=[pool.prefills], continuous=True, adaptive_tiles=False)
+    d.submit([seg(1)], [1], 8).result(timeout=5)
+    assert pool.prefills[0].options == []
+    d.close()
 
 
 def test_continuous_replica_two_decoders_share_the_prefill_slot():

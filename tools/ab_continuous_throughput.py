@@ -9,6 +9,7 @@ from dataclasses import replace
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch  # noqa: F401  (first, so that a run under rocprofv3 uses torch's bundled HIP runtime: tools/rocprof_runtime_repro.py)
 
 from sonicscribe_amd import spec, synth
 from sonicscribe_amd.engine import Engine
@@ -24,6 +25,8 @@ dims = replace(spec.FULL, eos_ids=())
 dec = Engine(dims, 0, max_batch=rows, max_ctx=512)
 dec.load_synthetic(20260128)
 dec.set_option("decode_chunk", chunk)
+for kv in filter(None, os.environ.get("SONIC_TOOL_OPTS", "").split(",")):      # engine knobs for A/B runs: SONIC_TOOL_OPTS=key=int,key=int
+    dec.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 prompt = [1, 17, 23, 5] + [dims.audio_token_id] * spec.audio_token_count(spec.valid_frames(n_samples)) + [7, 301, 302, 303, 9, 11]
 segs = [synth.synth_pcm(i, n_samples) for i in range(B)]
 want, _ = dec.transcribe_batch(segs, [prompt] * B, [max_new] * B)          # plain batch run: the tokens every row must reproduce
