@@ -1799,6 +1799,8 @@ extern "C" int sonic_splice_rows(sonic_engine* d, sonic_engine* p, int n, const 
     hipLaunchKernelGGL(splice_kv_kernel, dim3(n, dm.dec_layers * dm.dec_kv_heads), dim3(256), 0, d->st, a);
     hipLaunchKernelGGL(splice_state_kernel, dim3(n), dim3(256), 0, d->st, a);
     HIPC(d, hipEventRecord(d->splice_ev, d->st));
+    // (rows of one prefill may go to several decoders: an earlier splice's event is not forgotten, the source's stream takes it on now)
+    if (p->wait_pending && p->wait_ev != d->splice_ev) HIPC(d, hipStreamWaitEvent(p->st, p->wait_ev, 0));
     p->wait_ev = d->splice_ev; p->wait_pending = true;
     HIPC(d, hipGetLastError());
     if (seq_out) *seq_out = d->svc_launched;
@@ -1861,6 +1863,8 @@ extern "C" int sonic_fetch_row(sonic_engine* e, int row, int n, int32_t* out_ids
     ENTER(e);
     if (!e->svc_on) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_row needs sonic_service_begin");
     if (row < 0 || row >= e->Bm || n < 0 || n > e->out_cap) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_row: row %d / %d tokens out of range", row, n);
+    // (a row the newest check saw running is running: releasing it would leave the count of running rows one too high for good)
+    if (e->svc_checked > 0 && !e->svc_fin[row]) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_row: row %d has not finished (sonic_service_step's finished[])", row);
     if (n > 0) {
         HIPC(e, hipMemcpyAsync(out_ids, e->out_ids + (size_t)row * e->out_cap, (size_t)n * 4, hipMemcpyDeviceToHost, e->st_io));
         HIPC(e, hipStreamSynchronize(e->st_io));

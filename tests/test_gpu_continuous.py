@@ -82,6 +82,40 @@ def test_spliced_rows_equal_solo_runs(dims, mode):
     dec.close()
 
 
+def test_one_prefill_feeds_two_decoders_and_running_rows_cannot_be_fetched():
+    """Rows of ONE prefill go to two decoding handles; the slot's next prefill must wait for BOTH copies (each decoder has its own splice event).
+    And sonic_fetch_row refuses a row the newest check saw running."""
+    dims = replace(spec.TINY, eos_ids=())
+    dec = make(dims, 32)
+    dec2, pre = dec.slot(), dec.slot()
+    segs = [synth.synth_pcm(700 + i, 16000 * (3 + i % 4)) for i in range(8)]
+    prompts = [prompt_for(dims, len(s)) for s in segs]
+    budgets = [30, 12, 25, 18, 22, 9, 28, 14]
+    solo = [dec.transcribe_batch([segs[i]], [prompts[i]], [budgets[i]])[0][0] for i in range(8)]
+    dec.service_begin(); dec2.service_begin()
+    got = {}
+    pre.stage_pcm(segs[:4]); pre.prefill(prompts[:4], budgets[:4], wait=False)
+    sa = dec.splice_rows(pre, [0, 1], [3, 4])
+    sb = dec2.splice_rows(pre, [2, 3], [0, 20])
+    pre.stage_pcm(segs[4:]); pre.prefill(prompts[4:], budgets[4:], wait=False)         # overwrites the slot's rows: only behind both splices
+    fin, nn, seq, n_act = dec.service_step(1, 5)
+    while seq <= sa:
+        fin, nn, seq, n_act = dec.service_step(1, 5)
+    if not fin[3]:
+        with pytest.raises(RuntimeError):
+            dec.fetch_row(3, 1)
+    sc = dec.splice_rows(pre, [0, 1], [10, 11])
+    sd = dec2.splice_rows(pre, [2, 3], [1, 2])
+    for r, ids in drain(dec, {3: sa, 4: sa, 10: sc, 11: sc}).items():
+        got[{3: 0, 4: 1, 10: 4, 11: 5}[r]] = ids
+    for r, ids in drain(dec2, {0: sb, 20: sb, 1: sd, 2: sd}).items():
+        got[{0: 2, 20: 3, 1: 6, 2: 7}[r]] = ids
+    for i in range(8):
+        assert np.array_equal(got[i], solo[i]), i
+    dec.service_end(); dec2.service_end()
+    dec.close()
+
+
 def test_rows_that_stop_at_eos_are_refilled():
     """rows that hit EOS early hand their slot to queued requests while the long rows keep decoding; refilled rows are
     bit-identical to solo runs (an engineered EOS set, as tests/test_gpu_benchsize.py::test_eos_stop_vs_oracle does)."""
