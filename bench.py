@@ -46,6 +46,8 @@ from dataclasses import replace
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before anything starts the HIP runtime (sonicscribe_amd/__init__.py says why)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

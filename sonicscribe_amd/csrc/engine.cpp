@@ -377,6 +377,13 @@ static int build_constants(sonic_engine* e) {
 }
 
 // ------------------------------------------------------------------------------------------ create / destroy
+// The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round-robin in creation order; streams that
+// share a queue execute in order.  An engine with two slots owns six streams (one main + one fetch stream per handle), plus one per device
+// ring: with four queues the prefill slot's stream landed on the queue of a decoding handle and the bulk pipeline lost 7 % (141 vs 151
+// segments/s, profiles/round4_hw_queues.txt).  Ask for more queues before the runtime starts - it reads the variable at its first call; a
+// host that has already used HIP keeps what it had, and a value set by the user is left alone.
+__attribute__((constructor)) static void sonic_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int sonic_abi_version(void) { return SONIC_ABI_VERSION; }
 extern "C" int sonic_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
@@ -1834,7 +1841,8 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
             if (e->svc_launched > 0 && e->svc_active > 0 && hipEventQuery(e->chk_ev[(e->svc_launched - 1) % CHK_RING]) == hipSuccess) {
                 e->lookahead = e->lookahead * 2 < CHK_MAX_AHEAD ? e->lookahead * 2 : CHK_MAX_AHEAD;
                 e->svc_calm = 0; ++e->svc_dry;
-            } else if (++e->svc_calm >= 512 && e->lookahead > 1) { e->lookahead -= 1; e->svc_calm = 0; }   // ... and shallower again after a calm stretch (a splice waits behind the queue)
+            } else if (++e->svc_calm >= 64 && e->lookahead > 1) { e->lookahead /= 2; e->svc_calm = 0; }   // ... and shallower again after a calm stretch: a splice waits
+                                                                                                            // behind the queue and finished rows are seen that many chunks late
             (void)hipGetLastError();
             hipGraphExec_t gx = nullptr;
             TRY(chunk_graph(e, R, C, &gx));

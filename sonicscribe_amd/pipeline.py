@@ -21,12 +21,12 @@ import numpy as np
 
 
 class ContinuousPipeline:
-    def __init__(self, decoders: Sequence[Any], prefills: Sequence[Any], block: int = 32):
+    def __init__(self, decoders: Sequence[Any], prefills: Sequence[Any], block: int = 32, pair: bool = True):
         """decoders / prefills: engine handles sharing one weight copy (an Engine and its slot()s), all with the same max_batch; a decoder holds
         max_batch // block batches at a time.  Decoders are put into continuous mode here and taken out by close()."""
         if not decoders or not prefills:
             raise ValueError("at least one decoder and one prefill slot")
-        self.decoders, self.prefills, self.block = list(decoders), list(prefills), int(block)
+        self.decoders, self.prefills, self.block, self.pair = list(decoders), list(prefills), int(block), bool(pair)
         self.blocks = [list(range(i, i + self.block)) for i in range(0, (self.decoders[0].max_batch // self.block) * self.block, self.block)]
         if not self.blocks:
             raise ValueError("max_batch is smaller than a block")
@@ -62,7 +62,10 @@ class ContinuousPipeline:
             except BaseException as ex:
                 errors.append(ex)
 
+        half = {}                                                # decoder index -> it has both running and free blocks right now
+
         def decoder(d):
+            k = self.decoders.index(d)
             free = list(range(len(self.blocks)))
             occupied = {}                                        # block -> chunk sequence number after which its flags are valid
             try:
@@ -70,6 +73,13 @@ class ContinuousPipeline:
                     with lock:
                         if state["done"] >= n_batches:
                             return
+                        half[k] = bool(occupied) and bool(free)
+                        # an EMPTY loop leaves the next batch to a loop that is running part-filled: two batches in one 64-row loop read the
+                        # weights once (1.83 ms per step), two part-filled loops read them twice (2 x 1.35 ms)
+                        defer = self.pair and not occupied and any(v for j, v in half.items() if j != k)
+                    if defer:
+                        time.sleep(0.002)
+                        continue
                     while free:
                         try:
                             p, ev = ready.get(block=not occupied, timeout=0.02)
@@ -83,8 +93,14 @@ class ContinuousPipeline:
                         continue
                     fin, nn, seq, _ = d.service_step(1, (max(occupied) + 1) * self.block)
                     steps = 1
+                    done_blocks = [b for b, va in occupied.items() if seq > va and all(fin[r] for r in self.blocks[b])]
+                    if done_blocks and len(done_blocks) < len(occupied):
+                        # fetching a block's rows takes this thread about as long as a chunk takes the device: the other block's next chunk goes
+                        # out first, or the stream runs dry under the fetches (and the engine answers by queueing ever deeper)
+                        d.service_step(1, (max(occupied) + 1) * self.block)
+                        steps += 1
                     for b, va in list(occupied.items()):
-                        if seq > va and all(fin[r] for r in self.blocks[b]):
+                        if b in done_blocks:
                             bad = 0
                             for i, r in enumerate(self.blocks[b]):
                                 ids = d.fetch_row(r, int(nn[r]))

@@ -34,11 +34,11 @@ pre = [dec.slot() for _ in range(n_prefill)]
 decs = [dec] + [dec.slot() for _ in range(n_dec - 1)]
 for p in pre:
     p.stage_pcm(segs)                                                       # PCM stays staged on the slot
-pipe = ContinuousPipeline(decs, pre, block=B)
+pipe = ContinuousPipeline(decs, pre, block=B, pair=os.environ.get("SONIC_PIPE_PAIR", "1") != "0")
 run = lambda n: pipe.run(n, lambda p: p.prefill([prompt] * B, [max_new] * B, wait=False), lambda i, ids: np.array_equal(ids, want[i]))
 for tag, nb in (("warm-up", pipe.batches_in_flight), ("timed", n_batches)):
     r = run(nb)
     print(f"{tag}: {n_dec} decoder(s) x {rows} rows, prefill slots {n_prefill}, chunk {chunk} ({pipe.batches_in_flight} batches in flight): {nb} batches of {B} in "
-          f"{r['wall_s'] * 1e3:.0f} ms = {nb * B / r['wall_s']:.1f} segments/s ({r['wall_s'] / nb * 1e3:.1f} ms per batch); rows differing from the plain batch run: {r['wrong_rows']}", flush=True)
+          f"{r['wall_s'] * 1e3:.0f} ms = {nb * B / r['wall_s']:.1f} segments/s ({r['wall_s'] / nb * 1e3:.1f} ms per batch, {r['decode_chunks']} chunks queued); rows differing from the plain batch run: {r['wrong_rows']}", flush=True)
 pipe.close()
 dec.close()

@@ -24,7 +24,7 @@ python tools/pmc_summary.py /tmp/prof_w > $OUT/pmc_write_size.txt 2>&1
 python tools/decode_traffic.py $OUT/pmc_fetch_size.txt $OUT/pmc_write_size.txt > $OUT/pmc_decode.json 2>&1
 python tools/prof_summary.py /tmp/prof_i8 45 > $OUT/int8_b64_kernel_summary.txt 2>&1
 if [ "${2:-}" = "full" ]; then
-  python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err      # the driver's command line
 fi
 head -30 $OUT/kernel_trace_summary.txt
 cat $OUT/pmc_decode.json | head -8
