@@ -369,3 +369,33 @@ def test_continuous_replica_errors_cancel_and_close():
     with pytest.raises(RuntimeError):
         d2.submit([seg(0)], [1], 20)                                      # a failed engine refuses new work instead of hanging it
     d2.close()
+
+
+def test_bulk_pipeline_pairs_batches_and_checks_every_row():
+    """sonicscribe_amd/pipeline.py (bench.py's headline driver) over stub handles: every batch goes through prefill -> splice -> continuous
+    decode -> fetch, rows are checked, blocks are reused, and an empty decoder leaves the next batch to one that runs part-filled."""
+    from sonicscribe_amd.pipeline import ContinuousPipeline
+    pool = StubPool(n_rows=4, prefill_batch=2, prefill_delay=0.001, step_delay=0.0005)
+    dec2 = StubPool.Decoder(pool, 4)
+    pre = pool.prefills[0]
+    pipe = ContinuousPipeline([pool.decoder, dec2], [pre], block=2)
+    assert pipe.batches_in_flight == 5 and pool.decoder.on and dec2.on
+    n = {"prefills": 0}
+
+    def prefill(p):
+        n["prefills"] += 1
+        p.stage_pcm([seg(7), seg(9)], [0, 1, 2])
+        p.prefill([[1, 2, 3], [1, 2, 3]], [40, 24])
+
+    want = [want_tokens(7, 3, 40), want_tokens(9, 3, 24)]
+    res = pipe.run(9, prefill, lambda i, ids: ids.tolist() == want[i])
+    assert res["batches"] == 9 and res["wrong_rows"] == 0 and n["prefills"] == 9
+    assert pool.decoder.max_occupied <= 4 and dec2.max_occupied <= 4
+    assert all(r is None for r in pool.decoder.rows) and all(r is None for r in dec2.rows)          # every row handed back
+    assert max(pool.decoder.max_occupied, dec2.max_occupied) == 4                                   # two batches shared one loop
+    bad = pipe.run(2, prefill, lambda i, ids: i != 1)                                               # a failing check is counted, not raised
+    assert bad["batches"] == 2 and bad["wrong_rows"] == 2
+    pipe.close()
+    assert not pool.decoder.on and not dec2.on
+    with pytest.raises(ValueError):
+        ContinuousPipeline([], [pre])
