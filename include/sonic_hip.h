@@ -175,12 +175,14 @@ SONIC_API int sonic_prefill_enqueue(sonic_engine* e, const int32_t* req_win, int
  *                               pool steps faster) and return the newest completed check: finished[r] = 1 once row r hit EOS / its budget (or is
  *                               free), n_new[r] its tokens
  *   sonic_fetch_row(d, row, n, ids)   the n tokens of a finished row; the row is free again
+ *   sonic_fetch_rows(d, n, rows, counts, ids, ld)   the same for n finished rows in one call (row i's tokens at ids + i * ld)
  * A request's tokens are the same bits as in a solo run (rows are independent in every decode kernel; tests/test_gpu_continuous.py). */
 SONIC_API int sonic_service_begin(sonic_engine* d);
 SONIC_API int sonic_service_end(sonic_engine* d);
 SONIC_API int sonic_splice_rows(sonic_engine* d, sonic_engine* p, int n, const int32_t* src_rows, const int32_t* dst_rows, int64_t* seq_out);
 SONIC_API int sonic_service_step(sonic_engine* d, int n_chunks, int rows, int32_t* finished_out, int32_t* n_new_out, int64_t* seq_out, int32_t* n_active_out);
 SONIC_API int sonic_fetch_row(sonic_engine* d, int row, int n, int32_t* out_ids);
+SONIC_API int sonic_fetch_rows(sonic_engine* d, int n, const int32_t* rows, const int32_t* counts, int32_t* out_ids, int out_ld);
 
 /* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as
  * 2048-byte chunks in a host dict (backend/audio_manager.py:21-33, fed from backend/main.py:813-842) and concatenates on the host for

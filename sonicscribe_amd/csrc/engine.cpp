@@ -1882,6 +1882,33 @@ extern "C" int sonic_fetch_row(sonic_engine* e, int row, int n, int32_t* out_ids
     return SONIC_OK;
 }
 
+// sonic_fetch_row for n rows in one call: the D2H copies go out together, one wait, one release launch - what a block of 32 finished rows costs
+// the host drops from 32 lock / copy / wait / launch rounds (about a chunk's worth of time, during which the loop's queue could run dry) to one
+__global__ void release_rows_kernel(int* kv_len, int* tok_pos, int* finished, SpliceArgs a, int n) {
+    const int i = threadIdx.x;
+    if (i < n) { const int row = a.dst[i]; kv_len[row] = 1; tok_pos[row] = 0; finished[row] = 1; }
+}
+extern "C" int sonic_fetch_rows(sonic_engine* e, int n, const int32_t* rows, const int32_t* counts, int32_t* out_ids, int out_ld) {
+    if (!e || !rows || !counts || !out_ids) return SONIC_ERR_INVALID;
+    ENTER(e);
+    if (!e->svc_on) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_rows needs sonic_service_begin");
+    if (n < 1 || n > 64) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_rows: %d rows", n);
+    SpliceArgs a{};
+    for (int i = 0; i < n; ++i) {
+        const int row = rows[i], c = counts[i];
+        if (row < 0 || row >= e->Bm || c < 0 || c > e->out_cap || c > out_ld) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_rows: row %d / %d tokens out of range", row, c);
+        if (e->svc_checked > 0 && !e->svc_fin[row]) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_rows: row %d has not finished (sonic_service_step's finished[])", row);
+        for (int j = 0; j < i; ++j) if (rows[j] == row) return fail(e, SONIC_ERR_INVALID, "sonic_fetch_rows: row %d named twice", row);
+        a.dst[i] = row;
+    }
+    for (int i = 0; i < n; ++i)
+        if (counts[i] > 0) HIPC(e, hipMemcpyAsync(out_ids + (size_t)i * out_ld, e->out_ids + (size_t)rows[i] * e->out_cap, (size_t)counts[i] * 4, hipMemcpyDeviceToHost, e->st_io));
+    HIPC(e, hipStreamSynchronize(e->st_io));
+    hipLaunchKernelGGL(release_rows_kernel, dim3(1), dim3(64), 0, e->st, e->kv_len, e->tok_pos, e->finished, a, n);
+    HIPC(e, hipGetLastError());
+    return SONIC_OK;
+}
+
 // ---- asynchronous form: the batch runs on a worker thread of the engine's own; the caller's thread returns at once and may drive other slots.
 // One job per engine (slot) at a time; between sonic_run_staged_async and sonic_wait the handle takes no other call except ring appends.
 static int run_staged_entry(sonic_engine* e) {

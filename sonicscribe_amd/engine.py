@@ -30,7 +30,7 @@ EXPORTS = [
     "sonic_ring_create", "sonic_ring_destroy", "sonic_ring_append", "sonic_ring_head", "sonic_transcribe_mixed", "sonic_stage_mixed",
     "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info",
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
-    "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_prefill_enqueue",
+    "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_fetch_rows", "sonic_prefill_enqueue",
 ]
 ABI_VERSION = 4
 
@@ -141,6 +141,7 @@ def load_library():
     lib.sonic_splice_rows.argtypes = [vp, vp, C.c_int, vp, vp, i64p]
     lib.sonic_service_step.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64p, ip]
     lib.sonic_fetch_row.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.sonic_fetch_rows.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
     for name in EXPORTS:
         getattr(lib, name)
     if lib.sonic_abi_version() != ABI_VERSION:
@@ -474,6 +475,14 @@ class Engine:
         out = np.zeros(max(1, int(n)), np.int32)
         self._check(self.lib.sonic_fetch_row(self.h, int(row), int(n), _p(out)))
         return out[:n].copy()
+
+    def fetch_rows(self, rows: Sequence[int], counts: Sequence[int]) -> List[np.ndarray]:
+        """fetch_row for several finished rows in one call (one wait, one release launch)"""
+        r, c = np.asarray(rows, np.int32), np.asarray(counts, np.int32)
+        ld = max(1, int(c.max()) if len(c) else 1)
+        out = np.zeros((len(r), ld), np.int32)
+        self._check(self.lib.sonic_fetch_rows(self.h, len(r), _p(r), _p(c), _p(out), ld))
+        return [out[i, :int(c[i])].copy() for i in range(len(r))]
 
     def synchronize(self):
         """block until everything queued on this handle's stream has completed (sonic_synchronize)"""

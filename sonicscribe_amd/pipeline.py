@@ -102,8 +102,8 @@ class ContinuousPipeline:
                     for b, va in list(occupied.items()):
                         if b in done_blocks:
                             bad = 0
-                            for i, r in enumerate(self.blocks[b]):
-                                ids = d.fetch_row(r, int(nn[r]))
+                            got = d.fetch_rows(self.blocks[b], [int(nn[r]) for r in self.blocks[b]])
+                            for i, ids in enumerate(got):
                                 if check is not None and not check(i, ids):
                                     bad += 1
                             del occupied[b]; free.append(b)

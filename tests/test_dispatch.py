@@ -275,6 +275,9 @@ class StubPool:
             assert n == len(toks)
             return np.asarray(toks, np.int32)
 
+        def fetch_rows(self, rows, counts):
+            return [self.fetch_row(r, n) for r, n in zip(rows, counts)]
+
     def __init__(self, n_rows=4, prefill_batch=4, n_prefill=1, prefill_delay=0.0, step_delay=0.001):
         self.prefill_delay, self.step_delay = prefill_delay, step_delay
         self.decoder = StubPool.Decoder(self, n_rows)

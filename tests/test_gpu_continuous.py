@@ -108,7 +108,18 @@ def test_one_prefill_feeds_two_decoders_and_running_rows_cannot_be_fetched():
     sd = dec2.splice_rows(pre, [2, 3], [1, 2])
     for r, ids in drain(dec, {3: sa, 4: sa, 10: sc, 11: sc}).items():
         got[{3: 0, 4: 1, 10: 4, 11: 5}[r]] = ids
-    for r, ids in drain(dec2, {0: sb, 20: sb, 1: sd, 2: sd}).items():
+    # the second decoder's four rows leave through ONE call (sonic_fetch_rows) once all of them are finished
+    want_rows = {0: sb, 20: sb, 1: sd, 2: sd}
+    for _ in range(2000):
+        fin, nn, seq, _ = dec2.service_step(1, 21)
+        if all(seq > va and fin[r] for r, va in want_rows.items()):
+            break
+    else:
+        raise AssertionError("rows did not finish")
+    order = [20, 0, 2, 1]
+    with pytest.raises(RuntimeError):
+        dec2.fetch_rows([0, 0], [1, 1])                                                # a row named twice
+    for r, ids in zip(order, dec2.fetch_rows(order, [int(nn[r]) for r in order])):
         got[{0: 2, 20: 3, 1: 6, 2: 7}[r]] = ids
     for i in range(8):
         assert np.array_equal(got[i], solo[i]), i
