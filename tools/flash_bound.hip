@@ -534,6 +534,174 @@ __global__ __launch_bounds__(256, 2) void flash_ring_kernel(FlashArgs a) {
 }
 
 
+// Staggered form.  A block is 8 waves = 256 queries: waves 0-3 and 4-7 are SIMD partners and run the same program HALF A KEY TILE apart, with
+// one barrier per half tile: while one partner is in its MFMA-heavy half (S = K.Q^T, then the row maxima) the other is in its VALU-heavy half
+// (exp2 / sums / conversion, then O += V.P).  Two waves that alternate phases on their own drift into lockstep - both wait for the matrix pipe,
+// then both for the VALU (tools/mfma_valu_overlap.hip: a MFMA wave and a VALU wave on one SIMD overlap completely, two mixed waves hardly).
+// K / V tiles: LDS-DMA ring of NST stages (prefetch distance NST - 2: a tile stays until the late partner is done with it).  Same arithmetic.
+template <int NST, int MINB>
+__global__ __launch_bounds__(512, MINB) void flash_stag_kernel(FlashArgs a) {
+    typedef bf16_t T;
+    constexpr int HD = 64, QB = 2;
+    typedef typename ET<T>::v8 V8;
+    typedef typename ET<T>::v4 V4;
+    constexpr int HS = HD / 32, HB = HD / 16, KROW = HD * 2, KT_BYTES = 64 * KROW, VT_BYTES = HD * 128, BUF = KT_BYTES + VT_BYTES, PF = NST - 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int lag = wid >> 2;
+    const int b = blockIdx.z, h = blockIdx.y, q_len = a.T, kv_len = a.T, q0 = blockIdx.x * 256;
+    if (q0 >= q_len) return;
+    const T* Q = (const T*)a.Q + (long)b * a.q_seq_stride + (long)h * HD;
+    const T* K = (const T*)a.K + (long)b * a.k_seq_stride + (long)h * a.k_head_stride;
+    const T* Vt = (const T*)a.Vt + (long)b * a.vt_seq_stride + (long)h * a.vt_head_stride;
+    const int n_tiles = (kv_len + 63) / 64;
+    // wave w fetches K rows 8w .. 8w+7 and V^T rows 8w .. 8w+7 of every tile (one 1 KiB piece each), swizzled on the global side
+    const int r8 = wid * 8 + (lane >> 3), pc = lane & 7;
+    const T* ksrc = K + (long)r8 * a.k_ld + ((pc ^ kswz<HD>(r8)) << 3);
+    const T* vsrc = Vt + (long)r8 * a.vt_ld + ((pc ^ (r8 & 7)) << 3);
+    auto load_tile = [&](int kt) {
+        const int key0 = (kt < n_tiles ? kt : n_tiles - 1) * 64;
+        char* sK = smem + (kt % NST) * BUF; char* sV = sK + KT_BYTES;
+        glds16(ksrc + (long)key0 * a.k_ld, sK + wid * 1024);
+        glds16(vsrc + key0, sV + wid * 1024);
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_tile(p);
+    V8 qf[QB][HS];
+    int qrow[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        qrow[qb] = q0 + wid * (QB * 16) + qb * 16 + fr;
+        const int qr = qrow[qb] < q_len ? qrow[qb] : q_len - 1;
+#pragma unroll
+        for (int hs = 0; hs < HS; ++hs) qf[qb][hs] = *(const V8*)(Q + (long)qr * a.q_ld + hs * 32 + fg * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int hs = 0; hs < HS; ++hs) asm volatile("" : "+v"(qf[qb][hs]));
+    f32x4 oacc[QB][HB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) oacc[qb][hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun[QB], lrun[QB], moff[QB], alph[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { mrun[qb] = -1e30f; lrun[qb] = 0.f; moff[qb] = 0.f; alph[qb] = 1.f; }
+    const float cexp = a.scale * 1.44269504088896341f;
+    f32x4 st[2][2][QB];
+    const int n_half = 2 * n_tiles + 1;
+    for (int hstep = 0; hstep < n_half; ++hstep) {
+        if (!(hstep & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * 2) : "memory");      // this wave's pieces of tile hstep / 2 have landed
+        __builtin_amdgcn_s_barrier();
+        if (!(hstep & 1)) load_tile((hstep >> 1) + PF);
+        const int hh = hstep - lag;
+        if (hh < 0 || hh >= 2 * n_tiles) continue;
+        const int kt = hh >> 1, key0 = kt * 64;
+        const char* sK = smem + (kt % NST) * BUF; const char* sV = sK + KT_BYTES;
+        if (!(hh & 1)) {
+            // ---- first half: S^T = K . Q^T, masking, running maxima
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const int krow = ks * 32 + 8 * (fr >> 2) + 4 * sb + (fr & 3);
+                    f32x4 sq[QB];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) sq[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int hs = 0; hs < HS; ++hs) {
+                        const int c = hs * 4 + fg;
+                        const V8 kf = *(const V8*)(sK + krow * KROW + ((c ^ kswz<HD>(krow)) << 4));
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) sq[qb] = ET<T>::mfma(kf, qf[qb][hs], sq[qb]);
+                    }
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) st[ks][sb][qb] = sq[qb];
+                }
+            const bool edge = key0 + 64 > kv_len;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (edge) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int key = key0 + ks * 32 + 8 * fg + 4 * sb + j;
+                                st[ks][sb][qb][j] = key < kv_len ? st[ks][sb][qb][j] : -1e30f;
+                            }
+                }
+                float mx = -1e30f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, st[ks][sb][qb][j]);
+                mx = rows_max(mx);
+                const float mnew = fmaxf(mrun[qb], mx);
+                alph[qb] = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * cexp);
+                mrun[qb] = mnew;
+                moff[qb] = -mnew * cexp;
+            }
+        } else {
+            // ---- second half: P = exp2(S c - m c), row sums, bf16 fragments; O^T (rescaled when a maximum moved) += V^T . P^T
+            V8 pf[QB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float psum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[ks][sb][qb][j], cexp, moff[qb]));
+                            psum += p;
+                            pf[qb][ks][sb * 4 + j] = (T)p;
+                        }
+                lrun[qb] = lrun[qb] * alph[qb] + psum;
+            }
+            bool moved = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) moved = moved || alph[qb] != 1.0f;
+            if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) oacc[qb][hb] *= alph[qb];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) {
+                    const int vr = hb * 16 + fr, c = ks * 4 + fg;
+                    const V8 vf = *(const V8*)(sV + vr * 128 + ((c ^ (vr & 7)) << 4));
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][hb] = ET<T>::mfma(vf, pf[qb][ks], oacc[qb][hb]);
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T* O = (T*)a.O + (long)b * (a.q_seq_stride / a.q_ld) * a.o_ld + (long)h * HD;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l = rows_sum(lrun[qb]);
+        if (qrow[qb] < q_len) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (T)(oacc[qb][hb][j] / l);
+                *(V4*)(O + (long)qrow[qb] * a.o_ld + hb * 16 + fg * 4) = o;
+            }
+        }
+    }
+}
+
 int main() {
     const int B = 32, H = 20, T = 1500, HD = 64, Tp = 1536, C = H * HD;
     const size_t nq = (size_t)B * T * C, nv = (size_t)B * C * Tp;
@@ -596,6 +764,21 @@ int main() {
     hipMemset(o2, 0, nq * 2);
     timeit("LDS-DMA ring, 4 stages, 64 queries per wave", [&] { hipLaunchKernelGGL((flash_ring_kernel<4, 4>), grid64, dim3(256), 4 * 16384, 0, f2); });
     diff("ring (4 stages, 64 queries per wave)");
+    {
+        const dim3 grid256((T + 255) / 256, H, B);
+        hipFuncSetAttribute((const void*)flash_stag_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+        hipFuncSetAttribute((const void*)flash_stag_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+        hipFuncSetAttribute((const void*)flash_stag_kernel<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
+        hipMemset(o2, 0, nq * 2);
+        timeit("staggered SIMD partners, 8 waves, ring of 4, one block per CU", [&] { hipLaunchKernelGGL((flash_stag_kernel<4, 1>), grid256, dim3(512), 4 * 16384, 0, f2); });
+        diff("staggered (ring 4, 1 block)");
+        hipMemset(o2, 0, nq * 2);
+        timeit("staggered SIMD partners, 8 waves, ring of 4, two blocks per CU", [&] { hipLaunchKernelGGL((flash_stag_kernel<4, 2>), grid256, dim3(512), 4 * 16384, 0, f2); });
+        diff("staggered (ring 4, 2 blocks)");
+        hipMemset(o2, 0, nq * 2);
+        timeit("staggered SIMD partners, 8 waves, ring of 5, one block per CU", [&] { hipLaunchKernelGGL((flash_stag_kernel<5, 1>), grid256, dim3(512), 5 * 16384, 0, f2); });
+        diff("staggered (ring 5, 1 block)");
+    }
     {   // where a wave's time goes (ring, 3 stages, 32 queries per wave), under the real concurrency of the full grid
         const size_t nb = (size_t)grid.x * grid.y * grid.z;
         long long* tr; hipMalloc(&tr, nb * 4 * 5 * 8); hipMemset(tr, 0, nb * 4 * 5 * 8);

@@ -15,8 +15,8 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(i * 0.5f); }
     f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, e = 0.f;
-    const bool do_m = MODE == 0 || MODE == 3 || (MODE == 2 && !(wid & 1));
-    const bool do_v = MODE == 1 || MODE == 3 || (MODE == 2 && (wid & 1));
+    const bool do_m = MODE == 0 || MODE == 3 || ((MODE == 2 || MODE == 4) && !(wid & 1));
+    const bool do_v = MODE == 1 || MODE == 3 || ((MODE == 2 || MODE == 5) && (wid & 1));
     if (MODE == 3) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(512) void k32(float* out, int iters) {
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(i * 0.5f); }
     f32x16 c0 = {0}, c1 = c0, c2 = c0, c3 = c0;
     float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, e = 0.f;
-    const bool do_m = MODE == 0 || MODE == 3 || (MODE == 2 && !(wid & 1));
-    const bool do_v = MODE == 1 || MODE == 3 || (MODE == 2 && (wid & 1));
+    const bool do_m = MODE == 0 || MODE == 3 || ((MODE == 2 || MODE == 4) && !(wid & 1));
+    const bool do_v = MODE == 1 || MODE == 3 || ((MODE == 2 || MODE == 5) && (wid & 1));
     if (MODE == 3) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -116,10 +116,14 @@ int main() {
     run("all 8 waves: VALU only (8 fma/mul + 4 exp / 4 MFMA slots)", k<1>, 0, 16.0 * iters);
     run("4 waves MFMA + 4 waves VALU (one of each per SIMD)", k<2>, 16.0 * iters, 16.0 * iters);
     run("all 8 waves: both, interleaved in the wave", k<3>, 16.0 * iters, 16.0 * iters);
+    run("4 waves MFMA, the other 4 idle", k<4>, 16.0 * iters, 0);
+    run("4 waves VALU, the other 4 idle", k<5>, 0, 16.0 * iters);
     printf("the same with v_mfma_f32_32x32x16_bf16 (twice the FLOPs per instruction):\n");
     run("all 8 waves: MFMA only", k32<0>, 16.0 * iters, 0);
     run("all 8 waves: VALU only", k32<1>, 0, 16.0 * iters);
     run("4 waves MFMA + 4 waves VALU (one of each per SIMD)", k32<2>, 16.0 * iters, 16.0 * iters);
     run("all 8 waves: both, interleaved in the wave", k32<3>, 16.0 * iters, 16.0 * iters);
+    run("4 waves MFMA, the other 4 idle", k32<4>, 16.0 * iters, 0);
+    run("4 waves VALU, the other 4 idle", k32<5>, 0, 16.0 * iters);
     return 0;
 }
