@@ -200,3 +200,26 @@ def test_asrmodel_slots_behind_the_dispatcher():
     for st in streams:
         st.close()
     one.close(); two.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["bf16", "int8"])
+def test_gemm_tile_choice_never_shows_in_a_result(mode):
+    """Grids of 256x256 tiles that under-fill the chip go to the 128x128 kernel (csrc/gemm.hip small_grid_prefers128, option gemm_small_eff;
+    the continuous dispatcher flips the option per prefill, dispatch._ContinuousReplica._prefill).  Full-width layers, 1 / 2 / 5 requests of
+    mixed lengths: the step logits are the same BITS with the rule off (0), at its default (75) and with every eligible GEMM on small tiles
+    (1000) - both kernels accumulate every output element over k in the same order and share their epilogues."""
+    e = make(FULLW, max_batch=8, mode=mode)
+    segs = [synth.synth_pcm(900 + i, 16000 * s) for i, s in enumerate((5, 20, 2, 29, 9))]
+    prompts = [prompt_for(FULLW, len(s)) for s in segs]
+    got = {}
+    for eff in (0, 75, 1000):
+        e.set_option("gemm_small_eff", eff)
+        for B in (1, 2, 5):
+            ids, lg = e.transcribe_batch(segs[:B], prompts[:B], [4] * B, want_logits=True)
+            key = (B,)
+            if key in got:
+                assert np.array_equal(got[key][1].view(np.uint32), lg.view(np.uint32)), (eff, B, float(np.abs(got[key][1] - lg).max()))
+                assert all(np.array_equal(a, b) for a, b in zip(got[key][0], ids))
+            else:
+                got[key] = (ids, lg)
+    e.close()
