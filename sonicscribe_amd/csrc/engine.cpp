@@ -510,7 +510,8 @@ static int alloc_state(sonic_engine* e) {
     }
     if (hipHostMalloc((void**)&e->n_active_h, (CHK_RING + 1) * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
     if (hipHostMalloc((void**)&e->svc_h, (size_t)CHK_RING * SVC_WORDS * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&e->st_io, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return SONIC_ERR_HIP; }
+    // (the row-fetch stream st_io is created by the first sonic_service_begin: hardware queues are dealt to streams in creation order, and the main
+    //  streams of an engine and its slots should take the first ones - see sonic_more_hw_queues)
     if (hipEventCreateWithFlags(&e->xfer_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->splice_ev, hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->plan_cap = 3 * tc + 8 * 64;
     if (hipHostMalloc((void**)&e->plan_h, e->plan_cap * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
@@ -1750,6 +1751,7 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     ENTER(e);
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
     if (e->svc_on) return SONIC_OK;
+    if (!e->st_io) HIPC(e, hipStreamCreateWithFlags(&e->st_io, hipStreamNonBlocking));
     HIPC(e, stream_sync(e));
     hipLaunchKernelGGL(service_reset_kernel, dim3(1), dim3(64), 0, e->st, e->kv_len, e->tok_pos, e->n_new, e->finished, e->max_new_d, e->n_active);
     if (e->force_d) return fail(e, SONIC_ERR_INVALID, "teacher forcing is set: clear it before continuous decoding");
