@@ -7,7 +7,7 @@ import numpy as np
 from sonicscribe_amd import spec, synth
 from sonicscribe_amd.engine import Engine
 
-B = 32
+B = int(os.environ.get("TIMELINE_B", "32"))      # 33 .. 64: the fused kernels' second pass shows as the last point of gate/up
 dims = replace(spec.FULL, eos_ids=())
 n_samples = 20 * 16000
 n_audio = spec.audio_token_count(spec.valid_frames(n_samples))
@@ -25,7 +25,7 @@ names = ["qkv (skinny_xs)", "attention", "o_proj (skinny_o)", "gate/up (skinny_g
 points = {0: ["entry", "loads issued", "X in LDS", "last W multiplied", "synced", "slabs written"],
           1: ["entry", "prologue done (slab sum, RoPE, append)", "KV loop done", "merged in LDS", "O written"],
           2: ["entry", "loads issued", "all landed", "synced", "MFMA done", "end"],
-          3: ["entry", "first loads issued", "norm pass done, all W issued", "X + tile 0 landed (wave 0)", "X fragments read", "MFMA done (wave 0)", "end"],
+          3: ["entry", "first loads issued", "norm pass done, all W issued", "X + tile 0 landed (wave 0)", "X fragments read", "MFMA done (wave 0)", "end (rows 0-31 written)"] + (["second pass done (rows 32-63)"] if B > 32 else []),
           4: ["entry", "loads issued", "X in LDS", "last W multiplied", "synced", "slabs written"]}
 t_ref = None
 prev_end = None
