@@ -362,8 +362,8 @@ def streaming_measure(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed batches per leg (the bulk pipeline is timed from empty to drained: fewer than ~10 batches mostly measure its fill and drain)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--max-new", type=int, default=MAX_NEW)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
