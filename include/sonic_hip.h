@@ -39,7 +39,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table (tests/test_host_logic.py checks
  * `nm -D` against this header).  SONIC_ABI_VERSION moves whenever a signature or a struct layout below changes. */
 #define SONIC_API __attribute__((visibility("default")))
-#define SONIC_ABI_VERSION 4
+#define SONIC_ABI_VERSION 5
 SONIC_API int sonic_abi_version(void);
 
 typedef struct sonic_engine sonic_engine;
@@ -100,6 +100,12 @@ SONIC_API void sonic_destroy(sonic_engine* e);
 SONIC_API const char* sonic_last_error(sonic_engine* e); /* e may be NULL: error of the last failed sonic_create on this thread */
 /* name (NUL-terminated, truncated to name_cap), total / currently free device memory, hipRuntimeGetVersion(); any output may be NULL */
 SONIC_API int sonic_device_info(int device_id, char* name, int name_cap, int64_t* total_bytes, int64_t* free_bytes, int32_t* hip_runtime_version);
+/* How many hardware queues the HIP runtime of THIS process gives its streams on the device (measured once per device: eight probe streams with a
+ * 300 us spin kernel each; streams that share a queue run in order), what GPU_MAX_HW_QUEUES says now (0 = unset) and how many an engine with slots
+ * wants (8).  The runtime reads the variable at its first call only: in the reference's process torch initialises it (backend/asr.py:53
+ * `torch.cuda.is_available()`), so the host sets GPU_MAX_HW_QUEUES=8 in its environment - the library never writes the
+ * environment, and the first sonic_create warns on stderr when the measured count is below the wanted one (SONIC_QUIET=1 silences it). */
+SONIC_API int sonic_runtime_info(int device_id, int32_t* hw_queues, int32_t* hw_queues_env, int32_t* hw_queues_wanted);
 /* allocated: bytes of this handle's live device allocations (a slot: its own buffers; the weights are its owner's); reserved = allocated
  * (no caching allocator under the engine: sonic_destroy returns everything to the driver) */
 SONIC_API int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64_t* reserved_bytes);

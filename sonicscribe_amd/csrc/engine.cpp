@@ -110,6 +110,9 @@ struct sonic_engine {
     bool run_starved = false;                                      // the current batch saw the queue run dry (lookahead grew)
     int lookahead = 1;                                             // chunks queued beyond the one whose check the host waits for; adapts (1..CHK_MAX_AHEAD)
     int* plan_h = nullptr; size_t plan_cap = 0;                    // pinned staging of a batch's prompt plan (no stream synchronise between encoder and prefill)
+    // Two staging buffers used alternately, each with an event recorded behind the last copy that reads it: sonic_prefill_enqueue returns with those
+    // copies still queued behind the encoder, and the next run on this handle must not overwrite a buffer the stream has not read yet
+    int* plan_buf[2] = {nullptr, nullptr}; hipEvent_t plan_ev[2] = {nullptr, nullptr}; bool plan_busy[2] = {false, false}; int plan_idx = 0;
 
     // Slots (sonic_slot_create): further in-flight batches on ONE weight copy.  A slot is an engine of its own in every respect - stream, activation
     // buffers, KV cache, PCM staging, decode graphs, lock, options - except that its weight / constant pointers are the owner's.
@@ -380,9 +383,66 @@ static int build_constants(sonic_engine* e) {
 // The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round-robin in creation order; streams that
 // share a queue execute in order.  An engine with two slots owns six streams (one main + one fetch stream per handle), plus one per device
 // ring: with four queues the prefill slot's stream landed on the queue of a decoding handle and the bulk pipeline lost 7 % (141 vs 151
-// segments/s, profiles/round4_hw_queues.txt).  Ask for more queues before the runtime starts - it reads the variable at its first call; a
-// host that has already used HIP keeps what it had, and a value set by the user is left alone.
-__attribute__((constructor)) static void sonic_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// segments/s, profiles/round4_hw_queues.txt).  The runtime reads the variable once, at its first call, so it is the HOST PROCESS that has to set GPU_MAX_HW_QUEUES=8
+// before anything touches HIP (`import sonicscribe_amd` and bench.py do it with setdefault).  The library itself no longer writes the
+// environment (round 4's constructor did: setenv from a library constructor races with other threads' getenv and silently did nothing when torch
+// had started the runtime first).  Instead the first sonic_create on a device MEASURES how many hardware queues the process really has and says so
+// once on stderr when there are fewer than the pipeline wants; sonic_runtime_info reports the same numbers to the host.
+#define SONIC_HW_QUEUES_WANTED 8
+__global__ void hwq_probe_kernel(unsigned long long ticks) {      // spins for `ticks` of the 100 MHz constant clock (s_memrealtime)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static std::mutex g_hwq_mu;
+static int g_hwq_measured[64];                                      // per device: 0 = not probed yet
+// Eight streams each get one single-wave kernel that spins 300 us; streams that share a hardware queue run in order, so the wall time of the eight
+// is ceil(8 / queues) x 300 us.  Run once per device and process (about 1 ms), before the engine creates its own streams; the probe streams are
+// created and destroyed in one go (a multiple of every plausible queue count, so the runtime's round-robin hand-out is where it was).
+static int probe_hw_queues(int device) {
+    std::lock_guard<std::mutex> lk(g_hwq_mu);
+    if (device < 0 || device >= 64) return 0;
+    if (g_hwq_measured[device]) return g_hwq_measured[device];
+    int cur = 0; (void)hipGetDevice(&cur);
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    constexpr int NS = 8; constexpr unsigned long long TICKS = 30000;   // 300 us
+    hipStream_t st[NS] = {};
+    int made = 0, q = 0;
+    for (; made < NS; ++made) if (hipStreamCreateWithFlags(&st[made], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (made == NS) {
+        double best = 1e30;
+        for (int rep = 0; rep < 3; ++rep) {                           // rep 0 also loads the code object
+            for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(st[i]);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < NS; ++i) hipLaunchKernelGGL(hwq_probe_kernel, dim3(1), dim3(64), 0, st[i], rep == 0 ? 100ull : TICKS);
+            for (int i = 0; i < NS; ++i) (void)hipStreamSynchronize(st[i]);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (rep > 0 && us < best) best = us;
+        }
+        const double rounds = (best - 40.0) / (TICKS / 100.0);        // ~40 us of launch + synchronise overhead
+        int r = (int)(rounds + 0.5); if (r < 1) r = 1; if (r > NS) r = NS;
+        q = (NS + r - 1) / r;                                          // 1 round: >= 8 queues, 2 rounds: 4, 4 rounds: 2, 8 rounds: 1
+        if (hipGetLastError() != hipSuccess) q = 0;
+    }
+    for (int i = 0; i < made; ++i) (void)hipStreamDestroy(st[i]);
+    (void)hipSetDevice(cur);
+    g_hwq_measured[device] = q;
+    if (q > 0 && q < SONIC_HW_QUEUES_WANTED && !getenv("SONIC_QUIET")) {
+        const char* env = getenv("GPU_MAX_HW_QUEUES");
+        fprintf(stderr, "[sonic_hip] device %d: the HIP runtime of this process has %d hardware queue(s) for its streams (GPU_MAX_HW_QUEUES=%s%s); an engine with "
+                        "slots wants %d - streams that share a queue run in order (the bulk pipeline measured 141 instead of 152 segments/s on 4 queues).  Set "
+                        "GPU_MAX_HW_QUEUES=8 in the environment BEFORE the process first touches HIP / torch.cuda.\n", device, q, env ? env : "unset",
+                env && atoi(env) >= SONIC_HW_QUEUES_WANTED ? ": set after the runtime had started" : "", SONIC_HW_QUEUES_WANTED);
+    }
+    return q;
+}
+extern "C" int sonic_runtime_info(int device_id, int32_t* hw_queues, int32_t* hw_queues_env, int32_t* hw_queues_wanted) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { (void)hipGetLastError(); return fail(nullptr, SONIC_ERR_INVALID, "device %d not available", device_id); }
+    if (hw_queues) *hw_queues = probe_hw_queues(device_id);
+    if (hw_queues_env) { const char* v = getenv("GPU_MAX_HW_QUEUES"); *hw_queues_env = v ? atoi(v) : 0; }
+    if (hw_queues_wanted) *hw_queues_wanted = SONIC_HW_QUEUES_WANTED;
+    return SONIC_OK;
+}
 
 extern "C" int sonic_abi_version(void) { return SONIC_ABI_VERSION; }
 extern "C" int sonic_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
@@ -514,7 +574,11 @@ static int alloc_state(sonic_engine* e) {
     //  streams of an engine and its slots should take the first ones - see sonic_more_hw_queues)
     if (hipEventCreateWithFlags(&e->xfer_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->splice_ev, hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->plan_cap = 3 * tc + 8 * 64;
-    if (hipHostMalloc((void**)&e->plan_h, e->plan_cap * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+    for (int i = 0; i < 2; ++i) {
+        if (hipHostMalloc((void**)&e->plan_buf[i], e->plan_cap * 4, hipHostMallocDefault) != hipSuccess) { e->err = "hipHostMalloc failed"; return SONIC_ERR_HIP; }
+        if (hipEventCreateWithFlags(&e->plan_ev[i], (getenv("SONIC_SPIN_SYNC") ? 0 : hipEventBlockingSync) | hipEventDisableTiming) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
+    }
+    e->plan_h = e->plan_buf[0];
     for (auto& v : e->ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
     e->gemm_ev.resize(8 * (size_t)(d.enc_layers > 0 ? d.enc_layers : 1));   // per layer: [start, end] of the QKV, o, fc1, fc2 GEMM launches
     for (auto& v : e->gemm_ev) if (hipEventCreate(&v) != hipSuccess) { e->err = "hipEventCreate failed"; return SONIC_ERR_HIP; }
@@ -535,6 +599,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SONIC_ERR_HIP, "no HIP device available");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    (void)probe_hw_queues(device_id);                     // once per device and process; warns when streams will alias (see sonic_runtime_info)
     sonic_engine* e = new sonic_engine();
     e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
     e->i8 = mode == SONIC_MODE_INT8; e->dt = (e->i8 || mode == SONIC_MODE_F16) ? DT_F16 : DT_BF16;
@@ -616,7 +681,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->taps) (void)hipFree(e->taps);
     if (e->feats_f32) (void)hipFree(e->feats_f32);
     if (e->n_active_h) (void)hipHostFree(e->n_active_h);
-    if (e->plan_h) (void)hipHostFree(e->plan_h);
+    for (int i = 0; i < 2; ++i) { if (e->plan_buf[i]) (void)hipHostFree(e->plan_buf[i]); if (e->plan_ev[i]) (void)hipEventDestroy(e->plan_ev[i]); }
     if (e->svc_h) (void)hipHostFree(e->svc_h);
     if (e->st_io) { (void)hipStreamSynchronize(e->st_io); (void)hipStreamDestroy(e->st_io); }
     if (e->xfer_ev) (void)hipEventDestroy(e->xfer_ev);
@@ -1241,7 +1306,7 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     const QGroup grp{e->tok_seq, 1, R};        // one reference call = the prompt rows of one request
     // The plan goes through pinned memory, so the copies are truly asynchronous and nothing here waits for the encoder that is still running
     // on this stream (a pageable source forced a stream synchronise between encoder and prefill: a host-dependent bubble in every batch).
-    // plan_h is free again: the previous run of this engine ended with a stream synchronise.
+    // plan_h = the staging buffer run_to_first_token picked for this run (free: the run that used it last has had its copies waited for).
     {
         int* h = e->plan_h; size_t o = 0;
         auto put = [&](int* dst, const int* srcv, size_t n) -> hipError_t {
@@ -1254,6 +1319,8 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
         HIPC(e, put(e->q_off, hp.q_off.data(), (size_t)R)); HIPC(e, put(e->q_len, hp.q_len.data(), (size_t)R)); HIPC(e, put(e->kv_len, hp.q_len.data(), (size_t)R));
         HIPC(e, put(e->last_row, hp.last_row.data(), (size_t)R)); HIPC(e, put(e->max_new_d, hp.max_new.data(), (size_t)R));
         HIPC(e, put(e->n_active, &R, 1));
+        HIPC(e, hipEventRecord(e->plan_ev[e->plan_idx], e->st));       // every copy out of this buffer (win_req included) is older than this event
+        e->plan_busy[e->plan_idx] = true;
     }
     launch_fill_i32(e->n_new, 0, 64, e->st);
     if (e->amax_att) { launch_fill_i32((int*)e->amax_att, 0, 64 * 4, e->st); launch_fill_i32((int*)e->amax_act, 0, 64 * 4, e->st); launch_fill_i32(e->big_att, 0, 64 * 4, e->st); }   // (partials nobody writes stay 0)
@@ -1306,6 +1373,11 @@ static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, co
     }
     HostPlan hp;
     TRY(plan_requests(e, req_win, R, prompt_ids, prompt_off, max_new, hp));
+    {   // staging buffer of this run: the one used two runs ago; its copies are almost always long done (a blocking wait otherwise)
+        const int i = e->plan_idx ^ 1;
+        if (e->plan_busy[i]) { HIPC(e, hipEventSynchronize(e->plan_ev[i])); e->plan_busy[i] = false; }
+        e->plan_idx = i; e->plan_h = e->plan_buf[i];
+    }
     if (e->force_d && (e->force_R != R || e->force_ld < hp.max_steps))
         return fail(e, SONIC_ERR_INVALID, "forced ids are [%d][%d] but the run has %d requests / %d steps", e->force_R, e->force_ld, R, hp.max_steps);
     e->R = R; e->max_steps = hp.max_steps; e->last_qlen = hp.q_len; e->last_maxnew = hp.max_new;

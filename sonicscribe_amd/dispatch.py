@@ -243,7 +243,7 @@ class _ContinuousReplica:
         with self.cv:
             while not self.stop and (not self.q or max(self.free) <= 0):
                 self.cv.wait()
-            if self.stop and not self.q:
+            if self.stop:                                # closing: nothing new is started; close() fails what is still queued
                 return [], 0
             self.q = [r for r in self.q if not r.future.cancelled()]
             k = max(range(len(self.free)), key=self.free.__getitem__)        # the emptiest decoder takes the whole prefill batch
@@ -282,7 +282,15 @@ class _ContinuousReplica:
             self.handovers[k].append(h)
             self.cv.notify_all()
         while not h.taken.wait(0.5):                     # the slot's rows are the splice's source until the decode thread has queued it
-            if self.failed is not None:
+            if self.failed is not None:                  # the decode side died after this batch was prefilled: its handler may have drained the
+                with self.cv:                            # hand-over list before this one was appended - fail the batch here, exactly once
+                    mine = h in self.handovers[k]
+                    if mine:
+                        self.handovers[k].remove(h)
+                if mine:
+                    for r in batch:
+                        self._finish(r, error=self.failed)
+                    self._release(k, len(batch))
                 return
 
     def _release(self, k: int, n: int):
@@ -323,10 +331,15 @@ class _ContinuousReplica:
         try:
             while True:
                 with self.cv:
-                    while not self.handovers[k] and occupied == 0 and not self.stop:
+                    # idle = no row occupied and none reserved by a prefill in flight (free[k] counts both): a closing replica keeps its
+                    # decode loop until every prefill that has taken rows has handed them over and they are fetched (close() used to
+                    # leave a prefill thread spinning in _hand() with nobody left to take its rows)
+                    while not self.handovers[k] and occupied == 0 and self.failed is None and not (self.stop and self.free[k] == self.n_rows):
                         self.cv.wait()
+                    if self.failed is not None:
+                        raise self.failed                # a sibling decoder failed: this loop's rows are failed by its own handler below
                     hs, self.handovers[k] = self.handovers[k], []
-                    if self.stop and not hs and occupied == 0:
+                    if self.stop and not hs and occupied == 0 and self.free[k] == self.n_rows:
                         return
                 for h in hs:
                     free = [i for i, r in enumerate(rows) if r is None][:len(h.reqs)]
@@ -349,13 +362,15 @@ class _ContinuousReplica:
                         self._finish(r, ids)
                     self._release(k, len(done))
         except BaseException as ex:                      # the engine failed: nothing queued or in flight can complete
-            with self.cv:
-                self.failed = ex
+            with self.cv:                                # every decode loop comes through here (siblings re-raise `failed`): each fails ITS rows
+                if self.failed is None:
+                    self.failed = ex
+                ex = self.failed
                 pending, self.q = self.q, []
-                hs = [h for lst in self.handovers for h in lst]
-                self.handovers = [[] for _ in self.decoders]
+                hs, self.handovers[k] = self.handovers[k], []
+                mine, self.rows[k] = [x for x in rows if x is not None], [None] * self.n_rows
                 self.cv.notify_all()
-            for r in [x for rr in self.rows for x in rr if x is not None] + [x for h in hs for x in h.reqs] + pending:
+            for r in mine + [x for h in hs for x in h.reqs] + pending:
                 try:
                     self._finish(r, error=ex)
                 except BaseException:

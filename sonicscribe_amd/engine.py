@@ -31,8 +31,9 @@ EXPORTS = [
     "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info",
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
     "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_fetch_rows", "sonic_prefill_enqueue",
+    "sonic_runtime_info",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SonicDims(C.Structure):
@@ -128,6 +129,7 @@ def load_library():
     lib.sonic_decode_step.argtypes = [vp, C.c_int, ip, ip]
     lib.sonic_prefill_enqueue.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.sonic_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, i64p, i64p, ip]
+    lib.sonic_runtime_info.argtypes = [C.c_int, ip, ip, ip]
     lib.sonic_memory_info.argtypes = [vp, i64p, i64p]
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -632,6 +634,16 @@ def device_info(device_id: int = 0) -> dict:
     if lib.sonic_device_info(int(device_id), name, 256, C.byref(tot), C.byref(fr), C.byref(ver)) != 0:
         raise RuntimeError((lib.sonic_last_error(None) or b"").decode())
     return {"name": name.value.decode(), "total_bytes": int(tot.value), "free_bytes": int(fr.value), "hip_runtime_version": int(ver.value)}
+
+
+def runtime_info(device_id: int = 0) -> dict:
+    """Hardware queues the HIP runtime of this process really has on the device (measured), GPU_MAX_HW_QUEUES as it reads now, and what an
+    engine with slots wants (sonic_runtime_info)."""
+    lib = load_library()
+    q, env, want = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    if lib.sonic_runtime_info(int(device_id), C.byref(q), C.byref(env), C.byref(want)) != 0:
+        raise RuntimeError((lib.sonic_last_error(None) or b"").decode())
+    return {"hw_queues": int(q.value), "hw_queues_env": int(env.value), "hw_queues_wanted": int(want.value)}
 
 
 def device_count() -> int:

@@ -40,7 +40,8 @@ class ContinuousPipeline:
 
     def run(self, n_batches: int, prefill: Callable[[Any], None], check: Optional[Callable[[int, np.ndarray], bool]] = None) -> dict:
         """n_batches batches of `block` requests through the pipeline.  prefill(slot): run the slot's staged batch up to its first tokens
-        (Engine.prefill).  check(i, ids) for row i of every finished batch (returns False for a wrong row).  Returns wall time and counts."""
+        (Engine.prefill); it may return a tag that names the batch.  check(i, ids) - or check(i, ids, tag) for a tagged batch - for row i of
+        every finished batch (returns False for a wrong row).  Returns wall time and counts."""
         ready: "queue.Queue" = queue.Queue()
         lock = threading.Lock()
         state = {"todo": n_batches, "done": 0, "bad": 0, "steps": 0}
@@ -53,9 +54,9 @@ class ContinuousPipeline:
                         if state["todo"] <= 0:
                             return
                         state["todo"] -= 1
-                    prefill(p)
+                    tag = prefill(p)
                     ev = threading.Event()
-                    ready.put((p, ev))
+                    ready.put((p, ev, tag))
                     while not ev.wait(0.5):                      # a decoder has queued the splice: the slot may overwrite its rows
                         if errors:
                             return
@@ -68,6 +69,7 @@ class ContinuousPipeline:
             k = self.decoders.index(d)
             free = list(range(len(self.blocks)))
             occupied = {}                                        # block -> chunk sequence number after which its flags are valid
+            tags = {}                                            # block -> the tag its prefill returned
             try:
                 while not errors:
                     with lock:
@@ -82,12 +84,13 @@ class ContinuousPipeline:
                         continue
                     while free:
                         try:
-                            p, ev = ready.get(block=not occupied, timeout=0.02)
+                            p, ev, tag = ready.get(block=not occupied, timeout=0.02)
                         except queue.Empty:
                             break
                         free.sort()
                         b = free.pop(0)                          # lowest free block: the loop steps only as many rows as are occupied
                         occupied[b] = d.splice_rows(p, list(range(self.block)), self.blocks[b])
+                        tags[b] = tag
                         ev.set()
                     if not occupied:
                         continue
@@ -104,7 +107,7 @@ class ContinuousPipeline:
                             bad = 0
                             got = d.fetch_rows(self.blocks[b], [int(nn[r]) for r in self.blocks[b]])
                             for i, ids in enumerate(got):
-                                if check is not None and not check(i, ids):
+                                if check is not None and not (check(i, ids) if tags[b] is None else check(i, ids, tags[b])):
                                     bad += 1
                             del occupied[b]; free.append(b)
                             with lock:

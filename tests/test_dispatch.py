@@ -374,6 +374,51 @@ def test_continuous_replica_errors_cancel_and_close():
     d2.close()
 
 
+def test_continuous_replica_close_while_a_prefill_is_in_flight():
+    """close() 50 ms into a 200 ms prefill used to end the decode loop first; the prefill thread then span in _hand() for ever,
+    close() blocked for its whole join timeout and the futures stayed pending.  Now a request whose rows a prefill has reserved completes,
+    what is still queued fails with 'closed', and every thread is gone when close() returns."""
+    pool = StubPool(n_rows=4, prefill_batch=2, prefill_delay=0.2)
+    d = Dispatcher([pool.decoder], slots=[pool.prefills], continuous=True)
+    futs = [d.submit([seg(i)], [1, 2], 6) for i in range(4)]             # two go into the first prefill batch, two stay queued behind it
+    time.sleep(0.05)
+    t0 = time.perf_counter()
+    d.close()
+    assert time.perf_counter() - t0 < 5.0
+    assert all(f.done() for f in futs)
+    done, failed = [], []
+    for i, f in enumerate(futs):
+        try:
+            assert f.result(timeout=0).tolist() == want_tokens(i, 2, 6)
+            done.append(i)
+        except RuntimeError as ex:
+            assert "closed" in str(ex)
+            failed.append(i)
+    assert done == [0, 1] and failed == [2, 3]
+    assert not any(t.is_alive() for t in d.replicas[0].threads)
+    assert not pool.decoder.on and all(r is None for r in pool.decoder.rows)
+
+
+def test_continuous_replica_decoder_failure_while_a_prefill_is_in_flight():
+    """a decode thread that fails while a prefill is still running leaves a hand-over nobody will take: the prefill side
+    fails that batch itself.  With two decoders the sibling loop stops too instead of finishing futures that were already failed."""
+    class Broken(StubPool.Decoder):
+        def service_step(self, n_chunks=1, rows=0):
+            raise RuntimeError("HIP error: device lost")
+    pool = StubPool(n_rows=2, prefill_batch=1, prefill_delay=0.15)
+    pool.decoder = Broken(pool, 2)
+    dec2 = StubPool.Decoder(pool, 2)
+    d = Dispatcher([pool.decoder], slots=[[dec2] + pool.prefills], continuous=True, decoders=2)
+    fs = [d.submit([seg(i)], [1], 20) for i in range(4)]                 # one request per prefill batch: the second is in flight when the first one's decoder fails
+    for f in fs:
+        with pytest.raises(RuntimeError):
+            f.result(timeout=10)
+    t0 = time.perf_counter()
+    d.close()
+    assert time.perf_counter() - t0 < 5.0
+    assert not any(t.is_alive() for t in d.replicas[0].threads)
+
+
 def test_bulk_pipeline_pairs_batches_and_checks_every_row():
     """sonicscribe_amd/pipeline.py (bench.py's headline driver) over stub handles: every batch goes through prefill -> splice -> continuous
     decode -> fetch, rows are checked, blocks are reused, and an empty decoder leaves the next batch to one that runs part-filled."""

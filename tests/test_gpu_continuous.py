@@ -218,3 +218,31 @@ def test_asrmodel_two_decoders_of_64_rows_bulk_shape():
     assert got == [want[i % 50] for i in range(150)]
     assert rep.load() == 0 and all(r is None for rows in rep.rows for r in rows)
     ref.close(); bulk.close()
+
+
+@pytest.mark.parametrize("dims", [replace(spec.TINY, eos_ids=()), FULLW], ids=["tiny", "fullwidth"])
+def test_back_to_back_enqueued_prefills_keep_their_own_plans(dims):
+    """sonic_prefill_enqueue returns with the prompt plan's host-to-device copies still queued behind the encoder; a second enqueue on
+    the same handle used to overwrite the one pinned staging buffer before the first batch's copies had run - batch N prefilled with batch
+    N+1's token sources, positions, lengths and budgets.  Two enqueues on the SAME staged PCM (no stage_pcm in between, which would
+    synchronise) with different prompts and budgets must each give their solo tokens; a third reuses the first staging buffer."""
+    dec = make(dims, 32)
+    pre = dec.slot()
+    segs = [synth.synth_pcm(900 + i, 16000 * (4 + 3 * i)) for i in range(4)]
+    base = [prompt_for(dims, len(s)) for s in segs]
+    variants = [[p + [40 + 7 * v + i, 50 + v] * (v + 1) for i, p in enumerate(base)] for v in range(3)]     # different text tails => other lengths, positions, ids
+    budgets = [[5 + 3 * i + 11 * v for i in range(4)] for v in range(3)]
+    solo = [[dec.transcribe_batch([segs[i]], [variants[v][i]], [budgets[v][i]])[0][0] for i in range(4)] for v in range(3)]
+    dec.service_begin()
+    pre.stage_pcm(segs)
+    rows, who = {}, {}
+    for v in range(3):
+        pre.prefill(variants[v], budgets[v], wait=False)                 # queued only: the host is back before the encoder has run
+        seq = dec.splice_rows(pre, [0, 1, 2, 3], [8 * v + i for i in range(4)])
+        for i in range(4):
+            rows[8 * v + i] = seq; who[8 * v + i] = (v, i)
+    for r, ids in drain(dec, rows).items():
+        v, i = who[r]
+        assert len(ids) == budgets[v][i] and np.array_equal(ids, solo[v][i]), (v, i)
+    dec.service_end()
+    dec.close()
