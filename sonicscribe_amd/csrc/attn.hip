@@ -273,6 +273,9 @@ template <int VAR> static void launch_flash_v(const FlashArgs& a, int hd, bool c
     });
 }
 void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s) {
+    // the encoder's shape (head dim 64, every key visible) has its own kernel since round 5 (attn_enc.hip: 32x32x16 MFMAs, 64 queries per wave,
+    // LDS-DMA tiles, running maximum fixed after the first key tile)
+    if (hd == 64 && !causal && g_opts.flash_enc > 0 && a.Hq == a.Hkv) { launch_flash_enc(a, B, max_q, g_opts.flash_enc - 1, s); return; }
     dim3 grid((max_q + 127) / 128, a.Hq, B);
     switch (g_opts.flash_variant & 3) {
         case 1: launch_flash_v<1>(a, hd, causal, grid, s); break;

@@ -66,6 +66,7 @@ struct LaunchOpts {
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
     int decode_attn_v1 = 0;    // decode attention with P.V on the VALU (round 2), for A/B runs
     int flash_variant = 2;     // prefill / encoder attention: bit 0 two LDS buffers + one barrier per tile (no gain measured), bit 1 lazy accumulator rescale (-0.6 ms per batch; default)
+    int flash_enc = 1;         // encoder attention (head dim 64, no mask): 0 = flash_attn_kernel (rounds 1-4), v > 0 = flash_enc_kernel mode v - 1 (attn_enc.hip; round 5)
     int gemm256_persist = 0;   // 1: 16-bit 256x256 GEMM as one persistent launch (gemm256p.hip) - measured SLOWER than one block per tile (round 3), kept for A/B
     int gemm256_persist_cus = 256;   // ... on at most this many CUs (the rest stay free for whatever else runs; A/B)
     int gemm256_gm = 8;        // 256x256 GEMM raster: M tiles per group (a group sweeps all N tiles before the next M rows)

@@ -2447,6 +2447,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_skinny_i8_wide")) { e->opts.no_skinny_i8_wide = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gemm256_stagger")) { e->opts.gemm256_stagger = value; return SONIC_OK; }
     if (!strcmp(key, "flash_variant")) { e->opts.flash_variant = value; return SONIC_OK; }
+    if (!strcmp(key, "flash_enc")) { e->opts.flash_enc = value; return SONIC_OK; }          // 0: rounds 1-4's encoder attention; v > 0: flash_enc_kernel mode v - 1
     if (!strcmp(key, "gemm256_persist")) { e->opts.gemm256_persist = value; return SONIC_OK; }
     if (!strcmp(key, "gemm256_persist_cus")) { e->opts.gemm256_persist_cus = value > 0 ? value : 256; return SONIC_OK; }
     if (!strcmp(key, "gemm256_gm")) { e->opts.gemm256_gm = value > 0 ? value : 8; return SONIC_OK; }   // raster group height of the 256x256 GEMM (experiments)

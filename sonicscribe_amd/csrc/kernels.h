@@ -46,8 +46,10 @@ struct FlashArgs {
     int T, Hq, Hkv;
     float scale;
     int dt;                                // DT_BF16 / DT_F16
+    long long* dbg;                        // diagnostics (tools/flash_enc_bench): per block {shader clock, 100 MHz clock} at entry and exit; null in production
 };
 void launch_flash(const FlashArgs& a, int hd, bool causal, int B, int max_q, hipStream_t s);
+void launch_flash_enc(const FlashArgs& a, int B, int max_q, int mode, hipStream_t s);   // attn_enc.hip: head dim 64, no mask (the encoder)
 
 struct DecodeAttnArgs {
     const bf16_t* Q;      // [B][Hq*128] (roped); used when P == null

@@ -1,0 +1,147 @@
+// Round 5: the encoder's flash attention, old kernel (attn.hip, 16x16x32, 32 queries per wave) against flash_enc_kernel (attn_enc.hip) on the encoder's
+// shape (32 sequences x 20 heads x 1500 x 64), with a full fp64 reference for a few (sequence, head) pairs and a case that FORCES the
+// rare path of the fixed-maximum softmax (a late key far above the first tile's maximum).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I sonicscribe_amd/csrc tools/flash_enc_bench.hip -o build_tools/flash_enc_bench
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../sonicscribe_amd/csrc/attn.hip"
+#include "../sonicscribe_amd/csrc/attn_enc.hip"
+thread_local LaunchOpts g_opts;
+
+static float bf2f_h(unsigned short b) { unsigned u = (unsigned)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static unsigned short f2bf_h(float f) { unsigned u; std::memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 32, H = 20, T = 1500, HD = 64, Tp = 1536, C = H * HD;
+    const size_t nq = (size_t)B * T * C, nv = (size_t)B * C * Tp;
+    bf16_t *q, *k, *vt, *o, *o2;
+    hipMalloc(&q, nq * 2 + 65536); hipMalloc(&k, nq * 2 + 64 * C * 2 + 65536); hipMalloc(&vt, nv * 2 + 65536); hipMalloc(&o, nq * 2); hipMalloc(&o2, nq * 2);
+    std::vector<unsigned short> hq(nq), hk(nq), hv(nv);
+    auto fill = [&](std::vector<unsigned short>& h, size_t n, unsigned seed, float amp) {
+        unsigned s = seed;
+        for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; float f = ((int)(s >> 9) % 2001 - 1000) * (amp / 1000.f); h[i] = f2bf_h(f); }
+    };
+    fill(hq, nq, 1, 2.0f); fill(hk, nq, 2, 2.0f); fill(hv, nv, 3, 1.0f);
+    // the forced case: in sequence 0, head 3, key 1337 is 12 x key-sized in the direction of query 700 (score ~ +12 * |q|^2 / 8 above the rest)
+    const int fb = 0, fh = 3, fkey = 1337, fquery = 700;
+    for (int d = 0; d < HD; ++d) hk[((size_t)fb * T + fkey) * C + fh * HD + d] = f2bf_h(12.0f * bf2f_h(hq[((size_t)fb * T + fquery) * C + fh * HD + d]));
+    hipMemcpy(q, hq.data(), nq * 2, hipMemcpyHostToDevice); hipMemcpy(k, hk.data(), nq * 2, hipMemcpyHostToDevice); hipMemcpy(vt, hv.data(), nv * 2, hipMemcpyHostToDevice);
+    FlashArgs f{};
+    f.Q = q; f.q_ld = C; f.K = k; f.k_ld = C; f.Vt = vt; f.vt_ld = Tp; f.O = o; f.o_ld = C;
+    f.q_seq_stride = (long)T * C; f.k_seq_stride = (long)T * C; f.k_head_stride = HD; f.vt_seq_stride = (long)C * Tp; f.vt_head_stride = (long)HD * Tp;
+    f.T = T; f.Hq = H; f.Hkv = H; f.scale = 0.125f; f.dt = DT_BF16;
+    FlashArgs f2 = f; f2.O = o2;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double flops = 4.0 * B * H * (double)T * T * HD;
+    auto timeit = [&](const char* name, auto launch) {
+        launch(); hipDeviceSynchronize();
+        std::vector<float> ts;
+        for (int it = 0; it < 7; ++it) { hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ts.push_back(ms); }
+        std::sort(ts.begin(), ts.end());
+        printf("%-62s min %7.1f us  median %7.1f us  %6.1f TF/s  (%s)\n", name, ts[0] * 1e3, ts[3] * 1e3, flops / (ts[3] * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+    };
+    g_opts.flash_variant = 2;
+    g_opts.flash_enc = 0;                                    // launch_flash: rounds 1-4's kernel
+    for (int w = 0; w < 30; ++w) launch_flash(f, 64, false, B, T, 0);      // clocks up
+    hipDeviceSynchronize();
+    timeit("old: flash_attn_kernel<64> (flash_variant 2)", [&] { launch_flash(f, 64, false, B, T, 0); });
+    for (int rep = 0; rep < 3; ++rep) {
+        timeit("new: flash_enc mode 0 (fixed max, joint P.V)", [&] { launch_flash_enc(f2, B, T, 0, 0); });
+        timeit("new: flash_enc mode 2 (exact every tile, joint)", [&] { launch_flash_enc(f2, B, T, 2, 0); });
+        timeit("new: flash_encp mode 4 (pipelined, asm groups, 1 wave/SIMD)", [&] { launch_flash_enc(f2, B, T, 4, 0); });
+        timeit("old again", [&] { launch_flash(f, 64, false, B, T, 0); });
+    }
+    // ---- in-kernel clocks: shader cycles and wall time per block, modes 0 and 4
+    {
+        const size_t nblk = (size_t)((T + 255) / 256) * H * B;
+        long long* dbg; hipMalloc(&dbg, nblk * 32);
+        std::vector<long long> hd(nblk * 4);
+        for (int mode : {0, 4}) {
+            FlashArgs fd = f2; fd.dbg = dbg;
+            for (int w = 0; w < 20; ++w) launch_flash_enc(fd, B, T, mode, 0);
+            hipDeviceSynchronize();
+            hipMemcpy(hd.data(), dbg, nblk * 32, hipMemcpyDeviceToHost);
+            std::vector<double> cyc, ns;
+            for (size_t i = 0; i < nblk; ++i) { cyc.push_back((double)(hd[i * 4 + 2] - hd[i * 4 + 0])); ns.push_back((double)(hd[i * 4 + 3] - hd[i * 4 + 1]) * 10.0); }
+            std::sort(cyc.begin(), cyc.end()); std::sort(ns.begin(), ns.end());
+            const double c = cyc[nblk / 2], t = ns[nblk / 2];
+            printf("mode %d: median block %.0f shader cycles in %.0f ns -> clock %.2f GHz; per key tile %.0f cycles, per MFMA group (16 MFMAs = 1 slot) %.1f cycles\n",
+                   mode, c, t, c / t, c / 24.0, c / 24.0 / 32.0);
+        }
+    }
+    // ---- correctness: each mode against the old kernel (all outputs) and against fp64 for a few (sequence, head) pairs
+    std::vector<unsigned short> ha(nq), hb(nq);
+    launch_flash(f, 64, false, B, T, 0); hipDeviceSynchronize();
+    hipMemcpy(ha.data(), o, nq * 2, hipMemcpyDeviceToHost);
+    auto ref_pair = [&](int b, int h, std::vector<double>& out) {       // softmax(q k^T / 8) v in fp64 on the bf16 inputs
+        out.assign((size_t)T * HD, 0.0);
+        std::vector<double> sc(T);
+        for (int i = 0; i < T; ++i) {
+            double mx = -1e300;
+            for (int j = 0; j < T; ++j) {
+                double s = 0;
+                for (int d = 0; d < HD; ++d) s += (double)bf2f_h(hq[((size_t)b * T + i) * C + h * HD + d]) * (double)bf2f_h(hk[((size_t)b * T + j) * C + h * HD + d]);
+                sc[j] = s * 0.125; mx = sc[j] > mx ? sc[j] : mx;
+            }
+            double l = 0;
+            for (int j = 0; j < T; ++j) { sc[j] = std::exp(sc[j] - mx); l += sc[j]; }
+            for (int d = 0; d < HD; ++d) {
+                double acc = 0;
+                for (int j = 0; j < T; ++j) acc += sc[j] * (double)bf2f_h(hv[((size_t)b * C + h * HD + d) * Tp + j]);
+                out[(size_t)i * HD + d] = acc / l;
+            }
+        }
+    };
+    const int pairs[3][2] = {{fb, fh}, {0, 0}, {B - 1, H - 1}};
+    std::vector<std::vector<double>> refs(3);
+    for (int p = 0; p < 3; ++p) ref_pair(pairs[p][0], pairs[p][1], refs[p]);
+    auto check = [&](const char* name, const std::vector<unsigned short>& got) {
+        size_t nd = 0, nd2 = 0; double maxd = 0;
+        {   // error statistics vs fp64 over the three reference pairs, in units of the output's own bf16 step
+            double se_n = 0, se_o = 0; size_t cnt = 0, big_n = 0, big_o = 0;
+            for (int p = 0; p < 3; ++p)
+                for (int i = 0; i < T; ++i)
+                    for (int d = 0; d < HD; ++d) {
+                        const size_t idx = ((size_t)pairs[p][0] * T + i) * C + pairs[p][1] * HD + d;
+                        const double r = refs[p][(size_t)i * HD + d];
+                        int ex; std::frexp(std::fabs(r) > 1e-30 ? r : 1e-30, &ex);
+                        const double step = std::ldexp(1.0, ex - 8);                 // bf16 spacing at |r|
+                        const double en = std::fabs(bf2f_h(got[idx]) - r) / step, eo = std::fabs(bf2f_h(ha[idx]) - r) / step;
+                        se_n += en; se_o += eo; ++cnt; big_n += en > 0.75; big_o += eo > 0.75;
+                    }
+            printf("  %-28s mean |err| vs fp64 in bf16 steps: %.4f (old kernel %.4f); share above 0.75 step: %.4f %% (old %.4f %%)\n", name, se_n / cnt, se_o / cnt, 100.0 * big_n / cnt, 100.0 * big_o / cnt);
+        }
+        for (size_t i = 0; i < nq; ++i) {
+            if (got[i] != ha[i]) { ++nd; const double d = std::fabs((double)bf2f_h(got[i]) - (double)bf2f_h(ha[i])); maxd = d > maxd ? d : maxd; if (std::abs((int)got[i] - (int)ha[i]) > 1) ++nd2; }
+        }
+        printf("  %-28s vs old kernel: %zu of %zu outputs differ (%.3f %%), %zu by more than one bf16 step, max |diff| %.5f\n", name, nd, nq, 100.0 * nd / nq, nd2, maxd);
+        for (int p = 0; p < 3; ++p) {
+            const int b = pairs[p][0], h = pairs[p][1];
+            double e_new = 0, e_old = 0, rmax = 0; int nan = 0;
+            for (int i = 0; i < T; ++i)
+                for (int d = 0; d < HD; ++d) {
+                    const size_t idx = ((size_t)b * T + i) * C + h * HD + d;
+                    const double r = refs[p][(size_t)i * HD + d], gn = bf2f_h(got[idx]), go = bf2f_h(ha[idx]);
+                    if (!(gn == gn)) ++nan;
+                    e_new = std::fmax(e_new, std::fabs(gn - r)); e_old = std::fmax(e_old, std::fabs(go - r)); rmax = std::fmax(rmax, std::fabs(r));
+                }
+            printf("      (seq %d, head %d) vs fp64: max |err| new %.6f  old %.6f  (max |ref| %.4f, NaNs %d)%s\n", b, h, e_new, e_old, rmax, nan, p == 0 ? "   <- holds the forced rare-path row" : "");
+        }
+        // the forced row itself
+        const size_t idx = ((size_t)fb * T + fquery) * C + fh * HD;
+        double e = 0; for (int d = 0; d < HD; ++d) e = std::fmax(e, std::fabs((double)bf2f_h(got[idx + d]) - refs[0][(size_t)fquery * HD + d]));
+        printf("      forced row (query %d): max |err| vs fp64 %.6f\n", fquery, e);
+    };
+    for (int mode : {0, 2, 4}) {
+        hipMemset(o2, 0xFF, nq * 2);
+        launch_flash_enc(f2, B, T, mode, 0); hipDeviceSynchronize();
+        hipMemcpy(hb.data(), o2, nq * 2, hipMemcpyDeviceToHost);
+        char nm[64]; snprintf(nm, sizeof nm, "flash_enc mode %d", mode);
+        check(nm, hb);
+    }
+    return 0;
+}
