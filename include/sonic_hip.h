@@ -57,8 +57,8 @@ typedef enum {
  * LLM.int8() (row-wise int8 weights, per-token int8 activations, outlier columns |x| >= 6.0 in fp16).  bitsandbytes is absent offline,
  * so this mode is checked against the restatement in oracle/sonic_oracle.c only (parity unpinned). */
 enum { SONIC_MODE_NATIVE = 0 /* bf16, asr.py mode="native" */, SONIC_MODE_INT8 = 1 /* asr.py mode="int8" */,
-       /* test only: fp16 weights and activations through the SAME kernel templates (their KF16 / f16_t instantiations; the fused decode
-        * kernels are bf16-only, so the decode step takes the unfused forms), no quantisation.  Not an asr.py mode: it exists so that layouts,
+       /* test only: fp16 weights and activations through the SAME kernel templates (their KF16 / f16_t instantiations - since round 5 also
+        * the fused decode kernels skinny_o / skinny_gu the bf16 headline runs), no quantisation.  Not an asr.py mode: it exists so that layouts,
         * epilogues, RoPE, masking, KV append and the greedy controller can be checked at fp16's 8x finer rounding against the reference's fp32
         * arithmetic (tests/test_gpu_fp16_mode.py) */
        SONIC_MODE_F16 = 2 };

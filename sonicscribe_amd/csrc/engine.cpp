@@ -918,7 +918,7 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         }
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
         TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
-        if (e->dt == DT_BF16 && skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave; the fused decode kernels are bf16 only)
+        if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave); both 16-bit element types (round 5)
             TRY(dalloc_big(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
             launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
             e->weight_bytes += (int64_t)2 * d.dec_ff * d.dec_d * 2;
@@ -1177,15 +1177,15 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         if (fuse_o) {
             // o_proj + residual add (+ row sum-of-squares partials) -> gate/up with RMSNorm applied while staging X + SwiGLU:
             // two kernels instead of o_proj, add+RMSNorm, gate/up, SwiGLU
-            SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1; oa.kt = kt_slot(e, l, 2);
+            SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1; oa.dt = dt; oa.kt = kt_slot(e, l, 2);
             launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
-            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.kt = kt_slot(e, l, 3);
+            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt; ga.kt = kt_slot(e, l, 3);
             launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 16, L.ln2, d.dec_rms_eps, e->st);
         } else {
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st, dt);
         if (fuse_gu) {          // gate/up + SwiGLU in one kernel, no slabs
-            SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1;
+            SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt;
             launch_skinny_gu(ga, e->sact, e->st);
         } else {
             skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
@@ -2563,7 +2563,7 @@ extern "C" int sonic_test_skinny_gu(sonic_engine* e, const float* X, const float
     bf16_t* dWt = tb.get<bf16_t>((size_t)N * K); bf16_t* dA = tb.get<bf16_t>((size_t)M * (N / 2));
     if (!dX || !dW || !dWt || !dA) return fail(e, SONIC_ERR_OOM, "HIP out of memory in test hook");
     launch_tile_weights_gu8(dW, dWt, N, K, e->st);
-    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.M = M; a.N = N; a.K = K; a.ksplit = 1;
+    SkinnyArgs a{}; a.X = dX; a.ldx = K; a.W = dWt; a.M = M; a.N = N; a.K = K; a.ksplit = 1; a.dt = e->dt;
     launch_skinny_gu(a, dA, e->st);
     return down_bf16(e, tb, dA, act, (size_t)M * (N / 2));
 }

@@ -563,8 +563,8 @@ struct GuNorm { const float* SS; int nblk; const float* w; float eps; };   // SS
 // eight fragments of its own position (ds_read_b128, lane-linear), lanes 0-31 then hold four gate columns of one row, lanes 32-63 their up
 // partners (D[n][m]: n = 4 * (lane / 16) + e, gate n < 8, up n + 8), one cross-lane move pairs them and lanes 0-31 store four columns at once.
 // (Round 3's form walked 768 outputs with 16 scalar LDS reads and a 2-byte store each: 3.8 us of an 11.2 us kernel.)
-template <int MB, int TPB>
-__device__ __forceinline__ void gu_reduce_store(const f32x4* red, int wk, int lane, bf16_t* act, int ff, int col0, int row0, int m_valid) {
+template <typename T, int MB, int TPB>
+__device__ __forceinline__ void gu_reduce_store(const f32x4* red, int wk, int lane, T* act, int ff, int col0, int row0, int m_valid) {
     if (wk < TPB * MB) {
         const int j = wk / MB, mb = wk % MB;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -578,10 +578,10 @@ __device__ __forceinline__ void gu_reduce_store(const f32x4* red, int wk, int la
         for (int e = 0; e < 4; ++e) u[e] = __shfl(s[e], (lane + 32) & 63, 64);
         const int m = mb * 16 + (lane & 15);
         if (lane < 32 && m < m_valid) {
-            bf16x4 o;
+            typename ET<T>::v4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(silu_f(rbf(s[e]))) * rbf(u[e]));
-            *(bf16x4*)(act + (long)(row0 + m) * ff + col0 + j * 8 + (lane >> 4) * 4) = o;
+            for (int e = 0; e < 4; ++e) o[e] = (T)(rT<T>(silu_f(rT<T>(s[e]))) * rT<T>(u[e]));
+            *(typename ET<T>::v4*)(act + (long)(row0 + m) * ff + col0 + j * 8 + (lane >> 4) * 4) = o;
         }
     }
 }
@@ -589,8 +589,10 @@ __device__ __forceinline__ void gu_reduce_store(const f32x4* red, int wk, int la
 // NP = 2 (33 .. 64 rows): the block makes a second pass over rows 32 .. 63 - X image staged into the same LDS, the W fragments are still in
 // registers - so W is streamed once for all 64 rows and every row sees exactly the arithmetic of the one-pass kernel (same k order, same
 // reduction tree): a request's result does not depend on whether its batch has 8, 32 or 64 rows.
-template <int MB, int KS8, int TPB, bool NORM, int NP = 1>
-__global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* act, int ff, GuNorm nm) {
+template <typename T, int MB, int KS8, int TPB, bool NORM, int NP = 1>
+__global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, int ff, GuNorm nm) {
+    typedef typename ET<T>::v8 V8;
+    const T* aX = (const T*)a.X; const T* aW = (const T*)a.W;
     constexpr int K = KS8 * 256, NKB = K / 64, RG = MB * 2, NI = NKB * RG, KBS = MB * 2048, WTOT = TPB * KS8;
     static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
     for (int t = 0; t < PW; ++t) {                                   // X (NORM: the raw residual) -> LDS by DMA, lane-linear pieces
         const int ii = wk * PW + t, kblock = ii / RG, rg = ii % RG;
         int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
-        const bf16_t* src = a.X + (long)row * a.ldx + kblock * 64 + lc * 8;
+        const T* src = aX + (long)row * a.ldx + kblock * 64 + lc * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
     }
@@ -632,8 +634,8 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         }
     }
     constexpr int WPRE = NORM ? WTOT / 2 : WTOT, WREM = WTOT - WPRE;
-    bf16x8 wf[WTOT];                                                 // [tile j][k-step u] of this wave's K eighth
-    const bf16_t* wp = a.W + ((long)blockIdx.x * TPB * (K >> 5) + wk * KS8) * 512 + lane * 8;
+    V8 wf[WTOT];                                                     // [tile j][k-step u] of this wave's K eighth
+    const T* wp = aW + ((long)blockIdx.x * TPB * (K >> 5) + wk * KS8) * 512 + lane * 8;
     // W fragments by inline asm (nt), so that every wait on them is hand-counted: beside LDS-DMA the compiler's own bookkeeping waits
     // vmcnt(0) at the first use of an ordinary load.  The 13-bit instruction offset reaches four 1 KiB fragments per base address.
 #define GU_WBASE(f) (wp + ((long)((f) / KS8) * (K >> 5) + (((f) % KS8) / 4) * 4) * 512)
@@ -666,13 +668,13 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         for (int tt = 0; tt < PW; ++tt) {
             const int ii = wk * PW + tt, rg = ii % RG, kb = tt / RG;
             int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
-            float rr; bf16x8 xv;
+            float rr; V8 xv;
             asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_read_b128 %1, %4\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(rr), "=&v"(xv) : "v"(row << 2), "v"(rl_scale), "v"(lbase + tt * 1024) : "memory");
             const f32x4 w0 = nw[kb * 2], w1 = nw[kb * 2 + 1];
-            bf16x8 o;
+            V8 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { o[j] = f2bf(w0[j] * rbf(bf2f(xv[j]) * rr)); o[4 + j] = f2bf(w1[j] * rbf(bf2f(xv[4 + j]) * rr)); }
+            for (int j = 0; j < 4; ++j) { o[j] = (T)(w0[j] * rT<T>((float)xv[j] * rr)); o[4 + j] = (T)(w1[j] * rT<T>((float)xv[4 + j] * rr)); }
             asm volatile("ds_write_b128 %0, %1" ::"v"(lbase + tt * 1024), "v"(o) : "memory");
 #pragma unroll
             for (int f = WPRE + tt * WREM / PW; f < WPRE + (tt + 1) * WREM / PW; ++f)      // the next W fragment(s) go out behind this piece
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         __syncthreads();
     }
     KT(a, 3);
-    bf16x8 xfr[KS8][MB];
+    V8 xfr[KS8][MB];
     if constexpr (KS8 >= 2) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WTOT - KS8 < 63 ? WTOT - KS8 : 63) : "memory");   // X + tile 0's fragments
         // X fragments by inline asm: behind an LDS-DMA the compiler cannot see retired, it would put vmcnt(0) in front of a ds_read
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int m = mb * 16 + r;
-                xfr[u][mb] = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+                xfr[u][mb] = *(const V8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
             }
         }
     }
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 #pragma unroll
         for (int u = 0; u < KS8; ++u)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xfr[u][mb], acc[j][mb], 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb) acc[j][mb] = ET<T>::mfma(wf[j * KS8 + u], xfr[u][mb], acc[j][mb]);
         __builtin_amdgcn_sched_barrier(0);          // tile j's MFMAs go out before the wait for tile j + 1
     }
     KT(a, 5);
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         for (int mb = 0; mb < MB; ++mb) red[((wk * TPB + j) * MB + mb) * 64 + lane] = acc[j][mb];
     __syncthreads();
     constexpr int NC = 8 * TPB;
-    gu_reduce_store<MB, TPB>(red, wk, lane, act, ff, blockIdx.x * NC, 0, a.M);
+    gu_reduce_store<T, MB, TPB>(red, wk, lane, act, ff, blockIdx.x * NC, 0, a.M);
     KT(a, 6);
     if constexpr (NP == 2) {
         // ---- second pass: rows 32 .. 63.  No load is in flight any more (W landed in pass one), so plain waits do.
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
         for (int t = 0; t < PW; ++t) {
             const int ii = wk * PW + t, kblock = ii / RG, rg = ii % RG;
             int row = rg * 8 + lr; row = row < M2 ? row : M2 - 1;
-            const bf16_t* src = a.X + (long)(32 + row) * a.ldx + kblock * 64 + lc * 8;
+            const T* src = aX + (long)(32 + row) * a.ldx + kblock * 64 + lc * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
         }
@@ -786,12 +788,12 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
                 const int ii = wk * PW + tt, rg = ii % RG, kb = tt / RG;
                 int row = rg * 8 + lr; row = row < M2 ? row : M2 - 1;
                 const float rr = __shfl(rl_scale, row, 64);
-                bf16x8* px = (bf16x8*)(smem + ii * 1024 + lane * 16);
-                const bf16x8 xv = *px;
+                V8* px = (V8*)(smem + ii * 1024 + lane * 16);
+                const V8 xv = *px;
                 const f32x4 w0 = nw[kb * 2], w1 = nw[kb * 2 + 1];
-                bf16x8 o;
+                V8 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { o[j] = f2bf(w0[j] * rbf(bf2f(xv[j]) * rr)); o[4 + j] = f2bf(w1[j] * rbf(bf2f(xv[4 + j]) * rr)); }
+                for (int j = 0; j < 4; ++j) { o[j] = (T)(w0[j] * rT<T>((float)xv[j] * rr)); o[4 + j] = (T)(w1[j] * rT<T>((float)xv[4 + j] * rr)); }
                 *px = o;
             }
         }
@@ -807,9 +809,9 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int m = mb * 16 + r;
-                const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+                const V8 xf = *(const V8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
 #pragma unroll
-                for (int j = 0; j < TPB; ++j) acc2[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j * KS8 + u], xf, acc2[j][mb], 0, 0, 0);
+                for (int j = 0; j < TPB; ++j) acc2[j][mb] = ET<T>::mfma(wf[j * KS8 + u], xf, acc2[j][mb]);
             }
         }
         __syncthreads();
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) red[((wk * TPB + j) * MB + mb) * 64 + lane] = acc2[j][mb];
         __syncthreads();
-        gu_reduce_store<MB, TPB>(red, wk, lane, act, ff, blockIdx.x * NC, 32, M2);
+        gu_reduce_store<T, MB, TPB>(red, wk, lane, act, ff, blockIdx.x * NC, 32, M2);
         KT(a, 7);
     }
 }
@@ -828,22 +830,23 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, bf16_t* ac
 // through LDS and then writes x = bf16(x + bf16(acc)) in place.  It also emits, per block, the partial sum of squares of its 16
 // columns of every updated row (SS[block / 4][row][4], fixed summation order): the consumer (skinny_gu_kernel<NORM>) turns them into the
 // RMSNorm scale, so the separate add+RMSNorm kernel between o_proj and gate/up disappears.
-template <int KS8>
-__global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, int ldxres, float* SS) {
+template <typename T, int KS8>
+__global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, T* x, int ldxres, float* SS) {
+    typedef typename ET<T>::v8 V8;
     constexpr int K = KS8 * 256, NKB = K / 64, RG = 2, NI = NKB * RG, KBS = 2048, mpad = 16;
     static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * mpad, M = a.M - row0 < mpad ? a.M - row0 : mpad;
-    const bf16_t* X = a.X + (long)row0 * a.ldx;
+    const T* X = (const T*)a.X + (long)row0 * a.ldx;
     x += (long)row0 * ldxres;
     KT(a, 0);
-    bf16x8 wf[KS8];
+    V8 wf[KS8];
     {
-        const bf16_t* wp = a.W + ((long)blockIdx.x * (K >> 5) + wk * KS8) * 512 + lane * 8;
+        const T* wp = (const T*)a.W + ((long)blockIdx.x * (K >> 5) + wk * KS8) * 512 + lane * 8;
 #pragma unroll
-        for (int u = 0; u < KS8; ++u) wf[u] = __builtin_nontemporal_load((const bf16x8*)(wp + u * 512));
+        for (int u = 0; u < KS8; ++u) wf[u] = __builtin_nontemporal_load((const V8*)(wp + u * 512));
     }
     {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
@@ -851,14 +854,14 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
         for (int t = 0; t < NI / 8; ++t) {
             const int ii = wk * (NI / 8) + t, kblock = ii / RG, rg = ii % RG;
             int row = rg * 8 + lr; row = row < M ? row : M - 1;
-            const bf16_t* src = X + (long)row * a.ldx + kblock * 64 + lc * 8;
+            const T* src = X + (long)row * a.ldx + kblock * 64 + lc * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
         }
     }
     // residual value this thread updates in the epilogue (threads 0..255: row tid / 16, column tid % 16), fetched up front
     const int em = (tid >> 4) & 15, ec = tid & 15;
-    const bf16_t xres = x[(long)(em < M ? em : M - 1) * ldxres + blockIdx.x * 16 + ec];
+    const T xres = x[(long)(em < M ? em : M - 1) * ldxres + blockIdx.x * 16 + ec];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     KT(a, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -868,8 +871,8 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
 #pragma unroll
     for (int u = 0; u < KS8; ++u) {
         const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
-        const bf16x8 xf = *(const bf16x8*)(smem + kblock * KBS + r * 128 + (((half * 4 + g) ^ (r & 7)) << 4));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc, 0, 0, 0);
+        const V8 xf = *(const V8*)(smem + kblock * KBS + r * 128 + (((half * 4 + g) ^ (r & 7)) << 4));
+        acc = ET<T>::mfma(wf[u], xf, acc);
     }
     KT(a, 4);
     __syncthreads();
@@ -884,8 +887,8 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, bf16_t* x, 
         for (int k = 0; k < 8; ++k) v += red[k * 64 + ln][j];
         float xn = 0.f;
         if (em < M) {
-            xn = rbf(bf2f(xres) + rbf(v));
-            x[(long)em * ldxres + blockIdx.x * 16 + ec] = f2bf(xn);
+            xn = rT<T>((float)xres + rT<T>(v));
+            x[(long)em * ldxres + blockIdx.x * 16 + ec] = (T)xn;
         }
         sq[em * 16 + ec] = xn * xn;
     }
@@ -904,8 +907,10 @@ template <int MB, int KS8, int TPB, bool NORM, int NP = 1> static void launch_gu
     const size_t lds = (size_t)(KS8 * 4) * MB * 2048;               // X image
     const size_t redb = (size_t)8 * TPB * MB * 1024;
     const size_t need = lds > redb ? lds : redb;
-    if (need > 65536) ensure_dyn_lds((const void*)skinny_gu_kernel<MB, KS8, TPB, NORM, NP>, (int)need);
-    hipLaunchKernelGGL((skinny_gu_kernel<MB, KS8, TPB, NORM, NP>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, act, a.N / 2, nm);
+    DT_SWITCH(a.dt, T, {
+        if (need > 65536) ensure_dyn_lds((const void*)skinny_gu_kernel<T, MB, KS8, TPB, NORM, NP>, (int)need);
+        hipLaunchKernelGGL((skinny_gu_kernel<T, MB, KS8, TPB, NORM, NP>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, (T*)act, a.N / 2, nm);
+    });
 }
 // true if the fused kernel handles this shape (else: skinny GEMM + swiglu_slab_kernel)
 bool skinny_gu_eligible(int M, int N, int K) {
@@ -932,8 +937,10 @@ void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, in
 template <int KS8> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
     const size_t lds = (size_t)(KS8 * 4) * 2048;
     const size_t need = lds > (size_t)(8 * 1024 + 1024) ? lds : (size_t)(8 * 1024 + 1024);
-    if (need > 65536) ensure_dyn_lds((const void*)skinny_o_kernel<KS8>, (int)need);
-    hipLaunchKernelGGL((skinny_o_kernel<KS8>), dim3(a.N / 16, (a.M + 15) / 16), dim3(512), need, s, a, x, ldxres, SS);
+    DT_SWITCH(a.dt, T, {
+        if (need > 65536) ensure_dyn_lds((const void*)skinny_o_kernel<T, KS8>, (int)need);
+        hipLaunchKernelGGL((skinny_o_kernel<T, KS8>), dim3(a.N / 16, (a.M + 15) / 16), dim3(512), need, s, a, (T*)x, ldxres, SS);
+    });
 }
 bool skinny_o_eligible(int M, int N, int K) {
     if (g_opts.no_fused_gu) return false;

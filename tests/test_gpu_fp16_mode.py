@@ -2,8 +2,8 @@
 
 north_star asks for logits within 1e-3 of the reference; the bf16 path is within 4-8 bf16 ulp (0.06-0.12) of the bf16 reference arithmetic,
 which says nothing about errors smaller than that.  The same templates compiled for IEEE half (their KF16 / f16_t instantiations: 128x128 and
-256x256 GEMMs with every epilogue, flash and decode attention, norms, RoPE + KV append, the skinny decode GEMMs, the greedy controller; the
-bf16-only fused decode kernels are replaced by their unfused forms) are checked here
+256x256 GEMMs with every epilogue, flash and decode attention, norms, RoPE + KV append, the skinny decode GEMMs, the greedy controller and -
+since round 5 - the fused decode kernels skinny_o / skinny_gu that the bf16 headline runs: VERDICT r4 item 7) are checked here
   * against the oracle in fp16 mode - same rounding points, only the summation order differs: a few fp16 ulp;
   * against the oracle in FP32 mode with the same weights (bf16-valued, exact in fp16) = the reference's fp32 arithmetic (the oracle's fp32
     mode is pinned to transformers' fp32 generate() at 1e-3, tests/test_oracle_golden.py): what is left is fp16 activation rounding.
@@ -109,4 +109,16 @@ def test_full_width_layers_vocab_59264():
     feats, mask = oracle.logmel(seg)
     a = o16.transcribe(feats, int(mask.sum()), prompt, 6, force_ids=force[0]); b = o32.transcribe(feats, int(mask.sum()), prompt, 6, force_ids=force[0])
     check("full-width 1 + 1 layers, 6 forced steps", lg[:, 0], a["step_logits"], b["step_logits"], ulps16=4.0, abs32=8e-3)
+    # the decode steps above went through the FUSED decode kernels (skinny_o + skinny_gu with RMSNorm in LDS: eligible at this width, and since
+    # round 5 instantiated for fp16 as well - they are what the bf16 headline runs).  The unfused forms must meet the same bounds, and the two
+    # paths must not be the same computation (different reduction trees: some logits differ in their last bits)
+    e.set_option("no_fused_gu", 1)
+    e.set_forced_ids(force)
+    _, lg_u = e.transcribe_batch([seg], [prompt], [6], want_logits=True)
+    e.set_forced_ids(None)
+    e.set_option("no_fused_gu", 0)
+    check("full-width 1 + 1 layers, unfused decode path", lg_u[:, 0], a["step_logits"], b["step_logits"], ulps16=4.0, abs32=8e-3)
+    assert np.array_equal(lg_u[0], lg[0])                              # (step 0 is the prefill: no decode kernel involved)
+    assert not np.array_equal(lg_u[1:], lg[1:]), "the fused decode kernels were not taken in fp16 mode"
+    assert np.abs(lg_u - lg).max() <= 8 * f16_ulp(np.abs(b["step_logits"]).max())
     e.close()
