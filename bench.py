@@ -436,6 +436,8 @@ def main():
     ap.add_argument("--slots", type=int, default=3, help="batches of --batch segments in flight per GPU on one engine / one weight copy (sonic_slot_create); 1 = rounds 1-3's definition")
     ap.add_argument("--pipeline", default="2x64+1", help="the headline leg: bulk pipeline 'DxR+P' = D decoding handles looping continuously over R rows each + P "
                     "prefill slots, all on the engine's one weight copy (sonicscribe_amd/pipeline.py); 'off' = the headline is the --slots leg")
+    ap.add_argument("--pipeline-host", default="native", choices=["native", "python"], help="who drives the bulk pipeline's hand-overs: threads inside libsonic_hip.so "
+                    "(sonic_pipeline_*, round 5) or round 4's Python threads (sonicscribe_amd/pipeline.py ContinuousPipeline; A/B)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects int8_b64 / streaming / pcie_inclusive of the N=1 line")
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -571,39 +573,53 @@ def main():
     # ---- leg C (headline): the bulk pipeline - decoding handles loop continuously over their rows, prefill slots splice whole batches in
     pipe_info = None
     if pipe_cfg:
-        from sonicscribe_amd.pipeline import ContinuousPipeline
+        from sonicscribe_amd.pipeline import ContinuousPipeline, NativePipeline
         nd, prow, npre = pipe_cfg
-        pipe = ContinuousPipeline(engines[:nd], engines[nd:nd + npre], block=B)
+        native = a.pipeline_host == "native"
         want_ids = ids
         prompts_b, budgets_b = [prompt] * len(segs), [a.max_new] * len(segs)
-        run_pipe = lambda n: pipe.run(n, lambda p: p.prefill(prompts_b, budgets_b, wait=False), lambda i, got: np.array_equal(got, want_ids[i]))
-        run_pipe(pipe.batches_in_flight)                       # warm-up: graphs of the row count, every handle touched
         # Verification pass (untimed): the timed batches are identical, which cannot show a batch that was prefilled with its
         # neighbour's plan.  Here every batch is DIFFERENT - segments rotated and restaged, a different text tail per row, a different budget per
-        # row - and every row must give the tokens of the same request in a plain run_staged batch on the owner.
+        # row - and every row must give the tokens of the same request in a plain run_staged batch.
         n_var = 3
         var = []
         for v in range(n_var):
             segs_v = segs[v + 1:] + segs[:v + 1]
             prompts_v = [prompt + [40 + v, 50 + (i * 5 + v) % 23] * (1 + (i + v) % 3) for i in range(len(segs))]
             budgets_v = [max(1, a.max_new - (i * 7 + v * 13) % 41) for i in range(len(segs))]
-            eng_v = engines[nd]                                  # a prefill slot computes the expected tokens as a plain batch (the decoders are in continuous mode)
+            eng_v = engines[nd]                                  # a prefill slot computes the expected tokens as a plain batch
             eng_v.stage_pcm(segs_v); eng_v.run_staged(prompts_v, budgets_v)
             var.append((segs_v, prompts_v, budgets_v, eng_v.fetch_tokens(len(segs), a.max_new)))
-        import itertools
-        ctr, ctr_lock = itertools.count(), threading.Lock()
+        n_ver = 2 * n_var + 1
+        if native:
+            pipe = NativePipeline(engines[:nd], engines[nd:nd + npre], block=B)
+            tick = [pipe.submit(var[j % n_var][1], var[j % n_var][2], segments=var[j % n_var][0]) for j in range(n_ver)]
+            wrong = 0
+            for j, t in enumerate(tick):
+                got = pipe.wait(t)
+                wrong += sum(0 if (len(g) == var[j % n_var][2][i] and np.array_equal(g, var[j % n_var][3][i])) else 1 for i, g in enumerate(got))
+            res_v = {"batches": n_ver, "wrong_rows": wrong}
+            for p_ in engines[nd:nd + npre]:
+                p_.stage_pcm(segs)                              # back to the timed workload's staged PCM
+            run_pipe = lambda n: pipe.run(n, prompts_b, budgets_b, lambda i, got: np.array_equal(got, want_ids[i]))
+        else:
+            pipe = ContinuousPipeline(engines[:nd], engines[nd:nd + npre], block=B)
+            run_pipe = lambda n: pipe.run(n, lambda p: p.prefill(prompts_b, budgets_b, wait=False), lambda i, got: np.array_equal(got, want_ids[i]))
+            run_pipe(pipe.batches_in_flight)                   # graphs of the row count, every handle touched
+            import itertools
+            ctr, ctr_lock = itertools.count(), threading.Lock()
 
-        def prefill_var(p):
-            with ctr_lock:
-                v = next(ctr) % n_var
-            p.stage_pcm(var[v][0])
-            p.prefill(var[v][1], var[v][2], wait=False)
-            return v
-        res_v = pipe.run(2 * n_var + 1, prefill_var, lambda i, got, v: len(got) == var[v][2][i] and np.array_equal(got, var[v][3][i]))
-        assert res_v["batches"] == 2 * n_var + 1 and res_v["wrong_rows"] == 0, f"pipeline verification pass (varied batches): {res_v}"
-        for p_ in engines[nd:nd + npre]:
-            p_.stage_pcm(segs)                                  # back to the timed workload's staged PCM
-        run_pipe(pipe.batches_in_flight)
+            def prefill_var(p):
+                with ctr_lock:
+                    v = next(ctr) % n_var
+                p.stage_pcm(var[v][0])
+                p.prefill(var[v][1], var[v][2], wait=False)
+                return v
+            res_v = pipe.run(n_ver, prefill_var, lambda i, got, v: len(got) == var[v][2][i] and np.array_equal(got, var[v][3][i]))
+            for p_ in engines[nd:nd + npre]:
+                p_.stage_pcm(segs)
+        assert res_v["batches"] == n_ver and res_v["wrong_rows"] == 0, f"pipeline verification pass (varied batches): {res_v}"
+        run_pipe(pipe.batches_in_flight)                       # warm-up in the timed pattern
         barrier()
         c0 = cpu_s()
         t0 = time.perf_counter()
@@ -615,6 +631,8 @@ def main():
         pipe.close()
         pipe_info = {"decoders": nd, "rows_per_decoder": prow, "prefill_slots": npre, "batches_in_flight": pipe.batches_in_flight, "rows_bit_identical_to_single_batch": True,
                      "decode_chunks_queued": res["decode_chunks"],
+                     "host": ("native threads inside libsonic_hip.so (sonic_pipeline_*: condition variables + blocking events, no interpreter in the loop)" if native
+                              else "Python threads over the C ABI (round 4's driver)"),
                      "verification_pass": {"batches": res_v["batches"], "wrong_rows": res_v["wrong_rows"],
                                            "what": f"{n_var} different batches (segments rotated and restaged, per-row text tails and budgets) cycled through the pipeline "
                                                    "before the clock: every row equals the same request in a plain batch run"}}
@@ -650,7 +668,7 @@ def main():
             "rtf": 1.0 / (SEG_SECONDS * value),
             "config": {"workload": ((f"bulk pipeline on one engine / one weight copy ({weight_bytes / 2 ** 20:.0f} MiB): {pipe_info['decoders']} decoding handles each run ONE continuous greedy loop over "
                                      f"{pipe_info['rows_per_decoder']} rows ({pipe_info['rows_per_decoder'] // B} batches of {B} per loop), {pipe_info['prefill_slots']} prefill slot(s) run log-mel + encoder + prompt forward + first "
-                                     f"token of whole batches and splice their rows into a free block (sonic_service_* / sonic_prefill / sonic_splice_rows / sonic_fetch_row, sonicscribe_amd/pipeline.py): "
+                                     f"token of whole batches and splice their rows into a free block (sonic_service_* / sonic_prefill / sonic_splice_rows / sonic_fetch_row), hand-overs by {pipe_info['host']}: "
                                      f"up to {pipe_info['batches_in_flight']} batches of {B} in flight; {a.steps} batches timed from an empty pipeline to the last fetched row, every row's tokens equal the single-batch run's; ") if pipe_info else
                                     (f"{n_slots} batches of {B} in flight, one engine, one weight copy ({weight_bytes / 2 ** 20:.0f} MiB; per-slot stream, activation "
                                      f"buffers, KV cache, decode graphs): {a.steps} batches go round-robin to the slots through sonic_run_staged_async / sonic_wait, ") if n_slots > 1

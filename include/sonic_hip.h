@@ -39,7 +39,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table (tests/test_host_logic.py checks
  * `nm -D` against this header).  SONIC_ABI_VERSION moves whenever a signature or a struct layout below changes. */
 #define SONIC_API __attribute__((visibility("default")))
-#define SONIC_ABI_VERSION 5
+#define SONIC_ABI_VERSION 6
 SONIC_API int sonic_abi_version(void);
 
 typedef struct sonic_engine sonic_engine;
@@ -120,6 +120,33 @@ SONIC_API int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64
  * sonic_slot_count: the owner plus its live slots. */
 SONIC_API int sonic_slot_create(sonic_engine* owner_or_slot, sonic_engine** slot_out);
 SONIC_API int sonic_slot_count(sonic_engine* e);
+
+/* ---- the bulk pipeline as native threads (round 5) ----
+ * What sonicscribe_amd/pipeline.py's host loop does (round 4: Python threads over the calls above, polling) inside the library: one thread per
+ * prefill handle (stage PCM, queue log-mel + encoder + prompt forward + first token, hand the batch over), one per decoding handle (splice
+ * handed-over batches into free row blocks of its continuously decoding handle, queue decode chunks, fetch the rows of a block the moment all of
+ * them are finished).  Every wait is a condition variable or a blocking HIP event: no polling, no interpreter in the loop - the headline no longer
+ * depends on how quickly a busy host schedules Python threads.  The reference's counterpart: three executor threads around one model object
+ * (backend/main.py:429-445, 616-624).
+ *   sonic_pipeline_create(decoders, n_dec, prefills, n_pre, block, rows_per_decoder, &p)   handles of ONE weight copy (an engine and its slots);
+ *                       the decoders are put into continuous mode (sonic_service_begin); a decoder holds rows_per_decoder / block batches at a time
+ *   sonic_pipeline_submit(p, pcm, offsets, W, req_win, R, prompt_ids, prompt_off, max_new, out_ids, out_ld, out_len, &ticket)
+ *                       one batch of R <= block requests (arguments as sonic_transcribe_batch).  pcm == NULL: the batch is what the prefill
+ *                       handles already have staged (sonic_stage_pcm on each of them; the benchmark's HBM-resident input).  The prompt arrays
+ *                       are copied; pcm, out_ids and out_len must stay valid until the ticket is waited for.  Returns at once.
+ *   sonic_pipeline_wait(p, ticket)   blocks until that batch's rows are in out_ids / out_len and returns its status; ticket 0: every batch
+ *                       submitted so far, first failure or SONIC_OK.  A bad request fails alone; a failed decoding handle fails everything in flight.
+ *   sonic_pipeline_destroy(p)       completes what was submitted, joins the threads, sonic_service_end on the decoders (the handles stay yours) */
+typedef struct sonic_pipeline sonic_pipeline;
+SONIC_API int sonic_pipeline_create(sonic_engine* const* decoders, int n_dec, sonic_engine* const* prefills, int n_pre, int block, int rows_per_decoder,
+                                    sonic_pipeline** out);
+SONIC_API int sonic_pipeline_submit(sonic_pipeline* p, const int16_t* pcm, const int64_t* offsets, int W, const int32_t* req_win, int R,
+                                    const int32_t* prompt_ids, const int64_t* prompt_off, const int32_t* max_new,
+                                    int32_t* out_ids, int out_ld, int32_t* out_len, int64_t* ticket_out);
+SONIC_API int sonic_pipeline_wait(sonic_pipeline* p, int64_t ticket);
+SONIC_API int sonic_pipeline_stats(sonic_pipeline* p, int64_t* batches_done, int64_t* chunks_queued, int32_t* batches_in_flight_max);
+SONIC_API const char* sonic_pipeline_last_error(sonic_pipeline* p);
+SONIC_API int sonic_pipeline_destroy(sonic_pipeline* p);
 
 /* ---- weights (names: GlmAsrForConditionalGeneration.state_dict() keys, see sonicscribe_amd/spec.py) ---- */
 SONIC_API int sonic_load_tensor(sonic_engine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);

@@ -2386,6 +2386,7 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     launch_synth_fill(0x1234, (long)M * K, 1.0f, 0.f, dA, nullptr, e->st);
     launch_synth_fill(0x5678, (long)N * K, 0.05f, 0.f, dW, nullptr, e->st);
     a.A = dA; a.lda = K; a.W = dW; a.C = dC; a.ldc = (epi == EPI_QKV_VT) ? 2 * N / 3 : Nout; a.bias = db; a.R = dC; a.ldr = Nout; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = e->dt;
+    a.gelu_lut = e->opt_no_gelu_lut ? nullptr : e->gelu_lut;          // as the encoder's fc1 (round 5: the bench used to time the arithmetic GELU)
     for (int i = 0; i < 2; ++i) launch_gemm(a, epi, e->st);
     hipEvent_t ea, eb; HIPC(e, hipEventCreate(&ea)); HIPC(e, hipEventCreate(&eb));
     (void)hipEventRecord(ea, e->st);

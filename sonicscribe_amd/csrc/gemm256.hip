@@ -466,8 +466,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 if constexpr (LUT) {
                     if (a.gelu_lut) {
                         const unsigned short* lut = (const unsigned short*)(smem + LDS256_BYTES);
-                        // branch-free: every lane reads the table at a clamped index (the four reads of a fragment in flight together),
-                        // the two out-of-table cases are selects afterwards
+                        // Round 5: the table index in packed 16-bit arithmetic on the bf16 PAIRS v_cvt_pk_bf16_f32 produces (the round-4 form
+                        // converted every value to bf16 and back, took the index from the float's bits and clamped / selected per element:
+                        // ~14 VALU instructions per element, 8-10 us of a GELU tile's 16 us fixed cost).  A value outside the table
+                        // (|x| < 2^-14 or >= 16: about 5e-5 of the elements) makes the wave redo the fragment the round-4 way: same bits.
+                        typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+                        typedef __bf16 b16x2_t __attribute__((ext_vector_type(2)));
+                        b16x2_t p01, p23;
+                        p01[0] = (__bf16)((float)acc[nb][mb][0] + bv[0]); p01[1] = (__bf16)((float)acc[nb][mb][1] + bv[1]);
+                        p23[0] = (__bf16)((float)acc[nb][mb][2] + bv[2]); p23[1] = (__bf16)((float)acc[nb][mb][3] + bv[3]);
+                        const u16x2_t u01 = __builtin_bit_cast(u16x2_t, p01), u23 = __builtin_bit_cast(u16x2_t, p23);
+                        const u16x2_t k7 = {0x7FFF, 0x7FFF}, kp = {GELU_LUT_E0 << 7, GELU_LUT_E0 << 7}, kh = {GELU_LUT_HALF, GELU_LUT_HALF};
+                        const u16x2_t i01 = (u01 & k7) - kp, i23 = (u23 & k7) - kp;                   // index in the half table; wraps to >= HALF when outside
+                        const u16x2_t mx = __builtin_elementwise_max(i01, i23);
+                        const u16x2_t s01 = i01 + (u01 >> 15) * kh, s23 = i23 + (u23 >> 15) * kh;     // + HALF for negative values
+                        const bool oob = mx[0] >= GELU_LUT_HALF || mx[1] >= GELU_LUT_HALF;
+                        unsigned t0 = lut[s01[0]], t1 = lut[s01[1]], t2 = lut[s23[0]], t3 = lut[s23[1]];
+                        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));                     // (the four reads stay unconditional and in flight together)
+                        if (__builtin_amdgcn_ballot_w64(oob) == 0) {
+                            typedef unsigned u32x2o_t __attribute__((ext_vector_type(2)));
+                            u32x2o_t ov; ov[0] = t0 | (t1 << 16); ov[1] = t2 | (t3 << 16);
+                            *(u32x2o_t*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = ov;
+                            continue;
+                        }
                         float l[4]; unsigned t[4]; int idx[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                             t[j] = lut[gelu_lut_slot(l[j], idx[j])];
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(t[j]));          // (keeps the reads unconditional and batched)
+                        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(t[j]));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_lut_value(l[j], idx[j], t[j]);
                         *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;

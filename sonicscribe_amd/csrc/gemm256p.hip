@@ -46,9 +46,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a) {
     constexpr int CE = 8, TBK = 64;
     constexpr bool LUT = EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value;
     constexpr int LUT_BYTES = LUT ? GELU_LUT_N * 2 : 0;
-    constexpr int SR = LUT ? 32 : 64;            // rows per staging pass
+    constexpr int SR = LUT ? 32 : 64;            // rows per staging pass (SwiGLU / QKV + V^T epilogues: block-wide passes)
     constexpr int NPASS = 256 / SR;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring | GELU table | staging (SR rows x 512 B, XOR-swizzled 16-B chunks)
+    // bias / GELU / residual epilogues (round 5): every wave transposes ITS 128 x 64 outputs through a private 16-row scratch (WS_PITCH bytes per
+    // row) - no block barrier in the epilogue, all eight waves work at once
+    constexpr bool PERWAVE = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID;
+    constexpr int WS_PITCH = 144, WS_BYTES = 16 * WS_PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring | GELU table | staging (SR rows x 512 B, XOR-swizzled 16-B chunks; or 8 wave scratches)
     char* const stg = smem + RING_BYTES + LUT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,13 +235,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a) {
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b4[nb]) : "v"(a.bias + n) : "memory");
             }
         }
+        // ---- residual rows of this wave's 128 x 64 outputs (per-wave epilogue): 16 x 16 bytes per lane, asm loads for the same reason
+        i32x4 rres[PERWAVE && EPI == EPI_BIAS_RESID ? 16 : 1];
+        if constexpr (PERWAVE && EPI == EPI_BIAS_RESID) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int m = m0 + wr * 128 + (q >> 1) * 16 + (lane >> 3) + 8 * (q & 1); m = m < a.M ? m : a.M - 1;
+                int n = n0 + wc * 64 + (lane & 7) * 8; n = n < a.N ? n : 0;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[q]) : "v"(R + (long)m * a.ldr + n) : "memory");
+            }
+        }
         // ---- the next tile's first two K tiles go out now; the epilogue below works beside them
         const int vbn = vb + gridDim.x;
         const bool more = vbn < nt;
         int tmn = 0, tnn = 0;
         if (more) { tile_of(vbn, tmn, tnn); set_src(tmn * T256, tnn * T256); prologue(); }
         if (has_bias) {
-            if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PERWAVE && EPI == EPI_BIAS_RESID) { if (more) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else { if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(b4[nb]));
         } else {
@@ -307,6 +322,67 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a) {
                     if (m < a.M && oc < No) *(O8*)(C + (long)m * a.ldc + oc) = *(const O8*)stg_addr(row, ch * 8);
                 }
                 __syncthreads();
+            }
+        } else if constexpr (PERWAVE) {
+            // acc[nb][mb][j] = D[n = n0 + wc*64 + nb*16 + fg*4 + j][m = m0 + wr*128 + mb*16 + fr].  Pass mb: the wave's 16 rows x 64 columns go
+            // through its scratch (lane (fr, fg) writes 8 bytes at row fr, column nb*16 + fg*4) and leave as 128-byte row pieces (8 lanes x 16 B).
+            // LDS operations of one wave execute in order, so neither the read-after-write inside a pass nor the write-after-read between passes
+            // needs a barrier.  Residual rows were requested before the next tile's operand DMAs and are waited for with a counted vmcnt
+            // (they are older than the DMAs; the stores of earlier passes are younger): the K loop's DMAs stay in flight under the epilogue.
+            char* const ws = stg + wid * WS_BYTES;
+            const int rrow = lane >> 3, rch = lane & 7;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const float bv[4] = {b4[nb][0], b4[nb][1], b4[nb][2], b4[nb][3]};
+                    O4 o;
+                    if (EPI == EPI_BIAS_GELU) {
+                        bool done = false;
+                        if constexpr (LUT) {
+                            if (a.gelu_lut) {
+                                const unsigned short* lut = (const unsigned short*)(smem + RING_BYTES);
+                                float l[4]; unsigned t[4]; int idx[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    l[j] = rT<OT>((float)acc[nb][mb][j] + bv[j]);
+                                    idx[j] = gelu_lut_index(l[j]);
+                                    t[j] = lut[gelu_lut_slot(l[j], idx[j])];
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(t[j]));
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_lut_value(l[j], idx[j], t[j]);
+                                done = true;
+                            }
+                        }
+                        if (!done) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(rT<OT>((float)acc[nb][mb][j] + bv[j]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (OT)rT<OT>((float)acc[nb][mb][j] + bv[j]);   // RESID: the linear's own output; R is added below
+                    }
+                    *(O4*)(ws + fr * WS_PITCH + (nb * 16 + fg * 4) * 2) = o;
+                }
+                if (EPI == EPI_BIAS_RESID) {
+                    // residual pieces of this pass have landed: all but the (14 - 2 mb) younger residual loads, the next tile's 16 DMAs and the 2 mb stores so far
+                    if (more) asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rrow + 8 * i;
+                    const int m = m0 + wr * 128 + mb * 16 + row, n = n0 + wc * 64 + rch * 8;
+                    O8 v = *(const O8*)(ws + row * WS_PITCH + rch * 16);
+                    if (EPI == EPI_BIAS_RESID) {
+                        asm volatile("" : "+v"(rres[mb * 2 + i]));
+                        const O8 rv = __builtin_bit_cast(O8, rres[mb * 2 + i]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (OT)((float)v[j] + (float)rv[j]);
+                    }
+                    if (m < a.M && n < a.N) *(O8*)(C + (long)m * a.ldc + n) = v;
+                }
             }
         } else {
             // fused partial RoPE (encoder q / k heads): dims [0,16) are accumulator block 0 and their rotation partners [16,32) block 1 of the
@@ -396,7 +472,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a) {
 
 template <typename KD, int EPI> static void launch256p_v(const GemmArgs& a, int cus, hipStream_t s) {
     constexpr bool LUT = EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value;
-    constexpr int LDS = RING_BYTES + (LUT ? GELU_LUT_N * 2 + 32 * 512 : 64 * 512);
+    constexpr bool PERWAVE = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID;
+    constexpr int LDS = RING_BYTES + (PERWAVE ? (LUT ? GELU_LUT_N * 2 : 0) + 8 * 16 * 144 : (LUT ? GELU_LUT_N * 2 + 32 * 512 : 64 * 512));
     ensure_dyn_lds((const void*)gemm256p_kernel<KD, EPI>, LDS);
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256, nt = tilesM * tilesN;
     int grid = nt < cus ? nt : cus;

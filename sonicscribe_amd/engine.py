@@ -32,8 +32,9 @@ EXPORTS = [
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
     "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_fetch_rows", "sonic_prefill_enqueue",
     "sonic_runtime_info",
+    "sonic_pipeline_create", "sonic_pipeline_submit", "sonic_pipeline_wait", "sonic_pipeline_stats", "sonic_pipeline_last_error", "sonic_pipeline_destroy",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SonicDims(C.Structure):
@@ -130,6 +131,13 @@ def load_library():
     lib.sonic_prefill_enqueue.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.sonic_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, i64p, i64p, ip]
     lib.sonic_runtime_info.argtypes = [C.c_int, ip, ip, ip]
+    lib.sonic_pipeline_create.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.sonic_pipeline_submit.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, i64p]
+    lib.sonic_pipeline_wait.argtypes = [vp, C.c_int64]
+    lib.sonic_pipeline_stats.argtypes = [vp, i64p, i64p, ip]
+    lib.sonic_pipeline_last_error.argtypes = [vp]
+    lib.sonic_pipeline_last_error.restype = C.c_char_p
+    lib.sonic_pipeline_destroy.argtypes = [vp]
     lib.sonic_memory_info.argtypes = [vp, i64p, i64p]
     lib.sonic_set_forced_ids.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.sonic_test_greedy.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]

@@ -7,11 +7,16 @@ streams fill each other's launch gaps; the MFMA-bound prefill work runs beside t
 `ASRModel.transcribe()`, backend/asr.py:335-488, per segment) and - rows being independent in every decode kernel up to 64 rows - exactly the
 tokens of a solo run.
 
-The driver is host threads over GIL-releasing C-ABI calls: one per decoder (splice, step, fetch), one per prefill slot.  It is what bench.py times
-for its headline and what `tools/ab_continuous_throughput.py` sweeps; request-level scheduling for live traffic is dispatch._ContinuousReplica.
+Two drivers of the same schedule:
+  * NativePipeline (round 5, the headline leg of bench.py): the hand-overs are native threads inside libsonic_hip.so (csrc/pipeline.cpp,
+    sonic_pipeline_*): this module only submits batches and waits for tickets;
+  * ContinuousPipeline (round 4): Python threads over GIL-releasing C-ABI calls, one per decoder (splice, step, fetch), one per prefill slot -
+    kept for A/B (`bench.py --pipeline-host python`, `tools/ab_continuous_throughput.py`) and for the CPU tests, which drive it with stub engines.
+Request-level scheduling for live traffic is dispatch._ContinuousReplica.
 """
 from __future__ import annotations
 
+import ctypes as C
 import queue
 import threading
 import time
@@ -128,3 +133,86 @@ class ContinuousPipeline:
         if errors:
             raise errors[0]
         return {"wall_s": dt, "batches": state["done"], "wrong_rows": state["bad"], "decode_chunks": state["steps"]}
+
+
+class NativePipeline:
+    """The bulk pipeline with its host loop inside the library (include/sonic_hip.h sonic_pipeline_*; csrc/pipeline.cpp): submit() queues a
+    batch and returns a ticket, native threads stage / prefill / splice / step / fetch, wait() blocks on a condition variable.  Same handles,
+    same schedule and - rows being independent in every decode kernel - the same tokens as ContinuousPipeline."""
+
+    def __init__(self, decoders: Sequence[Any], prefills: Sequence[Any], block: int = 32):
+        if not decoders or not prefills:
+            raise ValueError("at least one decoder and one prefill slot")
+        self.decoders, self.prefills, self.block = list(decoders), list(prefills), int(block)
+        self.lib = self.decoders[0].lib
+        self.rows = (self.decoders[0].max_batch // self.block) * self.block
+        if self.rows < self.block:
+            raise ValueError("max_batch is smaller than a block")
+        dec = (C.c_void_p * len(self.decoders))(*[d.h for d in self.decoders])
+        pre = (C.c_void_p * len(self.prefills))(*[p.h for p in self.prefills])
+        h = C.c_void_p()
+        rc = self.lib.sonic_pipeline_create(dec, len(self.decoders), pre, len(self.prefills), self.block, self.rows, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"sonic_pipeline_create failed with status {rc}: " + (self.lib.sonic_last_error(self.decoders[0].h) or b"").decode())
+        self.h = h
+        self.batches_in_flight = len(self.decoders) * (self.rows // self.block) + len(self.prefills)
+        self._keep = {}                                     # ticket -> arrays the native side reads / writes until the ticket is collected
+
+    def _err(self) -> str:
+        return (self.lib.sonic_pipeline_last_error(self.h) or b"").decode()
+
+    def submit(self, prompts: Sequence[Sequence[int]], max_new: Sequence[int], segments: Optional[Sequence[np.ndarray]] = None,
+               req_win: Optional[Sequence[int]] = None) -> int:
+        """One batch of len(prompts) <= block requests.  segments: int16 PCM windows (staged by the pipeline's prefill thread), or None = the
+        batch is what every prefill handle has staged already.  Returns the ticket."""
+        from .engine import Engine, _p
+        ids, poffs = Engine._pack_prompts(prompts)
+        mn = np.ascontiguousarray(max_new, dtype=np.int32)
+        rw = np.ascontiguousarray(req_win, dtype=np.int32) if req_win is not None else None
+        R = len(prompts)
+        ld = int(mn.max())
+        out = np.zeros((R, ld), np.int32)
+        out_len = np.zeros(R, np.int32)
+        pcm = offs = None
+        W = 0
+        if segments is not None:
+            pcm, offs = self.decoders[0]._pack_pcm(segments)
+            W = len(segments)
+        t = C.c_int64(0)
+        rc = self.lib.sonic_pipeline_submit(self.h, _p(pcm), _p(offs), W, _p(rw), R, _p(ids), _p(poffs), _p(mn), _p(out), ld, _p(out_len), C.byref(t))
+        if rc != 0:
+            raise RuntimeError(self._err() or f"sonic_pipeline_submit failed with status {rc}")
+        self._keep[t.value] = (pcm, offs, out, out_len)
+        return int(t.value)
+
+    def wait(self, ticket: int) -> List[np.ndarray]:
+        """Blocks until the batch is complete; returns its rows' token ids.  Raises what the batch failed with."""
+        rc = self.lib.sonic_pipeline_wait(self.h, int(ticket))
+        _, _, out, out_len = self._keep.pop(ticket)
+        if rc != 0:
+            raise RuntimeError(self._err() or f"batch failed with status {rc}")
+        return [out[r, : out_len[r]].copy() for r in range(len(out_len))]
+
+    def stats(self) -> dict:
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self.lib.sonic_pipeline_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"batches": int(a.value), "decode_chunks": int(b.value), "batches_in_flight": int(c.value)}
+
+    def run(self, n_batches: int, prompts: Sequence[Sequence[int]], max_new: Sequence[int], check: Optional[Callable[[int, np.ndarray], bool]] = None) -> dict:
+        """n_batches copies of one batch that every prefill handle has staged (bench.py's timed loop): everything is submitted at once, the clock
+        runs until the last ticket is complete; rows are checked after it has stopped."""
+        c0 = self.stats()["decode_chunks"]
+        t0 = time.perf_counter()
+        tickets = [self.submit(prompts, max_new) for _ in range(n_batches)]
+        rows = [self.wait(t) for t in tickets]
+        dt = time.perf_counter() - t0
+        bad = 0
+        if check is not None:
+            for got in rows:
+                bad += sum(0 if check(i, ids) else 1 for i, ids in enumerate(got))
+        return {"wall_s": dt, "batches": len(rows), "wrong_rows": bad, "decode_chunks": self.stats()["decode_chunks"] - c0}
+
+    def close(self):
+        if self.h:
+            self.lib.sonic_pipeline_destroy(self.h)
+            self.h = None
