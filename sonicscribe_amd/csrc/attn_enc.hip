@@ -42,7 +42,11 @@ __device__ __forceinline__ float halves_sum(float v) {
 
 #define FE_TILE 8192                      // one K tile (64 keys x 128 B) or one V^T tile (64 hd rows x 128 B)
 #define FE_STAGE (2 * FE_TILE)
-#define FE_BIG 1.0e30f                    // a tile's partial row sum at or above this (or not finite) sends the tile through the exact path
+// A tile's partial row sum at or above FE_BIG (or not finite) sends the tile through the exact path.  bf16 has fp32's exponent range; an fp16
+// probability overflows at 65504, so in fp16 (int8 mode / the fp16 test mode) the fixed maximum may lag the true one by at most ~10 nats.
+template <typename T> struct FEBig { static constexpr float v = 1.0e30f; };
+template <> struct FEBig<f16_t> { static constexpr float v = 3.0e4f; };
+#define FE_BIG (FEBig<T>::v)
 
 // MODE bit 0: the second product of the two query blocks as separate MFMA runs (query block A's P.V beside block B's softmax)
 //      bit 1: exact path on every tile (the classic online softmax; A/B and the reference for the fast path's tests)
@@ -294,7 +298,7 @@ typedef unsigned u32x4e_t __attribute__((ext_vector_type(4)));
 // block in which some partial row sum left the safe range is recomputed by the classic online softmax after the loop (exact_block; never seen on
 // real activations, forced in tests/test_gpu_flash_enc.py).
 // Four LDS stages (V(t-1) | K(t), V(t) | K(t+1) | the tile in flight), one barrier per key tile.
-template <typename T> struct FEAsm;
+template <typename T, bool AG> struct FEAsm;       // AG: O and the Q fragments are AGPR operands (one wave per SIMD) or plain VGPRs (two)
 // The softmax beside an MFMA is itself pipelined over three groups, so that no instruction reads a result younger than a whole group (a
 // v_fma -> v_exp -> v_add chain inside ONE group waits for each stage's latency: measured 109 cycles per group instead of the ~45 the issue costs add up to):
 //     group g:   add + add + packed convert of group g-1's exponentials (x0, x1)  |  exp of group g's scaled scores (t0, t1, made in group g-1)  |
@@ -310,21 +314,21 @@ template <typename T> struct FEAsm;
 #define FE_RD "ds_read_b128 %[nf], %[na] offset:%c[off]\n\ts_waitcnt lgkmcnt(%c[w])\n\t"
 #define FE_NORD "s_waitcnt lgkmcnt(%c[w])\n\t"
 #define FE_CARRY [x0] "+v"(x0), [x1] "+v"(x1), [t0] "+v"(t0), [t1] "+v"(t1)
-#define FE_ASM_IMPL(TY, MF, CVT)                                                                                                                             \
-    template <> struct FEAsm<TY> {                                                                                                                           \
+#define FE_ASM_IMPL(TY, AGB, OC, MF, CVT)                                                                                                                   \
+    template <> struct FEAsm<TY, AGB> {                                                                                                                           \
         typedef typename ET<TY>::v8 V8;                                                                                                                      \
         static __device__ __forceinline__ void lds(V8& f, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(addr)); }                      \
         /* group 0: O (AGPRs) += fr . p; exp of group 0, fma of group 1 */                                                                                     \
         template <int W, int OFF> static __device__ __forceinline__ void pv_first(f32x16& o, V8 fr, u32x4e_t b, float e0, float e1, float c, float moff,     \
                                                                                   float& x0, float& x1, float& t0, float& t1, V8& nf, unsigned na) {          \
             asm volatile(FE_RD MF " %[o], %[fr], %[b], %[o]\n\t" FE_EXP FE_FMA                                                                               \
-                         : [o] "+a"(o), [x0] "=&v"(x0), [x1] "=&v"(x1), [t0] "+v"(t0), [t1] "+v"(t1), [nf] "=&v"(nf)                                         \
+                         : [o] "+" OC(o), [x0] "=&v"(x0), [x1] "=&v"(x1), [t0] "+v"(t0), [t1] "+v"(t1), [nf] "=&v"(nf)                                         \
                          : [fr] "v"(fr), [b] "v"(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [na] "v"(na), [off] "n"(OFF), [w] "n"(W));       \
         }                                                                                                                                                    \
         template <int W, int OFF> static __device__ __forceinline__ void pv_mid(f32x16& o, V8 fr, u32x4e_t b, float e0, float e1, float c, float moff,       \
                                                                                 float& ps, unsigned& pk, float& x0, float& x1, float& t0, float& t1, V8& nf, unsigned na) { \
             asm volatile(FE_RD MF " %[o], %[fr], %[b], %[o]\n\t" FE_ADDCVT(CVT) FE_EXP FE_FMA                                                                \
-                         : [o] "+a"(o), [ps] "+v"(ps), [pk] "=&v"(pk), FE_CARRY, [nf] "=&v"(nf)                                                              \
+                         : [o] "+" OC(o), [ps] "+v"(ps), [pk] "=&v"(pk), FE_CARRY, [nf] "=&v"(nf)                                                              \
                          : [fr] "v"(fr), [b] "v"(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [na] "v"(na), [off] "n"(OFF), [w] "n"(W));       \
         }                                                                                                                                                    \
         /* S (VGPRs) = fr . q (AGPRs) / += */                                                                                                                 \
@@ -332,40 +336,42 @@ template <typename T> struct FEAsm;
                                                                                  float& ps, unsigned& pk, float& x0, float& x1, float& t0, float& t1, V8& nf, unsigned na) { \
             asm volatile(FE_RD MF " %[o], %[fr], %[b], 0\n\t" FE_ADDCVT(CVT) FE_EXP FE_FMA                                                                   \
                          : [o] "=&v"(o), [ps] "+v"(ps), [pk] "=&v"(pk), FE_CARRY, [nf] "=&v"(nf)                                                             \
-                         : [fr] "v"(fr), [b] "a"(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [na] "v"(na), [off] "n"(OFF), [w] "n"(W));       \
+                         : [fr] "v"(fr), [b] OC(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [na] "v"(na), [off] "n"(OFF), [w] "n"(W));       \
         }                                                                                                                                                    \
         template <int W, int OFF> static __device__ __forceinline__ void qk_mid(f32x16& o, V8 fr, V8 b, float e0, float e1, float c, float moff,             \
                                                                                 float& ps, unsigned& pk, float& x0, float& x1, float& t0, float& t1, V8& nf, unsigned na) { \
             asm volatile(FE_RD MF " %[o], %[fr], %[b], %[o]\n\t" FE_ADDCVT(CVT) FE_EXP FE_FMA                                                                \
                          : [o] "+v"(o), [ps] "+v"(ps), [pk] "=&v"(pk), FE_CARRY, [nf] "=&v"(nf)                                                              \
-                         : [fr] "v"(fr), [b] "a"(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [na] "v"(na), [off] "n"(OFF), [w] "n"(W));       \
+                         : [fr] "v"(fr), [b] OC(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [na] "v"(na), [off] "n"(OFF), [w] "n"(W));       \
         }                                                                                                                                                    \
         template <int W> static __device__ __forceinline__ void qk_mid_nord(f32x16& o, V8 fr, V8 b, float e0, float e1, float c, float moff,                 \
                                                                             float& ps, unsigned& pk, float& x0, float& x1, float& t0, float& t1) {            \
             asm volatile(FE_NORD MF " %[o], %[fr], %[b], %[o]\n\t" FE_ADDCVT(CVT) FE_EXP FE_FMA                                                              \
                          : [o] "+v"(o), [ps] "+v"(ps), [pk] "=&v"(pk), FE_CARRY                                                                              \
-                         : [fr] "v"(fr), [b] "a"(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [w] "n"(W));                                    \
+                         : [fr] "v"(fr), [b] OC(b), [e0] "v"(e0), [e1] "v"(e1), [c] "v"(c), [mo] "v"(moff), [w] "n"(W));                                    \
         }                                                                                                                                                    \
         /* group 15: no further scores to scale; the trailing s_nop is the trans -> VALU wait state for the compiler's code behind the statement */            \
         template <int W> static __device__ __forceinline__ void qk_last(f32x16& o, V8 fr, V8 b, float& ps, unsigned& pk, float& x0, float& x1, float t0, float t1) { \
             asm volatile(FE_NORD MF " %[o], %[fr], %[b], %[o]\n\t" FE_ADDCVT(CVT) "v_exp_f32 %[x0], %[t0]\n\tv_exp_f32 %[x1], %[t1]\n\ts_nop 1"             \
                          : [o] "+v"(o), [ps] "+v"(ps), [pk] "=&v"(pk), [x0] "+v"(x0), [x1] "+v"(x1)                                                          \
-                         : [fr] "v"(fr), [b] "a"(b), [t0] "v"(t0), [t1] "v"(t1), [w] "n"(W));                                                                \
+                         : [fr] "v"(fr), [b] OC(b), [t0] "v"(t0), [t1] "v"(t1), [w] "n"(W));                                                                \
         }                                                                                                                                                    \
         /* the MFMAs alone (prologue, last P.V) */                                                                                                            \
-        static __device__ __forceinline__ void pv(f32x16& o, V8 fr, u32x4e_t b) { asm volatile(MF " %0, %1, %2, %0" : "+a"(o) : "v"(fr), "v"(b)); }            \
-        static __device__ __forceinline__ void qk(f32x16& o, V8 fr, V8 b) { asm volatile(MF " %0, %1, %2, %0" : "+v"(o) : "v"(fr), "a"(b)); }                 \
-        static __device__ __forceinline__ void qk0(f32x16& o, V8 fr, V8 b) { asm volatile(MF " %0, %1, %2, 0" : "=&v"(o) : "v"(fr), "a"(b)); }                \
-        static __device__ __forceinline__ void zero(f32x16& o, V8 z) { asm volatile(MF " %0, %1, %1, 0" : "=&a"(o) : "v"(z)); }                               \
+        static __device__ __forceinline__ void pv(f32x16& o, V8 fr, u32x4e_t b) { asm volatile(MF " %0, %1, %2, %0" : "+" OC(o) : "v"(fr), "v"(b)); }            \
+        static __device__ __forceinline__ void qk(f32x16& o, V8 fr, V8 b) { asm volatile(MF " %0, %1, %2, %0" : "+v"(o) : "v"(fr), OC(b)); }                 \
+        static __device__ __forceinline__ void qk0(f32x16& o, V8 fr, V8 b) { asm volatile(MF " %0, %1, %2, 0" : "=&v"(o) : "v"(fr), OC(b)); }                \
+        static __device__ __forceinline__ void zero(f32x16& o, V8 z) { asm volatile(MF " %0, %1, %1, 0" : "=&" OC(o) : "v"(z)); }                               \
     };
-FE_ASM_IMPL(bf16_t, "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
-FE_ASM_IMPL(f16_t, "v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32")
+FE_ASM_IMPL(bf16_t, true, "a", "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
+FE_ASM_IMPL(f16_t, true, "a", "v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32")
+FE_ASM_IMPL(bf16_t, false, "v", "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
+FE_ASM_IMPL(f16_t, false, "v", "v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32")
 
-template <typename T>
-__global__ __launch_bounds__(256, 1) void flash_encp_kernel(FlashArgs a) {
+template <typename T, bool AG>
+__global__ __launch_bounds__(256, AG ? 1 : 2) void flash_encp_kernel(FlashArgs a) {
     typedef typename ET<T>::v8 V8;
     typedef typename ET<T>::v4 V4;
-    typedef FEAsm<T> AS;
+    typedef FEAsm<T, AG> AS;
     __shared__ __attribute__((aligned(16))) char smem[4 * FE_STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -419,7 +425,10 @@ __global__ __launch_bounds__(256, 1) void flash_encp_kernel(FlashArgs a) {
         for (int ks = 0; ks < 4; ++ks) { qA[ks] = *(const V8*)(Q + (long)ra * a.q_ld + ks * 16 + h * 8); qB[ks] = *(const V8*)(Q + (long)rb * a.q_ld + ks * 16 + h * 8); }
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+a"(qA[ks])); asm volatile("" : "+a"(qB[ks])); }       // retired here, and at home in AGPRs
+    for (int ks = 0; ks < 4; ++ks) {                                          // retired here (and, AG, at home in AGPRs)
+        if constexpr (AG) { asm volatile("" : "+a"(qA[ks])); asm volatile("" : "+a"(qB[ks])); }
+        else { asm volatile("" : "+v"(qA[ks])); asm volatile("" : "+v"(qB[ks])); }
+    }
 
     const int kap = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);
     int koff[4], voff[4];
@@ -594,7 +603,8 @@ void launch_flash_enc(const FlashArgs& a, int B, int max_q, int mode, hipStream_
     dim3 grid((max_q + 255) / 256, a.Hq, B), block(256);
     DT_SWITCH(a.dt, T, {
         switch (mode & 7) {
-            case 4: hipLaunchKernelGGL((flash_encp_kernel<T>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((flash_encp_kernel<T, true>), grid, block, 0, s, a); break;     // one wave per SIMD, O / Q in AGPRs
+            case 5: hipLaunchKernelGGL((flash_encp_kernel<T, false>), grid, block, 0, s, a); break;    // two waves per SIMD, everything in VGPRs
             case 1: hipLaunchKernelGGL((flash_enc_kernel<T, 1>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((flash_enc_kernel<T, 2>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((flash_enc_kernel<T, 3>), grid, block, 0, s, a); break;

@@ -146,6 +146,7 @@ struct GemmArgs {
     // (GELU_LUT_N bf16 bit patterns: both signs x exponents 2^-14 .. 2^3 x 128 mantissas) is copied to LDS and indexed by the bits
     const unsigned short* gelu_lut;
     int raster_gm;                   // 256x256 kernel: M tiles per raster group (0: default 8)
+    long long* dbg;                  // diagnostics (sonic_bench_gemm with option gemm_trace): per block 8 words {entry, first K tile landed, K loop done, stores issued (100 MHz clock), hw id}; null in production
 };
 #define GELU_LUT_E0 113                     // biased exponent of 2^-14
 #define GELU_LUT_NE 18                      // exponents 2^-14 .. 2^3  (|x| < 16)

@@ -139,7 +139,7 @@ struct sonic_engine {
 
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
-    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0;
+    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0, opt_gemm_trace = 0, opt_no_rope_tiles = 0;
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
     int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
@@ -1340,6 +1340,7 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
         RopeAppendArgs ra{}; ra.dt = dt;
         ra.qkv = e->dqkv; ra.ld = e->qkvN; ra.q_out = e->dq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = e->Vts; ra.vt_ld = e->max_ctx;
         ra.tok_seq = e->tok_seq; ra.tok_pos = e->tok_pos_pf; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = M;
+        if (!e->opt_no_rope_tiles) { ra.q_off = e->q_off; ra.q_len = e->q_len; ra.n_seq = R; ra.max_p = hp.max_p; }       // tiles of 16 positions per sequence (round 5)
         launch_rope_append(ra, false, e->st);
         FlashArgs f{}; f.dt = dt;
         f.Q = e->dq; f.q_ld = e->QD; f.K = e->Kc + kvoff; f.k_ld = d.dec_head_dim; f.Vt = e->Vts; f.vt_ld = e->max_ctx; f.O = e->datt; f.o_ld = e->QD;
@@ -2388,6 +2389,36 @@ extern "C" int sonic_bench_gemm(sonic_engine* e, int M, int N, int K, int epi, i
     a.A = dA; a.lda = K; a.W = dW; a.C = dC; a.ldc = (epi == EPI_QKV_VT) ? 2 * N / 3 : Nout; a.bias = db; a.R = dC; a.ldr = Nout; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = e->dt;
     a.gelu_lut = e->opt_no_gelu_lut ? nullptr : e->gelu_lut;          // as the encoder's fc1 (round 5: the bench used to time the arithmetic GELU)
     for (int i = 0; i < 2; ++i) launch_gemm(a, epi, e->st);
+    if (e->opt_gemm_trace) {
+        // diagnostics: where a 256x256 tile's time goes (in-kernel 100 MHz stamps of every block of ONE launch) and how long a CU waits between two blocks
+        const int nblk = ((M + 255) / 256) * ((N + 255) / 256);
+        long long* dbg = tb.get<long long>((size_t)nblk * 8);
+        if (dbg) {
+            (void)hipMemsetAsync(dbg, 0, (size_t)nblk * 64, e->st);
+            GemmArgs t = a; t.dbg = dbg;
+            launch_gemm(t, epi, e->st);
+            std::vector<long long> h((size_t)nblk * 8);
+            if (d2h(e, h.data(), dbg, (size_t)nblk * 64) == hipSuccess) {
+                std::map<long long, std::vector<std::pair<long long, long long>>> per_cu;     // hw id -> (entry, exit)
+                double s01 = 0, s12 = 0, s23 = 0; int n = 0;
+                for (int b = 0; b < nblk; ++b) {
+                    const long long* r = &h[(size_t)b * 8];
+                    if (!r[0] || !r[3]) continue;
+                    s01 += (r[1] - r[0]) * 0.01; s12 += (r[2] - r[1]) * 0.01; s23 += (r[3] - r[2]) * 0.01; ++n;
+                    per_cu[r[4] & 0x0000000F0000FF00ll].push_back({r[0], r[3]});            // XCC_ID[3:0] | HW_ID: se_id[15:13] sh_id[12] cu_id[11:8]
+                }
+                double gap = 0; int ng = 0; long long t_first = 0, t_last = 0;
+                for (auto& kv : per_cu) {
+                    auto& v = kv.second; std::sort(v.begin(), v.end());
+                    for (size_t i = 1; i < v.size(); ++i) { gap += (v[i].first - v[i - 1].second) * 0.01; ++ng; }
+                    for (auto& x : v) { if (!t_first || x.first < t_first) t_first = x.first; if (x.second > t_last) t_last = x.second; }
+                }
+                fprintf(stderr, "[gemm_trace] M=%d N=%d K=%d epi=%d: %d blocks on %zu CUs; per block: entry -> first K tile landed %.2f us, K loop %.2f us, epilogue %.2f us; "
+                                "gap between consecutive blocks of a CU %.2f us (n=%d); first entry -> last exit %.1f us\n",
+                        M, N, K, epi, n, per_cu.size(), s01 / n, s12 / n, s23 / n, ng ? gap / ng : 0.0, ng, (t_last - t_first) * 0.01);
+            }
+        }
+    }
     hipEvent_t ea, eb; HIPC(e, hipEventCreate(&ea)); HIPC(e, hipEventCreate(&eb));
     (void)hipEventRecord(ea, e->st);
     for (int i = 0; i < iters; ++i) launch_gemm(a, epi, e->st);
@@ -2458,6 +2489,8 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "decode_lookahead")) { e->lookahead = value < 1 ? 1 : (value > CHK_MAX_AHEAD ? CHK_MAX_AHEAD : value); return SONIC_OK; }   // start value (it adapts)
     if (!strcmp(key, "decode_chunk")) { e->opt_decode_chunk = value > 0 ? (value > 64 ? 64 : value) : 1; return SONIC_OK; }   // token steps per graph launch / early-stop check
+    if (!strcmp(key, "no_rope_tiles")) { e->opt_no_rope_tiles = value; return SONIC_OK; }  // prefill RoPE + KV append per token (rounds 1-4) instead of per 16-position tile (A/B)
+    if (!strcmp(key, "gemm_trace")) { e->opt_gemm_trace = value; return SONIC_OK; }        // sonic_bench_gemm prints an in-kernel timeline of one launch to stderr
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch
     if (!strcmp(key, "no_fused_rope")) { e->opt_no_fused_rope = value; return SONIC_OK; }  // encoder RoPE as its own pass (A/B against the fused epilogue)
     if (!strcmp(key, "ktrace")) {              // diagnostics: record in-kernel timestamps of decoder layer `value` (-1: off); sonic_debug_ktrace reads them

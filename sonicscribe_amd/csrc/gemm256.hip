@@ -52,6 +52,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int fr = lane & 15, fg = lane >> 4;
+#define G256_STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    G256_STAMP(0);
+    if (a.dbg && tid == 0) a.dbg[(long)blockIdx.x * 8 + 4] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
 
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
     const int nt = tilesM * tilesN;
@@ -106,6 +109,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                                                  (__attribute__((address_space(3))) void*)(smem + LDS256_BYTES + i * 1024), 16, 0, 0);
         }
     }
+    // The tile's 256 bias values -> LDS (16-bit kinds; 1 KiB = one DMA instruction of one wave, issued before the operand prologue: older than
+    // every operand DMA, so the K loop's first counted wait + barrier cover it).  Round 4 loaded them with four dependent global loads per lane
+    // AFTER the K loop: ~3 us of exposed load latency in every tile's epilogue.
+    constexpr int BIAS_OFF = LDS256_BYTES + (LUT ? GELU_LUT_N * 2 : 0);
+    constexpr bool SBIAS = !KD::I8;
+    if constexpr (SBIAS) {
+        if (wid == 1 && a.bias) {
+            int n = n0 + lane * 4; n = n + 3 < a.N ? n : 0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + n),
+                                             (__attribute__((address_space(3))) void*)(smem + BIAS_OFF), 16, 0, 0);
+        }
+    }
+    const float* sbias = (const float*)(smem + BIAS_OFF);
     Acc acc[4][8];   // [n-block][m-block]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -247,6 +263,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         using IM1 = std::integral_constant<int, -1>;
         auto run = [&](auto grp, auto vt) {
             wait_vm<12>();                                                               // D0(0) landed
+            G256_STAMP(1);
             int kt = 0;
             for (; kt < nk - 2; ++kt) stile(grp, vt, kt, I10{}, I12{}, I12{}, Yes{}, kt == 0);
             stile(grp, vt, kt, I10{}, I8{}, I4{}, No{}, false);
@@ -260,19 +277,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         } else { if (wid < 4) run(Yes{}, No{}); else run(No{}, No{}); }
     }
 
+    G256_STAMP(2);
     // ---- epilogue.  acc[nb][mb][j] = D[n = n0 + wc*64 + nb*16 + fg*4 + j][m = m0 + wr*128 + mb*16 + fr].
     // Per-lane stores of that layout are 8-byte pieces on 16 different lines per instruction (measured: ~18 us per tile,
     // a third of the kernel at K = 1280).  Instead the bf16 tile is staged in LDS (free once the K loop is done) with the
     // op's rounding sequence applied in registers, then written as full 512-byte rows, 16 B per lane; the residual is read
     // with the same coalesced pattern in that final pass.
     __syncthreads();
+    // Residual pieces of the row-wise store pass (16-bit kinds): requested NOW, 16 x 16 bytes per thread, so that they arrive while the tile is
+    // converted and staged.  Round 4 loaded each piece inside the store pass and waited for it there: 4-10 us of a residual tile's fixed cost
+    // was exposed load latency.  asm loads + one hand-placed wait (the compiler would otherwise wait at its own first use - fine - but it may
+    // also move plain loads below the staging code again).
+    constexpr bool RPRE = EPI == EPI_BIAS_RESID && !KD::I8;
+    i32x4 rpre[RPRE ? 16 : 1];
+    if constexpr (RPRE) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int c = it * 512 + tid, row = c >> 5, ch = c & 31;
+            int m = m0 + row, n = n0 + ch * 8;
+            m = m < a.M ? m : a.M - 1; n = n < a.N ? n : 0;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rpre[it]) : "v"(R + (long)m * a.ldr + n) : "memory");
+        }
+    }
     constexpr int CLD = 528;                     // staged row pitch in bytes (256 bf16 + 16 B skew)
     if (EPI == EPI_QKV_VT && vtile) {
         // staged transposed: row = n (256), columns = m; V^T[seg][n - n_split][t .. t+3] leaves in 8-byte pieces (T % 4 == 0)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const int nl = wc * 64 + nb * 16 + fr, n = n0 + nl;
-            const float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+            const float bv = (a.bias && n < a.N) ? (SBIAS ? sbias[nl] : a.bias[n]) : 0.f;
             const int nc = n < a.N ? n : a.N - 1;
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
@@ -380,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         const int nl = wc * 64 + nb * 16 + fg * 4, n = n0 + nl;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.bias && n < a.N) {
-            const f32x4 b4 = *(const f32x4*)(a.bias + n);
+            const f32x4 b4 = SBIAS ? *(const f32x4*)(sbias + nl) : *(const f32x4*)(a.bias + n);
             bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
         }
         const int nc = n + 3 < a.N ? n : 0;                  // (clamped: columns beyond N are computed and dropped)
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         float bv1[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 sb1 = {0.f, 0.f, 0.f, 0.f};
         if (rope && nb == 0) {
-            if (a.bias) { const f32x4 b4 = *(const f32x4*)(a.bias + nc + 16); bv1[0] = b4[0]; bv1[1] = b4[1]; bv1[2] = b4[2]; bv1[3] = b4[3]; }
+            if (a.bias) { const f32x4 b4 = SBIAS ? *(const f32x4*)(sbias + nl + 16) : *(const f32x4*)(a.bias + nc + 16); bv1[0] = b4[0]; bv1[1] = b4[1]; bv1[2] = b4[2]; bv1[3] = b4[3]; }
             if constexpr (KD::I8) sb1 = *(const f32x4*)(a.q.scb + nc + 16);
         }
 #pragma unroll
@@ -514,7 +547,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         }
     }
     __syncthreads();
-#pragma unroll 4
+    if constexpr (RPRE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 16; ++it) asm volatile("" : "+v"(rpre[it]));
+    }
+#pragma unroll RPRE ? 16 : 4
     for (int it = 0; it < 16; ++it) {
         const int c = it * 512 + tid, row = c >> 5, ch = c & 31;
         const int m = m0 + row, n = n0 + ch * 8;
@@ -548,18 +586,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 if (smem[LDS256_BYTES + row]) { *(O8*)((OT*)a.q.defer_out + (long)blockIdx.z * a.strideC + (long)m * a.ldc + n) = v; continue; }
             }
             if (EPI == EPI_BIAS_RESID) {
-                const O8 rv = *(const O8*)(R + (long)m * a.ldr + n);
+                O8 rv;
+                if constexpr (RPRE) rv = __builtin_bit_cast(O8, rpre[it]); else rv = *(const O8*)(R + (long)m * a.ldr + n);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (OT)((float)v[j] + (float)rv[j]);
             }
             *(O8*)(C + (long)m * a.ldc + n) = v;
         }
     }
+    G256_STAMP(3);
 }
 
 
 template <typename KD, int EPI, bool STG> static void launch256v(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = LDS256_BYTES + ((EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value) ? GELU_LUT_N * 2 : 0) + ((KD::I8 && EPI == EPI_BIAS_RESID) ? 256 : 0);
+    constexpr int LDS = LDS256_BYTES + ((EPI == EPI_BIAS_GELU && std::is_same<KD, KBF16>::value) ? GELU_LUT_N * 2 : 0) + ((KD::I8 && EPI == EPI_BIAS_RESID) ? 256 : 0) + (KD::I8 ? 0 : 1024);
     ensure_dyn_lds((const void*)gemm256_kernel<KD, EPI, STG>, LDS);
     const int tilesM = (a.M + T256 - 1) / T256, tilesN = (a.N + T256 - 1) / T256;
     hipLaunchKernelGGL((gemm256_kernel<KD, EPI, STG>), dim3(tilesM * tilesN, 1, a.batch > 0 ? a.batch : 1), dim3(512), LDS, s, a);

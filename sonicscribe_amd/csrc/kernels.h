@@ -79,6 +79,9 @@ struct RopeAppendArgs {
     const float* cs;                     // [ctx_max][hd]: cos[0..hd/2) | sin[0..hd/2)
     int Hq, Hkv, ctx_max, n_tok;
     int dt;
+    // prefill, round 5 (optional): packed-token offset and length of every sequence and the longest prompt.  With them the kernel works on tiles of
+    // 16 consecutive positions of ONE sequence, so the V^T scratch is written in 16-byte rows instead of one 2-byte store per element
+    const int* q_off; const int* q_len; int n_seq, max_p;
 };
 void launch_rope_append(const RopeAppendArgs& a, bool slab, hipStream_t s);
 

@@ -58,3 +58,27 @@ def test_rccl_branch_at_world_size_one():
     assert abs(out["value"] * out["ms_per_step"] / 1e3 - B) < 1e-6 * B
     assert abs(out["single_batch"]["value"] * out["single_batch"]["ms_per_step"] / 1e3 - B) < 1e-6 * B
     assert "backend nccl" in r.stderr
+
+
+def test_eight_ranks_share_one_gpu_and_leave_the_host_alone():
+    """The driver's SCALE run puts 8 ranks on one node whose job has 16 CPUs of quota: every rank runs its pipeline threads
+    (native since round 5: csrc/pipeline.cpp) plus the runtime's own.  Eight ranks of the real launch path on the one-GPU box (gloo, shared device,
+    tiny dimensions): one JSON line, n_gpus = 8, disjoint shards, and a rank needs at most ~1.5 host CPUs in every leg - waits sleep (blocking events,
+    condition variables), nothing polls - so 8 ranks stay within 12 CPUs."""
+    B, steps, n = 4, 2, 8
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", "29735",
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", "1", "--dims", "tiny", "--batch", str(B), "--max-new", "12",
+           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--slots", "2", "--pipeline", "2x8+1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["config"]["share_gpu"] is True and out["config"]["pipeline"]["rows_bit_identical_to_single_batch"] is True
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - n * B) < 1e-6 * n * B
+    assert "native threads" in out["config"]["pipeline"]["host"]
+    shards = {int(m.group(1)): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"\[bench\] rank (\d)/8 device 0 backend gloo segments \[(\d+), (\d+)\)", r.stderr)}
+    assert shards == {k: shard_range(n * B, k, n) for k in range(n)}, r.stderr[-1500:]
+    busy = out["config"]["host_cpus_busy"]
+    assert all(v <= 1.5 for v in busy.values()), busy          # x 8 ranks <= 12 CPUs of a 16-CPU quota

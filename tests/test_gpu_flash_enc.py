@@ -1,7 +1,7 @@
 """Round 5's encoder attention (csrc/attn_enc.hip: head dim 64, no mask - modeling_glmasr.py:171-221 through sdpa, driven from
 backend/asr.py:411-422) in its three forms against the oracle's attention: the shipped one (option flash_enc = 1: running maximum fixed after
-the first key tile), the classic online softmax of the same kernel (3), and the software-pipelined asm form (5: one wave per SIMD, O and Q in
-AGPRs; kept as a measured experiment).  The fixed-maximum forms have a rare path - a partial row sum that leaves the safe range sends the tile
+the first key tile), the classic online softmax of the same kernel (3), and the software-pipelined asm forms (5: one wave per SIMD, O and Q in
+AGPRs; 6: two waves per SIMD, everything in VGPRs).  The fixed-maximum forms have a rare path - a partial row sum that leaves the safe range sends the tile
 (form 1) or the block (form 5) through the exact computation - which a test has to FORCE (cdna_hip_programming.md rule 26): one late key
 hundreds of nats above everything before it."""
 import numpy as np
@@ -27,6 +27,15 @@ def eng():
 
 
 @pytest.fixture(scope="module")
+def eng16():
+    from sonicscribe_amd.engine import Engine, MODE_F16
+    e = Engine(spec.TINY, 0, MODE_F16, max_batch=4, max_ctx=256)
+    e.load_synthetic(20260128)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
 def orc():
     from oracle import oracle
     return oracle
@@ -43,7 +52,7 @@ def ref_attention(orc, q, k, v):
     return ref
 
 
-FORMS = [1, 3, 5]
+FORMS = [1, 3, 5, 6]
 
 
 @pytest.mark.parametrize("form", FORMS)
@@ -87,12 +96,33 @@ def test_forms_agree_and_the_exact_form_matches_rounds_1_to_4(eng):
     B, T, H, hd = 2, 1500, 2, 64
     q = bf(rng.standard_normal((B, T, H, hd))); k = bf(rng.standard_normal((B, T, H, hd))); v = bf(rng.standard_normal((B, T, H, hd)))
     outs = {}
-    for form in (0, 1, 3, 5):
+    for form in (0, 1, 3, 5, 6):
         eng.set_option("flash_enc", form)
         outs[form] = eng.test_attention(q, k, v, False)
     assert np.mean(outs[3] != outs[0]) < 1e-3 and np.abs(outs[3] - outs[0]).max() <= 2.0 ** -6
-    for form in (1, 5):
+    for form in (1, 5, 6):
         d = np.abs(outs[form] - outs[0])
         assert d.max() <= 2.0 ** -5 and d.mean() < 1e-3, (form, float(d.max()), float(d.mean()))
     eng.set_option("flash_enc", 1)
     assert np.array_equal(outs[1], eng.test_attention(q, k, v, False))          # deterministic
+
+
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("scale", [8.0, 40.0])
+def test_fp16_probabilities_do_not_overflow(eng16, form, scale):
+    """The fp16 instantiation (int8 mode runs it: asr.py:61,296): a probability relative to the FIRST tile's maximum overflows fp16 at 65504, i.e.
+    when a later score is ~11 nats above it - far inside what fp32 / bf16 tolerate.  The safe range of the fixed-maximum path is therefore per
+    element type; found by tests/test_gpu_int8.py (NaN logits with LayerNorm weights x 3.5) before this test existed."""
+    rng = np.random.default_rng(4)
+    B, T, H, hd = 1, 400, 2, 64
+    q = rng.standard_normal((B, T, H, hd)).astype(np.float32) * 0.3; k = rng.standard_normal((B, T, H, hd)).astype(np.float32) * 0.3
+    v = rng.standard_normal((B, T, H, hd)).astype(np.float32)
+    q, k, v = (x.astype(np.float16).astype(np.float32) for x in (q, k, v))
+    k[0, 333, 1] = (q[0, 10, 1] * scale).astype(np.float16).astype(np.float32)
+    eng16.set_option("flash_enc", form)
+    got = eng16.test_attention(q, k, v, False)
+    eng16.set_option("flash_enc", 1)
+    s = np.einsum("bqhd,bkhd->bhqk", q.astype(np.float64), k.astype(np.float64)) / 8.0
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bkhd->bqhd", p, v.astype(np.float64))
+    assert np.isfinite(got).all() and np.abs(got - ref).max() <= 0.01, (form, scale, float(np.abs(got - ref).max()))

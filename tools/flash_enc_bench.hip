@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         timeit("new: flash_enc mode 0 (fixed max, joint P.V)", [&] { launch_flash_enc(f2, B, T, 0, 0); });
         timeit("new: flash_enc mode 2 (exact every tile, joint)", [&] { launch_flash_enc(f2, B, T, 2, 0); });
-        timeit("new: flash_encp mode 4 (pipelined, asm groups, 1 wave/SIMD)", [&] { launch_flash_enc(f2, B, T, 4, 0); });
+        timeit("new: flash_encp mode 4 (pipelined, asm groups, 1 wave/SIMD, AGPR)", [&] { launch_flash_enc(f2, B, T, 4, 0); });
+        timeit("new: flash_encp mode 5 (pipelined, asm groups, 2 waves/SIMD, VGPR)", [&] { launch_flash_enc(f2, B, T, 5, 0); });
         timeit("old again", [&] { launch_flash(f, 64, false, B, T, 0); });
     }
     // ---- in-kernel clocks: shader cycles and wall time per block, modes 0 and 4
@@ -60,7 +61,7 @@ int main(int argc, char** argv) {
         const size_t nblk = (size_t)((T + 255) / 256) * H * B;
         long long* dbg; hipMalloc(&dbg, nblk * 32);
         std::vector<long long> hd(nblk * 4);
-        for (int mode : {0, 4}) {
+        for (int mode : {0, 4, 5}) {
             FlashArgs fd = f2; fd.dbg = dbg;
             for (int w = 0; w < 20; ++w) launch_flash_enc(fd, B, T, mode, 0);
             hipDeviceSynchronize();
@@ -136,7 +137,7 @@ int main(int argc, char** argv) {
         double e = 0; for (int d = 0; d < HD; ++d) e = std::fmax(e, std::fabs((double)bf2f_h(got[idx + d]) - refs[0][(size_t)fquery * HD + d]));
         printf("      forced row (query %d): max |err| vs fp64 %.6f\n", fquery, e);
     };
-    for (int mode : {0, 2, 4}) {
+    for (int mode : {0, 2, 4, 5}) {
         hipMemset(o2, 0xFF, nq * 2);
         launch_flash_enc(f2, B, T, mode, 0); hipDeviceSynchronize();
         hipMemcpy(hb.data(), o2, nq * 2, hipMemcpyDeviceToHost);
