@@ -708,7 +708,7 @@ def main():
                          "bytes_per_launch": w_bytes + kv_bytes, "avg_launch_ms": dec_ms, "launches_timed": n_dec * a.steps,
                          "algorithmic_bytes": {"weights": w_bytes, "kv_cache_avg": kv_bytes}},
         }
-        for prof in ("round4_pmc_decode.json", "round3_pmc_decode.json", "round2_pmc_decode.json"):     # newest committed PMC passes; labelled with their own commit
+        for prof in ("round5_pmc_decode.json", "round4_pmc_decode.json", "round3_pmc_decode.json", "round2_pmc_decode.json"):     # newest committed PMC passes; labelled with their own commit
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     pm = json.load(f)
