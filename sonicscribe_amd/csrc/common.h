@@ -59,6 +59,8 @@ struct LaunchOpts {
     int gemm_force128 = 0;     // route every GEMM to the 128x128 kernel
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
     int no_fused_gu64 = 0;     // ... only for batches of 33 .. 64 rows (round 3's path there; A/B)
+    int ktrace_wave = 0;       // in-kernel timeline of skinny_gu64_kernel: which wave stamps the inner points
+    int gu64_two_pass = 0;     // fused gate/up at 33 .. 64 rows: round 4's two passes of 32 rows instead of skinny_gu64_kernel (A/B)
     int no_skinny768 = 0;      // decode skinny GEMM: never the 768-deep K slices (A/B)
     int gemm_small_eff = 75;   // 256x256 grids that under-fill the chip go to the 128x128 kernel, priced at this % of the big kernel's rate (0: never)
     int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)
@@ -198,9 +200,17 @@ struct SkinnyArgs {
                                      // producer's blocks) of their absmax without the elements >= 6.0: the kernel quantises its X slice while
                                      // staging it - int8 = rn(x * 127 / absmax), 0 for outliers (LLM.int8 row-wise)
     long long* kt;                   // diagnostics: per-block timestamps [block][8] (100 MHz wall clock), null in production
+    int kt_thread;                   // ... the thread that stamps the inner points of skinny_gu64_kernel (0, 64 .. 448: one wave's view each; option ktrace_wave)
 };
 // in-kernel timeline point `slot` of this block (thread 0 only); a null pointer costs one scalar compare
-#define KT(a, slot) do { if ((a).kt && threadIdx.x == 0) (a).kt[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+// (the pointer is laundered through an SGPR so that the address arithmetic stays inside the branch: hoisted, it cost the 256-register kernels a spill)
+// and the index is 32-bit scalar arithmetic - the 64-bit form went through v_mad_u64_u32 on a spilled operand, i.e. a scratch reload + vmcnt(0) at every point)
+#define KT(a, slot) do { if ((a).kt && threadIdx.x == 0) { long long* kt_p_ = (a).kt; asm volatile("" : "+s"(kt_p_)); \
+        const unsigned kt_i_ = __builtin_amdgcn_readfirstlane((blockIdx.y * gridDim.x + blockIdx.x) * 8u + (unsigned)(slot)); \
+        kt_p_[kt_i_] = wall_clock64(); } } while (0)
+#define KTW(a, slot) do { if ((a).kt && threadIdx.x == (unsigned)(a).kt_thread) { long long* kt_p_ = (a).kt; asm volatile("" : "+s"(kt_p_)); \
+        const unsigned kt_i_ = __builtin_amdgcn_readfirstlane((blockIdx.y * gridDim.x + blockIdx.x) * 8u + (unsigned)(slot)); \
+        kt_p_[kt_i_] = wall_clock64(); } } while (0)
 
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);

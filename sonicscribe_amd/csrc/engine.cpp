@@ -718,7 +718,7 @@ extern "C" int sonic_device_info(int device_id, char* name, int name_cap, int64_
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { (void)hipGetLastError(); return fail(nullptr, SONIC_ERR_INVALID, "device %d not available", device_id); }
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, device_id) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, SONIC_ERR_HIP, "hipGetDeviceProperties failed"); }
-    if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s", pr.name); }
+    if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s", pr.name[0] ? pr.name : pr.gcnArchName); }   // (some boxes of the pool report an empty marketing name)
     if (total_bytes) *total_bytes = (int64_t)pr.totalGlobalMem;
     if (free_bytes) {
         size_t fr = 0, tot = 0; int cur = 0;
@@ -2469,6 +2469,8 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm_force128")) { e->opts.gemm_force128 = value; return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu64")) { e->opts.no_fused_gu64 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "gu64_two_pass")) { e->opts.gu64_two_pass = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "ktrace_wave")) { e->opts.ktrace_wave = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "i8_no_lnq")) { e->opt_i8_no_lnq = value; return SONIC_OK; }      // int8 encoder: LayerNorm does not quantise its rows (A/B)
     if (!strcmp(key, "i8_no_qkv_fuse")) { e->opt_i8_no_qkv_fuse = value; return SONIC_OK; }   // int8 encoder: RoPE and V^T as their own passes (A/B)

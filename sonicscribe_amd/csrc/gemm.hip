@@ -565,7 +565,7 @@ struct GuNorm { const float* SS; int nblk; const float* w; float eps; };   // SS
 // (Round 3's form walked 768 outputs with 16 scalar LDS reads and a 2-byte store each: 3.8 us of an 11.2 us kernel.)
 template <typename T, int MB, int TPB>
 __device__ __forceinline__ void gu_reduce_store(const f32x4* red, int wk, int lane, T* act, int ff, int col0, int row0, int m_valid) {
-    if (wk < TPB * MB) {
+    if (wk < TPB * MB) {                             // wk = task: (tile j, 16-row block mb)
         const int j = wk / MB, mb = wk % MB;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -605,17 +605,28 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
     KT(a, 0);
     f32x4 ssv[SSN];
     f32x4 nw[NORM ? KBW * 2 : 1];
+    f32x4 nwraw;
+    // NORM: scratch behind the X image / the reduction buffer - the 32 row scales (256 B) and 1 KiB of norm weights per wave.  As in skinny_gu64_kernel
+    // (see there: the CU's vector-memory path is what bounds these kernels), wave 0 alone fetches the sum-of-squares partials and leaves the row scales
+    // in LDS behind a sentinel, and a wave fetches its norm weights with one load.  Round 4: 16 + 8 loads per wave for them, now 2 + 1 on average.
+    constexpr int SCR = (KS8 * 4 * MB * 2048 > 8 * TPB * MB * 1024) ? KS8 * 4 * MB * 2048 : 8 * TPB * MB * 1024;
+    constexpr unsigned SENT = 0xFFFFFFFFu;
+    const unsigned sclds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + SCR, nwlds = sclds + 256 + wk * 1024;
     if (NORM) {
-        // sum-of-squares partials first: vmcnt retires in order, so they can be consumed while X / W are still in flight.
-        // (asm loads + explicit counted waits: with LDS-DMA and plain loads both in flight the compiler's waitcnt pass falls back
-        //  to vmcnt(0) at the first use, which would serialise the W fetch behind this pass)
-        // SS is [block / 4][32 rows][4]: one load instruction covers 32 rows x 16 B contiguous per lane half (8 cache lines, like a W
-        // load); a row-major [row][block] layout would touch 64 lines per instruction and cost as much pipe time as the W fetch.
-        const int rl = lane & 31;
-        const float* sp = nm.SS + ((long)(lane >> 5) * SSN * 32 + rl) * 4;
+        if (wk == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + lane * 4), "v"(SENT) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wk == 0) {
+            // sum-of-squares partials first: vmcnt retires in order, so they can be consumed while X / W are still in flight.
+            // (asm loads + explicit counted waits: with LDS-DMA and plain loads both in flight the compiler's waitcnt pass falls back
+            //  to vmcnt(0) at the first use, which would serialise the W fetch behind this pass)
+            // SS is [block / 4][32 rows][4]: one load instruction covers 32 rows x 16 B contiguous per lane half (8 cache lines, like a W
+            // load); a row-major [row][block] layout would touch 64 lines per instruction and cost as much pipe time as the W fetch.
+            const int rl = lane & 31;
+            const float* sp = nm.SS + ((long)(lane >> 5) * SSN * 32 + rl) * 4;
 #pragma unroll
-        for (int i = 0; i < SSN; ++i)
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ssv[i]) : "v"(sp + (i / 8) * 8 * 128), "n"((i % 8) * 512) : "memory");
+            for (int i = 0; i < SSN; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ssv[i]) : "v"(sp + (i / 8) * 8 * 128), "n"((i % 8) * 512) : "memory");
+        }
     }
 #pragma unroll
     for (int t = 0; t < PW; ++t) {                                   // X (NORM: the raw residual) -> LDS by DMA, lane-linear pieces
@@ -625,14 +636,8 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
     }
-    if (NORM) {
-#pragma unroll
-        for (int kb = 0; kb < KBW; ++kb) {
-            const int k0 = ((wk * PW) / RG + kb) * 64 + lc * 8;
-            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
-                         : "=&v"(nw[kb * 2]), "=&v"(nw[kb * 2 + 1]) : "v"(nm.w + k0) : "memory");
-        }
-    }
+    // this wave's norm weights: the 64 * KBW floats of its K blocks (KS8 = 1: half a K block per wave, the pair of waves fetches the same 64)
+    if (NORM) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nwraw) : "v"(nm.w + (((wk * PW) / RG) * 64 + (lane & (16 * KBW - 1)) * 4)) : "memory");
     constexpr int WPRE = NORM ? WTOT / 2 : WTOT, WREM = WTOT - WPRE;
     V8 wf[WTOT];                                                     // [tile j][k-step u] of this wave's K eighth
     const T* wp = aW + ((long)blockIdx.x * TPB * (K >> 5) + wk * KS8) * 512 + lane * 8;
@@ -642,26 +647,39 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
 #define GU_WLOAD(f) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[f]) : "v"(GU_WBASE(f)), "n"((((f) % KS8) % 4) * 1024) : "memory")
 #pragma unroll
     for (int f = 0; f < WPRE; ++f) GU_WLOAD(f);
-    KT(a, 1);
-    if (NORM) {
-        // Every lane rewrites exactly the 16 bytes its own DMA deposited, so only this wave's vmcnt orders it - no barrier.
-        __builtin_amdgcn_sched_barrier(0);            // keep all loads above in flight (the scheduler would sink W below the rewrite)
-        // All LDS traffic of this pass is inline asm: the compiler's waitcnt pass treats a DS instruction behind an outstanding
-        // LDS-DMA as aliasing it and inserts vmcnt(0), which would also wait for W.
+    if (NORM && wk == 0) {
+        // (behind the wave's other up-front requests: the partials are the oldest, they land while those go out)
+        __builtin_amdgcn_sched_barrier(0);
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < SSN; ++i) {
-            if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + 2 * KBW + WPRE) : "memory");   // partials landed
+            if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + 1 + WPRE) : "memory");         // partials landed
             asm volatile("" : "+v"(ssv[i]));                                                         // (uses stay below the wait)
             t += ssv[i][0]; t += ssv[i][1]; t += ssv[i][2]; t += ssv[i][3];
         }
         float t2;
         asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t2) : "v"((lane ^ 32) << 2), "v"(t) : "memory");
         t = t + t2;
-        const float rl_scale = 1.0f / sqrtf(t / (float)K + nm.eps);      // lane l holds the scale of row l & 31
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KBW + WPRE) : "memory");   // X pieces landed; norm weight + W still in flight
+        const float sc = 1.0f / sqrtf(t / (float)K + nm.eps);            // lanes l and l + 32: the scale of row l
+        asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + (lane & 31) * 4), "v"(sc) : "memory");
+    }
+    KT(a, 1);
+    if (NORM) {
+        // Every lane rewrites exactly the 16 bytes its own DMA deposited, so only this wave's vmcnt orders it - no barrier.
+        __builtin_amdgcn_sched_barrier(0);            // keep all loads above in flight (the scheduler would sink W below the rewrite)
+        // All LDS traffic of this pass is inline asm: the compiler's waitcnt pass treats a DS instruction behind an outstanding
+        // LDS-DMA as aliasing it and inserts vmcnt(0), which would also wait for W.
         const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (wk * PW) * 1024 + lane * 16;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPRE) : "memory");             // norm weight landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPRE) : "memory");             // X pieces and the norm weights landed; W still in flight
+        asm volatile("" : "+v"(nwraw));
+        asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(nwlds + lane * 16), "v"(nwraw) : "memory");
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb)               // weights of K block kb of this wave, chunk lc: the 8 of this lane's piece column
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(nw[kb * 2]), "=&v"(nw[kb * 2 + 1]) : "v"(nwlds + (kb * 64 + lc * 8) * 4) : "memory");
+        {   // the row scales are there when no lane sees the sentinel (wave 0 wrote them ~1 us after entry)
+            unsigned sv;
+            do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + (lane & 31) * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0);
+        }
 #pragma unroll
         for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));
 #pragma unroll
@@ -669,8 +687,8 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
             const int ii = wk * PW + tt, rg = ii % RG, kb = tt / RG;
             int row = rg * 8 + lr; row = row < a.M ? row : a.M - 1;
             float rr; V8 xv;
-            asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_read_b128 %1, %4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(rr), "=&v"(xv) : "v"(row << 2), "v"(rl_scale), "v"(lbase + tt * 1024) : "memory");
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(rr), "=&v"(xv) : "v"(sclds + row * 4), "v"(lbase + tt * 1024) : "memory");
             const f32x4 w0 = nw[kb * 2], w1 = nw[kb * 2 + 1];
             V8 o;
 #pragma unroll
@@ -825,6 +843,203 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
     }
 }
 
+// skinny_gu64_kernel: the same op for 33 .. 64 rows in ONE sweep (round 5; round 4's two-pass form is skinny_gu_kernel<.., NP = 2>, kept behind
+// sonic_set_option("gu64_two_pass", 1) for the A/B).  The two-pass kernel re-staged rows 32 .. 63 after pass one had finished with LDS: DMA round
+// trip + 2.2 us of RMSNorm VALU work + MFMA + a second reduction, 6.4 us in series behind an 10.8 us pass one (profiles/round5_decode_timeline_b64.txt).
+// Here the 64 rows go through LDS as FOUR passes of 16 rows over two 64 KiB buffers, and everything a wave does to them depends only on its own
+// loads (it stages, normalises and reads the X pieces of its own K eighth - no block barrier before the reduction):
+//   pass 0 -> buffer 0, pass 1 -> buffer 1 (up front, beside the partial sums, the norm weights and the first half of W);
+//   normalise pass 0, read its fragments into registers, DMA pass 2 into buffer 0;  the same for pass 1 / pass 3 / buffer 1 -
+//   so rows 32 .. 63 are staged and normalised WHILE W is still streaming in (W requests are interleaved so that the pass-2 / pass-3 DMA is not
+//   behind the last W requests in vmcnt order);  MFMAs of passes 0 / 1 per tile as it lands, then fragments of passes 2 / 3 and their MFMAs;
+//   ONE reduction over [8 waves][TPB tiles][4 row blocks] (96 KiB, in the dead buffers).
+// Per row the arithmetic is the one-pass kernel's: same MFMA sequence over k, same reduction order, same RMSNorm roundings - a request's bits do
+// not depend on the batch size (tests/test_gpu_parity.py::test_fused_decode_rows_vs_unfused, tests/test_gpu_slots.py).
+template <typename T, int KS8, int TPB, bool NORM>
+__global__ __launch_bounds__(512) void skinny_gu64_kernel(SkinnyArgs a, T* act, int ff, GuNorm nm) {
+    typedef typename ET<T>::v8 V8;
+    static_assert(KS8 >= 2 && KS8 % 2 == 0, "a wave's K eighth must be whole 64-wide K blocks");
+    const T* aX = (const T*)a.X; const T* aW = (const T*)a.W;
+    constexpr int K = KS8 * 256, NKB = K / 64, PW = KS8, KBW = KS8 / 2, BUF = NKB * 2048, WTOT = TPB * KS8;
+    constexpr int SSN = KS8 * 2;                                    // f32x4 of sum-of-squares partials per lane and 32-row region (as in skinny_gu_kernel)
+    // W request schedule (NORM): WPRE up front, WN0 / WN1 between the pieces of normalise passes 0 / 1, WL after the pass-3 DMA
+    constexpr int WPRE = NORM ? WTOT / 2 : WTOT, WN0 = (WTOT - WPRE) / 3, WN1 = WN0, WL = WTOT - WPRE - WN0 - WN1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;   // wave = K eighth
+    const int r = lane & 15, g = lane >> 4, lr = lane >> 3, lc = (lane & 7) ^ lr;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int mlast = a.M - 1;
+    KT(a, 0);
+    // What bounds this kernel is the CU's vector-memory path: ~15 ns per wave-wide 16-byte load, whatever it hits (measured with the in-kernel timeline: wave 7
+    // got its prologue requests out 4.4 us after wave 0).  Round 4's form had every wave fetch all sum-of-squares partials (2 x 16 KiB) and its 1 KiB of
+    // norm weights as eight 8-fold redundant loads: 256 + 64 of the 768 KiB a block pulled.  Now wave 0 alone fetches the partials, adds them in the
+    // order of skinny_gu_kernel (same bits) and leaves the 64 row scales in LDS; the other waves find them there (a sentinel cleared behind a barrier at
+    // entry marks "not yet": no barrier in the middle of the request stream, which would hold every wave until the last one has issued its prologue);
+    // and a wave fetches its norm weights with ONE load and re-reads them in the piece layout through 1 KiB of LDS.
+    constexpr int SCR = 2 * BUF > 8 * TPB * 4 * 1024 ? 2 * BUF : 8 * TPB * 4 * 1024;      // scratch behind the buffers / the reduction: 64 scales, 8 x 1 KiB of norm weights
+    constexpr unsigned SENT = 0xFFFFFFFFu;
+    const unsigned sclds = lds0 + SCR, nwlds = lds0 + SCR + 256 + wk * 1024;
+    f32x4 nw[NORM ? KBW * 2 : 1];
+    f32x4 nwraw;
+    f32x4 ssv[NORM ? SSN : 1], ssw[NORM ? SSN : 1];    // (wave 0)
+    if (NORM) {
+        if (wk == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + lane * 4), "v"(SENT) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wk == 0) {
+            // partials of region r (rows 32 r ..): lane half h adds groups 16 h .. 16 h + 15 in ascending order, then the halves are added
+            const float* ssp = nm.SS + ((long)(lane >> 5) * SSN * 32 + (lane & 31)) * 4;
+#pragma unroll
+            for (int i = 0; i < SSN; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ssv[i]) : "v"(ssp + (i / 8) * 8 * 128), "n"((i % 8) * 512) : "memory");
+#pragma unroll
+            for (int i = 0; i < SSN; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ssw[i]) : "v"(ssp + (long)(K / 64) * 128 + (i / 8) * 8 * 128), "n"((i % 8) * 512) : "memory");
+        }
+    }
+    // pass p (rows 16 p ..) of this wave's K eighth -> buffer p & 1, lane-linear 1 KiB pieces [K block][8-row group], chunk ^= row & 7 on the source
+#define GU64_STAGE(p) do { const T* xs = aX; asm volatile("" : "+s"(xs));   /* (addresses are computed here, not hoisted into the prologue) */ \
+        _Pragma("unroll") for (int t = 0; t < PW; ++t) { \
+        const int ii = wk * PW + t, kblock = ii >> 1, rg = ii & 1; \
+        int row = (p) * 16 + rg * 8 + lr; row = row < mlast ? row : mlast; \
+        const T* src = xs + (long)row * a.ldx + kblock * 64 + lc * 8; \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, \
+                                         (__attribute__((address_space(3))) void*)(smem + ((p) & 1) * BUF + ii * 1024), 16, 0, 0); } } while (0)
+    GU64_STAGE(0);
+    GU64_STAGE(1);
+    if (NORM) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nwraw) : "v"(nm.w + (wk * KBW * 64 + lane * 4)) : "memory");    // this wave's 256 norm weights
+    V8 wf[WTOT];                                                     // [tile j][k-step u] of this wave's K eighth
+    const T* wp = aW + ((long)blockIdx.x * TPB * (K >> 5) + wk * KS8) * 512 + lane * 8;
+#define GU_WBASE(f) (wp + ((long)((f) / KS8) * (K >> 5) + (((f) % KS8) / 4) * 4) * 512)
+#define GU_WLOAD(f) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(wf[f]) : "v"(GU_WBASE(f)), "n"((((f) % KS8) % 4) * 1024) : "memory")
+#pragma unroll
+    for (int f = 0; f < WPRE; ++f) GU_WLOAD(f);
+    if (NORM && wk == 0) {                             // (behind its other up-front requests: the partials are the oldest, they land while those go out)
+        {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW + 1 + WPRE) : "memory");
+            float sc[2];
+#define GU64_SS_SUM(reg, sv) do { float t = 0.f; \
+            _Pragma("unroll") for (int i = 0; i < SSN; ++i) { asm volatile("" : "+v"(sv[i])); t += sv[i][0]; t += sv[i][1]; t += sv[i][2]; t += sv[i][3]; } \
+            float t2; \
+            asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t2) : "v"((lane ^ 32) << 2), "v"(t) : "memory"); \
+            t = t + t2; \
+            sc[reg] = 1.0f / sqrtf(t / (float)K + nm.eps); } while (0)           /* lane l: the scale of row 32 reg + (l & 31) */
+            GU64_SS_SUM(0, ssv);
+            GU64_SS_SUM(1, ssw);
+#undef GU64_SS_SUM
+            asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + lane * 4), "v"(lane < 32 ? sc[0] : sc[1]) : "memory");   // scale of row `lane`
+        }
+    }
+    KTW(a, 1);
+    __builtin_amdgcn_sched_barrier(0);                // keep every load above in flight ahead of the VALU work
+    // one 16-row pass normalised in place: every lane rewrites exactly the 16 bytes its own DMA deposited (only this wave's vmcnt orders it);
+    // hn = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) (modeling_llama.py:60-65); W requests f0 .. f0 + nf - 1 go out between the pieces
+#define GU64_NORM(p, f0, nf) do { _Pragma("unroll") for (int tt = 0; tt < PW; ++tt) { \
+        const int rg = tt & 1, kb = tt >> 1; \
+        int row = (p) * 16 + rg * 8 + lr; row = row < mlast ? row : mlast; \
+        const unsigned pa = lds0 + ((p) & 1) * BUF + (wk * PW + tt) * 1024 + lane * 16; \
+        float rr; V8 xv; \
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" \
+                     : "=&v"(rr), "=&v"(xv) : "v"(sclds + row * 4), "v"(pa) : "memory"); \
+        const f32x4 w0 = nw[kb * 2], w1 = nw[kb * 2 + 1]; \
+        V8 o; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { o[j] = (T)(w0[j] * rT<T>((float)xv[j] * rr)); o[4 + j] = (T)(w1[j] * rT<T>((float)xv[4 + j] * rr)); } \
+        asm volatile("ds_write_b128 %0, %1" ::"v"(pa), "v"(o) : "memory"); \
+        _Pragma("unroll") for (int f = (f0) + tt * (nf) / PW; f < (f0) + (tt + 1) * (nf) / PW; ++f) GU_WLOAD(f); \
+        __builtin_amdgcn_sched_barrier(0); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+    // fragments of one pass: B operand rows = the pass's 16 rows, k = this wave's KS8 steps of 32
+#define GU64_FRAGS(p, xf) do { _Pragma("unroll") for (int u = 0; u < KS8; ++u) { \
+        const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1; \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[u]) : "v"(lds0 + ((p) & 1) * BUF + kblock * 2048 + r * 128 + (((half * 4 + g) ^ (r & 7)) << 4)) : "memory"); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        _Pragma("unroll") for (int u = 0; u < KS8; ++u) asm volatile("" : "+v"(xf[u])); } while (0)
+    V8 xa[KS8], xb[KS8];                               // passes 0 / 1, later 2 / 3
+    if (NORM) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPRE) : "memory");                        // passes 0 / 1 and the norm weights landed; W in flight
+        asm volatile("" : "+v"(nwraw));
+        asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(nwlds + lane * 16), "v"(nwraw) : "memory");
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb)               // weights of K block kb, chunk lc: the 8 of this lane's piece column
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(nw[kb * 2]), "=&v"(nw[kb * 2 + 1]) : "v"(nwlds + kb * 256 + lc * 32) : "memory");
+        {   // the row scales are there when no lane sees the sentinel (wave 0 wrote them ~1 us after entry)
+            unsigned sv;
+            do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + lane * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0);
+        }
+#pragma unroll
+        for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));
+        GU64_NORM(0, WPRE, WN0);
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPRE) : "memory");                        // passes 0 / 1 landed
+    }
+    GU64_FRAGS(0, xa);
+    GU64_STAGE(2);
+    if (NORM) GU64_NORM(1, WPRE + WN0, WN1);
+    GU64_FRAGS(1, xb);
+    GU64_STAGE(3);
+#pragma unroll
+    for (int f = WTOT - WL; f < WTOT; ++f) GU_WLOAD(f);
+    KTW(a, 2);
+    // in flight now, in vmcnt order: W[0, WPRE + WN0) | pass 2 (PW) | W[.., + WN1) | pass 3 (PW) | W last WL   (NORM = false: all of W | pass 2 | pass 3)
+    f32x4 acc[TPB][4];
+#pragma unroll
+    for (int j = 0; j < TPB; ++j) { acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // MFMAs of passes 0 / 1 for tiles [j0, j1): requests after tile j1 - 1's last fragment may still be in flight
+#define GU64_MMA01(j0, j1) do { _Pragma("unroll") for (int jj = (j0); jj < (j1); ++jj) { \
+        _Pragma("unroll") for (int u = 0; u < KS8; ++u) asm volatile("" : "+v"(wf[jj * KS8 + u])); \
+        _Pragma("unroll") for (int u = 0; u < KS8; ++u) { \
+            acc[jj][0] = ET<T>::mfma(wf[jj * KS8 + u], xa[u], acc[jj][0]); acc[jj][1] = ET<T>::mfma(wf[jj * KS8 + u], xb[u], acc[jj][1]); } } \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    constexpr int JE = NORM ? (WPRE + WN0) / KS8 : 0;                // tiles whose fragments were all requested before pass 2
+    if (NORM) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN1 + PW + WL) : "memory");               // pass 2 landed (and tiles < JE)
+        GU64_MMA01(0, JE);
+        GU64_NORM(2, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WL) : "memory");                          // pass 3 landed
+        GU64_NORM(3, 0, 0);
+        KTW(a, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KTW(a, 4);
+        GU64_MMA01(JE, TPB);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TPB; ++j) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TPB - 1 - j) * KS8 + 2 * PW) : "memory");
+            GU64_MMA01(j, j + 1);
+        }
+        KTW(a, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KTW(a, 4);
+    }
+    GU64_FRAGS(2, xa);
+    GU64_FRAGS(3, xb);
+#pragma unroll
+    for (int j = 0; j < TPB; ++j) {
+        acc[j][2] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[j][3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KS8; ++u) {
+            acc[j][2] = ET<T>::mfma(wf[j * KS8 + u], xa[u], acc[j][2]); acc[j][3] = ET<T>::mfma(wf[j * KS8 + u], xb[u], acc[j][3]);
+        }
+    }
+#undef GU64_MMA01
+#undef GU64_FRAGS
+#undef GU64_NORM
+#undef GU64_STAGE
+#undef GU_WLOAD
+#undef GU_WBASE
+    KTW(a, 5);
+    __syncthreads();
+    f32x4* red = (f32x4*)smem;   // [wk 8][tile TPB][4 row blocks][64]
+#pragma unroll
+    for (int j = 0; j < TPB; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) red[((wk * TPB + j) * 4 + mb) * 64 + lane] = acc[j][mb];
+    __syncthreads();
+    constexpr int NC = 8 * TPB;
+#pragma unroll
+    for (int task = 0; task < TPB * 4; task += 8) gu_reduce_store<T, 4, TPB>(red, task + wk, lane, act, ff, blockIdx.x * NC, 0, a.M);
+    KT(a, 6);
+}
+
 // skinny_o_kernel: decode-step o_proj with the residual add fused (modeling_llama.py:306-309).  Like skinny_gu_kernel the block sees the
 // whole K (X = attention output, one 16-row group per blockIdx.y, resident in LDS), owns one 16-column tile, sums the 8 K eighths
 // through LDS and then writes x = bf16(x + bf16(acc)) in place.  It also emits, per block, the partial sum of squares of its 16
@@ -906,10 +1121,19 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, T* x, int l
 template <int MB, int KS8, int TPB, bool NORM, int NP = 1> static void launch_gu_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
     const size_t lds = (size_t)(KS8 * 4) * MB * 2048;               // X image
     const size_t redb = (size_t)8 * TPB * MB * 1024;
-    const size_t need = lds > redb ? lds : redb;
+    const size_t need = (lds > redb ? lds : redb) + (NORM ? 256 + 8192 : 0);    // + the row scales and the waves' norm weights
     DT_SWITCH(a.dt, T, {
         if (need > 65536) ensure_dyn_lds((const void*)skinny_gu_kernel<T, MB, KS8, TPB, NORM, NP>, (int)need);
         hipLaunchKernelGGL((skinny_gu_kernel<T, MB, KS8, TPB, NORM, NP>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a, (T*)act, a.N / 2, nm);
+    });
+}
+template <int KS8, int TPB, bool NORM> static void launch_gu64_v(const SkinnyArgs& a, bf16_t* act, const GuNorm& nm, hipStream_t s) {
+    const size_t bufs = (size_t)2 * (KS8 * 4) * 2048, redb = (size_t)8 * TPB * 4 * 1024;          // two 16-row X buffers / the reduction over 64 rows
+    const size_t need = (bufs > redb ? bufs : redb) + (NORM ? 256 + 8192 : 0);                    // + the row scales and the waves' norm weights
+    DT_SWITCH(a.dt, T, {
+        if (need > 65536) ensure_dyn_lds((const void*)skinny_gu64_kernel<T, KS8, TPB, NORM>, (int)need);
+        SkinnyArgs a2 = a; a2.kt_thread = (g_opts.ktrace_wave & 7) * 64;
+        hipLaunchKernelGGL((skinny_gu64_kernel<T, KS8, TPB, NORM>), dim3(a.N / (16 * TPB)), dim3(512), need, s, a2, (T*)act, a.N / 2, nm);
     });
 }
 // true if the fused kernel handles this shape (else: skinny GEMM + swiglu_slab_kernel)
@@ -924,7 +1148,8 @@ template <bool NORM> static void launch_gu_any(const SkinnyArgs& a, bf16_t* act,
     const bool t3 = (a.N / 16) % 3 == 0;                             // 3 tiles per block where the tile count allows (768 tiles -> 256 blocks)
 #define GU(KS8) do { if (mb <= 1) { if (t3) launch_gu_v<1, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<1, KS8, 2, NORM>(a, act, nm, s); } \
                      else if (mb <= 2) { if (t3) launch_gu_v<2, KS8, 3, NORM>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM>(a, act, nm, s); } \
-                     else { if (t3) launch_gu_v<2, KS8, 3, NORM, 2>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM, 2>(a, act, nm, s); } } while (0)   /* 33 .. 64 rows: two passes of 32 */
+                     else if (KS8 >= 2 && !g_opts.gu64_two_pass) { if (t3) launch_gu64_v<(KS8 >= 2 ? KS8 : 2), 3, NORM>(a, act, nm, s); else launch_gu64_v<(KS8 >= 2 ? KS8 : 2), 2, NORM>(a, act, nm, s); } /* 33 .. 64 rows: one sweep */ \
+                     else { if (t3) launch_gu_v<2, KS8, 3, NORM, 2>(a, act, nm, s); else launch_gu_v<2, KS8, 2, NORM, 2>(a, act, nm, s); } } while (0)   /* ... as two passes of 32 (K = 256; A/B) */
     switch (a.K) { case 256: GU(1); break; case 512: GU(2); break; case 1024: GU(4); break; default: GU(8); break; }
 #undef GU
 }

@@ -184,8 +184,8 @@ def test_skinny(eng, M, N, K):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-3 * np.sqrt(K) * 0.1)
 
 
-@pytest.mark.parametrize("M,ff,K", [(32, 6144, 2048), (5, 4096, 256), (17, 4096, 512)])
-def test_skinny_fused_gate_up(eng, M, ff, K):
+@pytest.mark.parametrize("M,ff,K", [(32, 6144, 2048), (5, 4096, 256), (17, 4096, 512), (64, 6144, 2048), (41, 4096, 512), (33, 4096, 1024), (50, 4096, 256)])
+def test_skinny_fused_gate_up(eng, M, ff, K):      # 33 .. 64 rows: skinny_gu64_kernel (one sweep; K = 256: the two-pass form)
     rng = np.random.default_rng(ff + K + M)
     X = bf(rng.standard_normal((M, K))); Wg = bf(rng.standard_normal((ff, K)) * 0.05); Wu = bf(rng.standard_normal((ff, K)) * 0.05)
     Wi = np.empty((2 * ff, K), np.float32)
@@ -548,6 +548,14 @@ def test_fused_decode_rows_vs_unfused(R):
         ids_u, log_u = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
     finally:
         e.set_option("no_fused_gu", 0)
+    if R > 32:
+        # round 5: 33 .. 64 rows go through skinny_gu64_kernel (one sweep, four 16-row passes); round 4's two passes of 32 rows must give the same BITS
+        e.set_option("gu64_two_pass", 1)
+        try:
+            ids_2, log_2 = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
+        finally:
+            e.set_option("gu64_two_pass", 0)
+        assert all(np.array_equal(ids_f[i], ids_2[i]) for i in range(R)) and np.array_equal(log_f.view(np.uint32), log_2.view(np.uint32))
     same = 0
     for i in range(R):
         assert np.array_equal(ids_f[i], ids_g[i])

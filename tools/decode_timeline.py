@@ -25,7 +25,10 @@ names = ["qkv (skinny_xs)", "attention", "o_proj (skinny_o)", "gate/up (skinny_g
 points = {0: ["entry", "loads issued", "X in LDS", "last W multiplied", "synced", "slabs written"],
           1: ["entry", "prologue done (slab sum, RoPE, append)", "KV loop done", "merged in LDS", "O written"],
           2: ["entry", "loads issued", "all landed", "synced", "MFMA done", "end"],
-          3: ["entry", "first loads issued", "norm pass done, all W issued", "X + tile 0 landed (wave 0)", "X fragments read", "MFMA done (wave 0)", "end (rows 0-31 written)"] + (["second pass done (rows 32-63)"] if B > 32 else []),
+          3: (["entry", "up-front loads issued", "passes 0 / 1 normalised, passes 2 / 3 + all W requested", "passes 2 / 3 normalised (wave 0)", "all W landed (wave 0)",
+               "MFMA done (wave 0)", "end (64 rows written)"] if B > 32 and "gu64_two_pass=1" not in sys.argv[1:] else       # skinny_gu64_kernel (round 5)
+              ["entry", "first loads issued", "norm pass done, all W issued", "X + tile 0 landed (wave 0)", "X fragments read", "MFMA done (wave 0)", "end (rows 0-31 written)"]
+              + (["second pass done (rows 32-63)"] if B > 32 else [])),
           4: ["entry", "loads issued", "X in LDS", "last W multiplied", "synced", "slabs written"]}
 t_ref = None
 prev_end = None
