@@ -61,6 +61,8 @@ struct LaunchOpts {
     int no_fused_gu64 = 0;     // ... only for batches of 33 .. 64 rows (round 3's path there; A/B)
     int ktrace_wave = 0;       // in-kernel timeline of skinny_gu64_kernel: which wave stamps the inner points
     int gu64_two_pass = 0;     // fused gate/up at 33 .. 64 rows: round 4's two passes of 32 rows instead of skinny_gu64_kernel (A/B)
+    int o64_16rows = 0;        // fused o_proj at 33 .. 64 rows: 16-row blocks (round 4) instead of 32-row ones (A/B)
+    int no_skinny48 = 0;       // decode skinny GEMM: never the 48-row x 512 blocks (A/B)
     int no_skinny768 = 0;      // decode skinny GEMM: never the 768-deep K slices (A/B)
     int gemm_small_eff = 75;   // 256x256 grids that under-fill the chip go to the 128x128 kernel, priced at this % of the big kernel's rate (0: never)
     int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)

@@ -2472,6 +2472,8 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gu64_two_pass")) { e->opts.gu64_two_pass = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "ktrace_wave")) { e->opts.ktrace_wave = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "no_skinny48")) { e->opts.no_skinny48 = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "o64_16rows")) { e->opts.o64_16rows = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "i8_no_lnq")) { e->opt_i8_no_lnq = value; return SONIC_OK; }      // int8 encoder: LayerNorm does not quantise its rows (A/B)
     if (!strcmp(key, "i8_no_qkv_fuse")) { e->opt_i8_no_qkv_fuse = value; return SONIC_OK; }   // int8 encoder: RoPE and V^T as their own passes (A/B)
     if (!strcmp(key, "i8_dbg")) { e->opt_i8_dbg = value; drop_graphs(e); return SONIC_OK; }     // timing experiments (wrong results)

@@ -526,20 +526,22 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     __syncthreads();
     constexpr int BNR = WN * NT * 16, mpad = MB * 16;
     const int nb0 = blockIdx.x * BNR;
-    for (int o = tid; o < BNR * mpad; o += 512) {
-        const int m = o / BNR, nl = o % BNR, wn2 = nl >> 4, nloc = nl & 15, ln = (nloc >> 2) * 16 + (m & 15), j = nloc & 3;
-        const long dst = ((long)blockIdx.y * mpad + m) * a.N + nb0 + nl;
-        if constexpr (KD::I8) {
-            int s = 0;
+    // One (16-row tile, 16-row block of X) per wave-iteration: a lane adds the WK partials of its own accumulator position (whole fragments,
+    // ds_read_b128, ascending k from zero as before - same bits) and stores its four consecutive columns at once.  (Round 4 walked the outputs one
+    // by one: WK scalar LDS reads and a 4-byte store each, 4 - 8 store instructions per wave: 1.1 us of a 4.6 us kernel.)
+    for (int task = wid; task < WN * NT * MB; task += 8) {
+        const int wn2 = task / MB, mb = task % MB;
+        Acc sum;
 #pragma unroll
-            for (int k = 0; k < WK; ++k) s += red[((k * (WN * NT) + wn2) * MB + (m >> 4)) * 64 + ln][j];
-            ((int*)a.P)[dst] = s;                                    // exact int32 partial product; the consumer dequantises (int8_util.h)
-        } else {
-            float s = 0.f;
+        for (int e = 0; e < 4; ++e) sum[e] = 0;
 #pragma unroll
-            for (int k = 0; k < WK; ++k) s += red[((k * (WN * NT) + wn2) * MB + (m >> 4)) * 64 + ln][j];
-            a.P[dst] = s;
+        for (int k = 0; k < WK; ++k) {
+            const Acc v = red[((k * (WN * NT) + wn2) * MB + mb) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += v[e];
         }
+        // D[n][m]: lane (r, g) holds columns 4g .. 4g + 3 of X row r; int8: exact int32 partial products, the consumer dequantises (int8_util.h)
+        *(Acc*)((typename std::conditional<KD::I8, int, float>::type*)a.P + ((long)blockIdx.y * mpad + mb * 16 + r) * a.N + nb0 + wn2 * 16 + 4 * g) = sum;
     }
     KT(a, 5);
 }
@@ -1045,10 +1047,12 @@ __global__ __launch_bounds__(512) void skinny_gu64_kernel(SkinnyArgs a, T* act, 
 // through LDS and then writes x = bf16(x + bf16(acc)) in place.  It also emits, per block, the partial sum of squares of its 16
 // columns of every updated row (SS[block / 4][row][4], fixed summation order): the consumer (skinny_gu_kernel<NORM>) turns them into the
 // RMSNorm scale, so the separate add+RMSNorm kernel between o_proj and gate/up disappears.
-template <typename T, int KS8>
+template <typename T, int KS8, int MB = 1>
 __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, T* x, int ldxres, float* SS) {
+    // MB = 2 (33 .. 64 rows): a block takes 32 rows, so the grid stays at one block per CU (128 column tiles x 2) and the 16-column weight tile is
+    // fetched once per 32 rows - with 16-row blocks a CU ran two blocks, each with its own W fragments.  Per row the arithmetic is the same.
     typedef typename ET<T>::v8 V8;
-    constexpr int K = KS8 * 256, NKB = K / 64, RG = 2, NI = NKB * RG, KBS = 2048, mpad = 16;
+    constexpr int K = KS8 * 256, NKB = K / 64, RG = 2 * MB, NI = NKB * RG, KBS = MB * 2048, mpad = 16 * MB;
     static_assert(NI % 8 == 0, "X pieces must split over 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
@@ -1074,10 +1078,12 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, T* x, int l
                                              (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
         }
     }
-    // residual value this thread updates in the epilogue (threads 0..255: row tid / 16, column tid % 16), fetched up front
-    const int em = (tid >> 4) & 15, ec = tid & 15;
+    // residual value this thread updates in the epilogue (threads 0 .. 256 MB - 1: row tid / 16, column tid % 16), fetched up front
+    const int em = (tid >> 4) & (mpad - 1), ec = tid & 15;
     const T xres = x[(long)(em < M ? em : M - 1) * ldxres + blockIdx.x * 16 + ec];
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     KT(a, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     KT(a, 2);
@@ -1086,20 +1092,25 @@ __global__ __launch_bounds__(512) void skinny_o_kernel(SkinnyArgs a, T* x, int l
 #pragma unroll
     for (int u = 0; u < KS8; ++u) {
         const int kg = wk * KS8 + u, kblock = kg >> 1, half = kg & 1;
-        const V8 xf = *(const V8*)(smem + kblock * KBS + r * 128 + (((half * 4 + g) ^ (r & 7)) << 4));
-        acc = ET<T>::mfma(wf[u], xf, acc);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = mb * 16 + r;
+            const V8 xf = *(const V8*)(smem + kblock * KBS + m * 128 + (((half * 4 + g) ^ (m & 7)) << 4));
+            acc[mb] = ET<T>::mfma(wf[u], xf, acc[mb]);
+        }
     }
     KT(a, 4);
     __syncthreads();
-    f32x4* red = (f32x4*)smem;                       // [wk 8][64]
-    float* sq = (float*)(smem + 8 * 1024);           // [16 rows][16 cols] squares of the updated residual
-    red[wk * 64 + lane] = acc;
+    f32x4* red = (f32x4*)smem;                            // [wk 8][MB][64]
+    float* sq = (float*)(smem + 8 * MB * 1024);           // [16 MB rows][16 cols] squares of the updated residual
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) red[(wk * MB + mb) * 64 + lane] = acc[mb];
     __syncthreads();
-    if (tid < 256) {
-        const int ln = (ec >> 2) * 16 + em, j = ec & 3;
+    if (tid < 256 * MB) {
+        const int ln = (ec >> 2) * 16 + (em & 15), j = ec & 3, mb = em >> 4;
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += red[k * 64 + ln][j];
+        for (int k = 0; k < 8; ++k) v += red[(k * MB + mb) * 64 + ln][j];
         float xn = 0.f;
         if (em < M) {
             xn = rT<T>((float)xres + rT<T>(v));
@@ -1159,13 +1170,16 @@ void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s) { launch_
 void launch_skinny_gu_norm(const SkinnyArgs& a, bf16_t* act, const float* SS, int nblk, const float* w, float eps, hipStream_t s) {
     launch_gu_any<true>(a, act, GuNorm{SS, nblk, w, eps}, s);
 }
-template <int KS8> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
-    const size_t lds = (size_t)(KS8 * 4) * 2048;
-    const size_t need = lds > (size_t)(8 * 1024 + 1024) ? lds : (size_t)(8 * 1024 + 1024);
+template <int KS8, int MB> static void launch_o_vm(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
+    const size_t lds = (size_t)(KS8 * 4) * MB * 2048, redb = (size_t)MB * (8 * 1024 + 1024);
+    const size_t need = lds > redb ? lds : redb;
     DT_SWITCH(a.dt, T, {
-        if (need > 65536) ensure_dyn_lds((const void*)skinny_o_kernel<T, KS8>, (int)need);
-        hipLaunchKernelGGL((skinny_o_kernel<T, KS8>), dim3(a.N / 16, (a.M + 15) / 16), dim3(512), need, s, a, (T*)x, ldxres, SS);
+        if (need > 65536) ensure_dyn_lds((const void*)skinny_o_kernel<T, KS8, MB>, (int)need);
+        hipLaunchKernelGGL((skinny_o_kernel<T, KS8, MB>), dim3(a.N / 16, (a.M + 16 * MB - 1) / (16 * MB)), dim3(512), need, s, a, (T*)x, ldxres, SS);
     });
+}
+template <int KS8> static void launch_o_v(const SkinnyArgs& a, bf16_t* x, int ldxres, float* SS, hipStream_t s) {
+    if (a.M > 32 && !g_opts.o64_16rows) launch_o_vm<KS8, 2>(a, x, ldxres, SS, s); else launch_o_vm<KS8, 1>(a, x, ldxres, SS, s);
 }
 bool skinny_o_eligible(int M, int N, int K) {
     if (g_opts.no_fused_gu) return false;
@@ -1191,6 +1205,10 @@ static int skinny_pick_cfg(int N, int K) {
     if (!g_opts.no_skinny768 && K % 768 == 0 && N % 64 == 0 && K / 768 <= 8 && (long)(N / 64) * (K / 768) <= 256 &&
         (K % 1024 != 0 || (long)(N / 64) * (K / 768) > (long)(N / 64) * (K / 1024)) && (long)(N / 64) * (K / 768) >= 192) return 3;
     if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8 && (long)(N / 64) * (K / 1024) >= 192) return 1;
+    // 48 rows x 512 where that is one block per CU and 32 x 512 is not: the QKV projection of the full-size model (3072 x 2048) as 64 x 4 = 256 blocks
+    // instead of 96 x 4 = 384 (half of the CUs got two blocks, each with its own 32 - 64 KiB X image through the CU's vector-memory path)
+    if (!g_opts.no_skinny48 && K % 512 == 0 && N % 48 == 0 && K / 512 <= 8 && (long)(N / 48) * (K / 512) <= 256 && (long)(N / 48) * (K / 512) >= 192 &&
+        (long)(N / 32) * (K / 512) > 256) return 4;
     if (K % 512 == 0 && N % 32 == 0 && K / 512 <= 8) return 2;
     if (K % 1024 == 0 && N % 64 == 0 && K / 1024 <= 8) return 1;
     return 0;
@@ -1199,7 +1217,7 @@ int skinny_pick_ksplit(int N, int K) {
     const int cfg = skinny_pick_cfg(N, K);
     if (cfg == 1) return K / 1024;
     if (cfg == 3) return K / 768;
-    if (cfg == 2) return K / 512;
+    if (cfg == 2 || cfg == 4) return K / 512;
     const int kw = skinny_pick_kw(K);
     return kw ? K / (256 * kw) : 0;
 }
@@ -1229,6 +1247,7 @@ template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = fa
 template <typename KD, int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
     if (cfg == 1) launch_xs_v<KD, MB, 4, 2, 16>(a, a.K / 1024, s);
     else if (cfg == 3) launch_xs_v<KD, MB, 4, 2, 12>(a, a.K / 768, s);
+    else if (cfg == 4) launch_xs_v<KD, MB, 1, 8, 2, 3>(a, a.K / 512, s);
     else launch_xs_v<KD, MB, 2, 4, 4>(a, a.K / 512, s);
 }
 // int8 operands (Linear8bitLt decode step): 32 * NT weight rows x (4 * KSW * 64) of K per block.  The slabs are exact int32 sums, so the

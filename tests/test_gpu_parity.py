@@ -550,12 +550,14 @@ def test_fused_decode_rows_vs_unfused(R):
         e.set_option("no_fused_gu", 0)
     if R > 32:
         # round 5: 33 .. 64 rows go through skinny_gu64_kernel (one sweep, four 16-row passes); round 4's two passes of 32 rows must give the same BITS
-        e.set_option("gu64_two_pass", 1)
-        try:
-            ids_2, log_2 = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
-        finally:
-            e.set_option("gu64_two_pass", 0)
-        assert all(np.array_equal(ids_f[i], ids_2[i]) for i in range(R)) and np.array_equal(log_f.view(np.uint32), log_2.view(np.uint32))
+        # (and the fused o_proj's 32-row blocks the same bits as round 4's 16-row ones)
+        for opt in ("gu64_two_pass", "o64_16rows"):
+            e.set_option(opt, 1)
+            try:
+                ids_2, log_2 = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
+            finally:
+                e.set_option(opt, 0)
+            assert all(np.array_equal(ids_f[i], ids_2[i]) for i in range(R)) and np.array_equal(log_f.view(np.uint32), log_2.view(np.uint32)), opt
     same = 0
     for i in range(R):
         assert np.array_equal(ids_f[i], ids_g[i])
