@@ -434,8 +434,9 @@ def main():
                     "with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="ranks use device LOCAL_RANK mod device count (exercise the N-rank path on fewer GPUs; not a scaling measurement)")
     ap.add_argument("--slots", type=int, default=3, help="batches of --batch segments in flight per GPU on one engine / one weight copy (sonic_slot_create); 1 = rounds 1-3's definition")
-    ap.add_argument("--pipeline", default="2x64+1", help="the headline leg: bulk pipeline 'DxR+P' = D decoding handles looping continuously over R rows each + P "
-                    "prefill slots, all on the engine's one weight copy (sonicscribe_amd/pipeline.py); 'off' = the headline is the --slots leg")
+    ap.add_argument("--pipeline", default="3x64+1", help="the headline leg: bulk pipeline 'DxR+P' = D decoding handles looping continuously over R rows each + P "
+                    "prefill slots, all on the engine's one weight copy (sonicscribe_amd/pipeline.py); 'off' = the headline is the --slots leg.  "
+                    "(3x64+1 since round 5: 166-169 segments/s against 163-166 for 2x64+1 in alternating runs on one box, profiles/round5_pipeline_shapes.txt)")
     ap.add_argument("--pipeline-host", default="native", choices=["native", "python"], help="who drives the bulk pipeline's hand-overs: threads inside libsonic_hip.so "
                     "(sonic_pipeline_*, round 5) or round 4's Python threads (sonicscribe_amd/pipeline.py ContinuousPipeline; A/B)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects int8_b64 / streaming / pcie_inclusive of the N=1 line")
