@@ -682,7 +682,7 @@ def main():
                        "pipeline": pipe_info,
                        "hw_queues": hwq,                # hardware queues the HIP runtime of this process really has (measured, sonic_runtime_info), GPU_MAX_HW_QUEUES, wanted
                        "host_cpus_busy": host_cpu,      # CPU seconds per wall second of this process in each timed leg (rank 0): how much host the legs need
-                       "batches_in_flight": in_flight_n, "weight_copies": 1, "weight_bytes": weight_bytes, "slots_bit_identical_to_single_batch": slots_identical,
+                       "batches_in_flight": in_flight_n, "weight_copies": 1, "weight_bytes": weight_bytes, "weights_mb": round(weight_bytes / 2 ** 20, 1), "slots_bit_identical_to_single_batch": slots_identical,
                        "segments_per_gpu": B, "max_new_tokens": a.max_new, "parallelism": f"replica x{n_gpus} (segments sharded, no collective)",
                        "shard_of_rank0": [lo, hi], "dist_backend": (a.dist_backend if dist is not None else None), "share_gpu": bool(a.share_gpu)},
             # one batch at a time: the K steps of leg A (same barriers, same max over ranks); stages and roofline below are ITS device times

@@ -150,6 +150,9 @@ struct GemmArgs {
     // (GELU_LUT_N bf16 bit patterns: both signs x exponents 2^-14 .. 2^3 x 128 mantissas) is copied to LDS and indexed by the bits
     const unsigned short* gelu_lut;
     int raster_gm;                   // 256x256 kernel: M tiles per raster group (0: default 8)
+    int w_tiled;                     // 16-bit kinds: W is the decode step's fragment-tiled copy ([N / 16][K / 32][64 lanes][8], launch_tile_weights) - the ONE copy of a
+                                     // decoder projection since round 5; a 1-KiB LDS-DMA piece is then one (16-row, 32-k) fragment and the MFMA operand read is lane-linear
+    int gu8;                         // EPI_SWIGLU: gate / up rows interleaved in 8-row groups (launch_tile_weights_gu8) instead of 16-row groups
     long long* dbg;                  // diagnostics (sonic_bench_gemm with option gemm_trace): per block 8 words {entry, first K tile landed, K loop done, stores issued (100 MHz clock), hw id}; null in production
 };
 #define GELU_LUT_E0 113                     // biased exponent of 2^-14

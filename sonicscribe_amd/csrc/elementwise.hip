@@ -288,16 +288,16 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
     if (qo.q && !(dq.dbg & 2)) quant_emit_row<true>(yo, c < nv, c, row, qo, qpart, qparti);
 }
 
-// decode: act[r][c] = T(T(silu(T g)) * T u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU)
+// decode: act[r][c] = T(T(silu(T g)) * T u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU) or, gu8, in 8-row groups (the fused
+// gate/up kernel's weight copy, launch_tile_weights_gu8: the one decode copy of the projection since round 5)
 template <typename T>
-__global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 /* 2*ff */, T* act, int rows) {
+__global__ void swiglu_slab_kernel(const float* P, int ksplit, int mpad, int n2 /* 2*ff */, T* act, int rows, int gu8) {
     typedef typename ET<T>::v4 V4;
     const int ff = n2 >> 1;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 outputs
     if (idx >= (long)rows * (ff >> 2)) return;
     const int row = idx / (ff >> 2), c4 = (idx % (ff >> 2)) * 4;
-    const int grp = c4 >> 4, within = c4 & 15;
-    const int ng = grp * 32 + within, nu = ng + 16;
+    const int ng = gu8 ? (c4 >> 3) * 16 + (c4 & 7) : (c4 >> 4) * 32 + (c4 & 15), nu = ng + (gu8 ? 8 : 16);
     f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < ksplit; ++ks) {
         const float* p = P + ((long)ks * mpad + row) * n2;
@@ -679,9 +679,9 @@ void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const f
     const QuantOut o = qo ? *qo : QuantOut{};
     DT_SWITCH(dt, T, hipLaunchKernelGGL(add_rmsnorm_kernel<T>, dim3(rows), dim3(threads), 0, s, (T*)x, P, ksplit, mpad, w, (T*)y, rows, d, eps, q, o));
 }
-void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt) {
+void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt, int gu8) {
     const long n = (long)rows * (n2 >> 3);
-    DT_SWITCH(dt, T, hipLaunchKernelGGL(swiglu_slab_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, P, ksplit, mpad, n2, (T*)act, rows));
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(swiglu_slab_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, P, ksplit, mpad, n2, (T*)act, rows, gu8));
 }
 void launch_swiglu_quant(const float* P, int ksplit, int mpad, int ff, bf16_t* act, int rows, const DeqInfo& dq, const QuantOut& qo, hipStream_t s) {
     hipLaunchKernelGGL(swiglu_quant_kernel, dim3(rows), dim3(1024), 0, s, P, ksplit, mpad, ff, (f16_t*)act, dq, qo);

@@ -139,7 +139,7 @@ struct sonic_engine {
 
     // experiment knobs (sonic_set_option): per engine, copied into the launchers' thread-local view by ENTER()
     LaunchOpts opts;
-    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0, opt_gemm_trace = 0, opt_no_rope_tiles = 0;
+    int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0, opt_gemm_trace = 0, opt_no_rope_tiles = 0, opt_prefill_rowmajor = 0;
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
     int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
@@ -917,11 +917,28 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
             continue;
         }
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
-        TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d)); TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
+        TRY(tiled(L.wdown, &L.wdown_t, d.dec_d, d.dec_ff));
         if (skinny_gu_eligible(1, 2 * d.dec_ff, d.dec_d)) {          // fused gate/up kernel's layout (8-row gate/up interleave); both 16-bit element types (round 5)
+            // ONE decode copy of gate/up: the unfused path (A/B, shapes the fused kernel does not take) multiplies the same tiles and its SwiGLU pass
+            // reads the columns in the 8-row interleave (round 4 kept a second tiled copy in the 16-row interleave: 1.4 GB of the full-size model)
             TRY(dalloc_big(e, &L.wgu_t8, (size_t)2 * d.dec_ff * d.dec_d, false));
             launch_tile_weights_gu8(L.wgu, L.wgu_t8, 2 * d.dec_ff, d.dec_d, e->st);
             e->weight_bytes += (int64_t)2 * d.dec_ff * d.dec_d * 2;
+        } else {
+            TRY(tiled(L.wgu, &L.wgu_t, 2 * d.dec_ff, d.dec_d));
+        }
+    }
+    if (!e->i8 && !getenv("SONIC_KEEP_ROWMAJOR")) {
+        // the row-major decoder projections were only the prefill GEMMs' operand: those read the tiled copies now (GemmArgs.w_tiled)
+        HIPC(e, stream_sync(e));
+        auto drop = [&](bf16_t** w, size_t n) {
+            if (!*w) return;
+            for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w) { e->allocs.erase(it); break; }
+            (void)hipFree(*w); *w = nullptr; e->alloc_bytes -= (int64_t)((n * 2 + 3) / 4 * 4); e->weight_bytes -= (int64_t)n * 2;
+        };
+        for (auto& L : e->dec) {
+            drop(&L.wqkv, (size_t)e->qkvN * d.dec_d); drop(&L.wo, (size_t)d.dec_d * e->QD);
+            drop(&L.wgu, (size_t)2 * d.dec_ff * d.dec_d); drop(&L.wdown, (size_t)d.dec_d * d.dec_ff);
         }
     }
     TRY(dalloc_big(e, &e->embed_t, (size_t)d.vocab * d.dec_d, false));
@@ -937,9 +954,10 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
 
 // ------------------------------------------------------------------------------------------ pipeline stages
 static void gemm(sonic_engine* e, int epi, const bf16_t* A, long lda, const bf16_t* W, const float* bias, bf16_t* C, long ldc,
-                 int M, int N, int K, const bf16_t* R = nullptr, long ldr = 0) {
+                 int M, int N, int K, const bf16_t* R = nullptr, long ldr = 0, int w_tiled = 0, int gu8 = 0) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = e->dt;
+    a.w_tiled = w_tiled; a.gu8 = gu8;
     a.gelu_lut = e->opt_no_gelu_lut ? nullptr : e->gelu_lut;
     launch_gemm(a, epi, e->st);
 }
@@ -1188,8 +1206,8 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             SkinnyArgs ga{}; ga.X = e->shn; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt;
             launch_skinny_gu(ga, e->sact, e->st);
         } else {
-            skinny(e, e->shn, D, L.wgu_t, e->slab, R, 2 * d.dec_ff, D, &ks);
-            launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st, dt);
+            skinny(e, e->shn, D, L.wgu_t ? L.wgu_t : L.wgu_t8, e->slab, R, 2 * d.dec_ff, D, &ks);
+            launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st, dt, L.wgu_t ? 0 : 1);
         }
         }
         skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks, kt_slot(e, l, 4));
@@ -1335,8 +1353,15 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
+        // 16-bit modes: the prefill GEMMs read the decode step's fragment-tiled weights (GemmArgs.w_tiled) - one copy of every decoder projection
+        // since round 5 (the row-major ones are freed at load unless SONIC_KEEP_ROWMAJOR=1; option prefill_rowmajor then selects them for the A/B)
+        auto lin = [&](int epi, const bf16_t* X, long ldx, const bf16_t* w16, const bf16_t* wt, int gu8, const QW& q, bf16_t* C, long ldc, int N, int K,
+                       const bf16_t* Rr, long ldr, bool pq) {
+            if (!e->i8 && wt && (!w16 || !e->opt_prefill_rowmajor)) gemm(e, epi, X, ldx, wt, nullptr, C, ldc, M, N, K, Rr, ldr, 1, gu8);
+            else qlinear(e, epi, X, ldx, w16, q, nullptr, C, ldc, M, N, K, Rr, ldr, grp, nullptr, 0, 0, pq);
+        };
         const bool pq1 = rmsnorm_q(e, e->dx, L.ln1, e->dhn, M, D, d.dec_rms_eps, grp);
-        qlinear(e, EPI_BIAS, e->dhn, D, L.wqkv, L.qqkv, nullptr, e->dqkv, e->qkvN, M, e->qkvN, D, nullptr, 0, grp, nullptr, 0, 0, pq1);
+        lin(EPI_BIAS, e->dhn, D, L.wqkv, L.wqkv_t, 0, L.qqkv, e->dqkv, e->qkvN, e->qkvN, D, nullptr, 0, pq1);
         RopeAppendArgs ra{}; ra.dt = dt;
         ra.qkv = e->dqkv; ra.ld = e->qkvN; ra.q_out = e->dq; ra.Kc = e->Kc + kvoff; ra.Vc = e->Vc + kvoff; ra.Vt = e->Vts; ra.vt_ld = e->max_ctx;
         ra.tok_seq = e->tok_seq; ra.tok_pos = e->tok_pos_pf; ra.cs = e->dec_cs; ra.Hq = d.dec_heads; ra.Hkv = d.dec_kv_heads; ra.ctx_max = e->max_ctx; ra.n_tok = M;
@@ -1349,10 +1374,10 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
         f.q_off = e->q_off; f.q_len = e->q_len; f.kv_len = e->q_len; f.Hq = d.dec_heads; f.Hkv = d.dec_kv_heads;
         f.scale = 1.0f / sqrtf((float)d.dec_head_dim);
         launch_flash(f, 128, true, R, hp.max_p, e->st);
-        qlinear(e, EPI_BIAS_RESID, e->datt, e->QD, L.wo, L.qo, nullptr, e->dx, D, M, D, e->QD, e->dx, D, grp);
+        lin(EPI_BIAS_RESID, e->datt, e->QD, L.wo, L.wo_t, 0, L.qo, e->dx, D, D, e->QD, e->dx, D, false);
         const bool pq2 = rmsnorm_q(e, e->dx, L.ln2, e->dhn, M, D, d.dec_rms_eps, grp);
-        qlinear(e, EPI_SWIGLU, e->dhn, D, L.wgu, L.qgu, nullptr, e->dact, d.dec_ff, M, 2 * d.dec_ff, D, nullptr, 0, grp, nullptr, 0, 0, pq2);
-        qlinear(e, EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, L.qdown, nullptr, e->dx, D, M, D, d.dec_ff, e->dx, D, grp);
+        lin(EPI_SWIGLU, e->dhn, D, L.wgu, L.wgu_t8 ? L.wgu_t8 : L.wgu_t, L.wgu_t8 ? 1 : 0, L.qgu, e->dact, d.dec_ff, 2 * d.dec_ff, D, nullptr, 0, pq2);
+        lin(EPI_BIAS_RESID, e->dact, d.dec_ff, L.wdown, L.wdown_t, 0, L.qdown, e->dx, D, D, d.dec_ff, e->dx, D, false);
         if (e->taps_on) HIPC(e, hipMemcpyAsync(e->taps + (size_t)(l + 1) * e->tok_cap * D, e->dx, (size_t)M * D * 2, hipMemcpyDeviceToDevice, e->st));
     }
     // logits only for the last prompt position of each request (logits_to_keep=1, generation/utils.py:2612-2616)
@@ -2493,6 +2518,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "decode_lookahead")) { e->lookahead = value < 1 ? 1 : (value > CHK_MAX_AHEAD ? CHK_MAX_AHEAD : value); return SONIC_OK; }   // start value (it adapts)
     if (!strcmp(key, "decode_chunk")) { e->opt_decode_chunk = value > 0 ? (value > 64 ? 64 : value) : 1; return SONIC_OK; }   // token steps per graph launch / early-stop check
+    if (!strcmp(key, "prefill_rowmajor")) { e->opt_prefill_rowmajor = value; return SONIC_OK; } // prefill GEMMs read the row-major decoder weights (kept only under SONIC_KEEP_ROWMAJOR=1; A/B)
     if (!strcmp(key, "no_rope_tiles")) { e->opt_no_rope_tiles = value; return SONIC_OK; }  // prefill RoPE + KV append per token (rounds 1-4) instead of per 16-position tile (A/B)
     if (!strcmp(key, "gemm_trace")) { e->opt_gemm_trace = value; return SONIC_OK; }        // sonic_bench_gemm prints an in-kernel timeline of one launch to stderr
     if (!strcmp(key, "gemm_timing")) { e->opt_gemm_timing = value; return SONIC_OK; }      // HIP events around every encoder-layer GEMM launch

@@ -78,14 +78,21 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) 
     for (int i = 0; i < WN; ++i) {
         int rw = n0 + (wid * WN + i) * 8 + lr; rw = rw < a.N ? rw : a.N - 1;
         srcW[i] = (const ET_*)a.W + (long)rw * a.K + lc * CE;
+        if (a.w_tiled) {
+            // fragment-tiled W (GemmArgs.w_tiled): piece wid * WN + i of the stage = (row tile p >> 1, k-step p & 1), 1 KiB contiguous, lane-linear
+            const int p = wid * WN + i;
+            int nb = n0 + (p >> 1) * 16; nb = nb + 16 <= a.N ? nb : a.N - 16;
+            srcW[i] = (const ET_*)a.W + ((long)(nb >> 4) * (a.K / (BKE / 2)) + (p & 1)) * (BKE / 2 * 16) + lane * CE;
+        }
     }
+    const int kmulW = a.w_tiled ? 16 : 1;
     auto stage_load = [&](int stage, int k0) {
         char* sA = smem + stage * TSTAGE;
         char* sB = sA + TBM * BK * 2;
 #pragma unroll
         for (int i = 0; i < WM; ++i) glds16(srcA[i] + k0, sA + (wid * WM + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < WN; ++i) glds16(srcW[i] + k0, sB + (wid * WN + i) * 1024);
+        for (int i = 0; i < WN; ++i) glds16(srcW[i] + k0 * kmulW, sB + (wid * WN + i) * 1024);
     };
 
     Acc acc[WN][WM];  // [ni][mi]
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) 
 #pragma unroll
             for (int i = 0; i < WN; ++i) {
                 const int rw = wc * (WN * 16) + i * 16 + fr;
-                wf[i] = *(const Frag*)(sB + rw * 128 + ((c ^ (rw & 7)) << 4));
+                wf[i] = *(const Frag*)(sB + (a.w_tiled ? ((wc * WN + i) * 2 + kk) * 1024 + lane * 16 : rw * 128 + ((c ^ (rw & 7)) << 4)));
             }
             if (vtile) {
 #pragma unroll
@@ -155,6 +162,29 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (16-bit kinds only)
                     *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
+                }
+            }
+        }
+        return;
+    }
+    if (EPI == EPI_SWIGLU && a.gu8) {
+        // gate / up in 8-row groups (GemmArgs.gu8): lanes fg < 2 hold four gate columns of a 16-row tile, lanes fg >= 2 their up partners
+        // (v_permlane32_swap: the lower half finishes columns 2, 3 of its group of four, the upper half columns 0, 1 - see gemm256.hip)
+        typedef typename ET<OT>::v2 O2;
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int oc = ((n0 + wc * (WN * 16) + ni * 16) >> 1) + (fg & 1) * 4 + (fg < 2 ? 2 : 0);
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) {
+                const int m = m0 + wr * (WM * 16) + mi * 16 + fr;
+                const f32x4 v = {(float)acc[ni][mi][0], (float)acc[ni][mi][1], (float)acc[ni][mi][2], (float)acc[ni][mi][3]};
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[0]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[3]), __float_as_uint(v[1]), false, false);
+                if (m < a.M && (n0 + wc * (WN * 16) + ni * 16) < a.N) {
+                    O2 o;
+                    o[0] = (OT)(rT<OT>(silu_f(rT<OT>(__uint_as_float(s0[0])))) * rT<OT>(__uint_as_float(s0[1])));
+                    o[1] = (OT)(rT<OT>(silu_f(rT<OT>(__uint_as_float(s1[0])))) * rT<OT>(__uint_as_float(s1[1])));
+                    *(O2*)(C + (long)m * a.ldc + oc) = o;
                 }
             }
         }

@@ -88,8 +88,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             int n = n0 + (lrow >> 5) * 64 + h * 32 + (lrow & 31); n = n < a.N ? n : a.N - 1;
             srcA[h][i] = A + (long)m * a.lda + lc * CE;
             srcB[h][i] = (const ET_*)a.W + (long)n * a.K + lc * CE;
+            if (a.w_tiled) {
+                // fragment-tiled W: piece wid * 2 + i of the half-tile = (row tile wid of the image, k-step i): 1 KiB contiguous in memory, lane-linear
+                int nb = n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16; nb = nb + 16 <= a.N ? nb : a.N - 16;
+                srcB[h][i] = (const ET_*)a.W + ((long)(nb >> 4) * (a.K / (TBK / 2)) + i) * (TBK / 2 * 16) + lane * CE;
+            }
         }
     }
+    const int kmulB = a.w_tiled ? 16 : 1;        // elements the tiled source advances per element of k (a (16-row, k-step) tile is 16 x the k-step wide)
     auto dma = [&](const ET_* const (&src)[2], int k0, int buf, int slot) {
         char* dst = smem + buf * TILE_BYTES + slot * HT_BYTES + wid * 2048;
 #pragma unroll
@@ -144,14 +150,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const Frag*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
         }
     };
+    // byte offsets of this lane's four B fragments in a half-tile: swizzled rows, or (tiled W) piece (row tile, k-step) + lane * 16
+    int boff[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int row = wc * 32 + ni * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) boff[ni][kk] = a.w_tiled ? ((wc * 2 + ni) * 2 + kk) * 1024 + lane * 16 : row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4);
+    }
     auto read_b = [&](int buf, int half, Frag (&b)[2][2]) {
         const char* s = smem + buf * TILE_BYTES + (half ? SLOT_B1 : SLOT_B0) * HT_BYTES;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int row = wc * 32 + ni * 16 + fr;
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b[ni][kk] = *(const Frag*)(s + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
-        }
+            for (int kk = 0; kk < 2; ++kk) b[ni][kk] = *(const Frag*)(s + boff[ni][kk]);
     };
     // vt (compile-time): transposed MFMA roles for the V tiles of the fused QKV GEMM; hoisted out of the K loop
     auto quad = [&](auto vt, int mh, int nh, const Frag (&b)[2][2]) {
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         // ph1
         wait_vm<W1>();
         BARRIER();
-        if (ISSUE) { dma(srcA[0], kn, buf, SLOT_A0); dma(srcB[0], kn, buf, SLOT_B0); }
+        if (ISSUE) { dma(srcA[0], kn, buf, SLOT_A0); dma(srcB[0], kn * kmulB, buf, SLOT_B0); }
         read_b(buf, 1, b1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         // ph2
         wait_vm<W2>();
         BARRIER();
-        if (ISSUE) dma(srcB[1], kn, buf, SLOT_B1);
+        if (ISSUE) dma(srcB[1], kn * kmulB, buf, SLOT_B1);
         read_a(buf, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -215,8 +227,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     // prologue: K tiles 0 and 1, issue order = consumption order (A0,B0 | B1 | A1)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        dma(srcA[0], t * TBK, t, SLOT_A0); dma(srcB[0], t * TBK, t, SLOT_B0);
-        dma(srcB[1], t * TBK, t, SLOT_B1);
+        dma(srcA[0], t * TBK, t, SLOT_A0); dma(srcB[0], t * TBK * kmulB, t, SLOT_B0);
+        dma(srcB[1], t * TBK * kmulB, t, SLOT_B1);
         dma(srcA[1], t * TBK, t, SLOT_A1);
     }
     if (!STAGGER) {
@@ -245,13 +257,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             if (G0) quad(vt, 0, 0, b0); else { read_a(buf, 0); read_b(buf, 0, b0); lgkm0(); }
             wait_vm<W1>();
             BARRIER();                                                                   // slot 2
-            if (ISSUE) { dma(srcA[0], kn, buf, SLOT_A0); dma(srcB[0], kn, buf, SLOT_B0); }
+            if (ISSUE) { dma(srcA[0], kn, buf, SLOT_A0); dma(srcB[0], kn * kmulB, buf, SLOT_B0); }
             if (G0) { read_b(buf, 1, b1); lgkm0(); } else quad(vt, 0, 0, b0);
             BARRIER();                                                                   // slot 3
             if (G0) quad(vt, 0, 1, b1); else { read_b(buf, 1, b1); lgkm0(); }
             wait_vm<W2>();
             BARRIER();                                                                   // slot 4
-            if (ISSUE) dma(srcB[1], kn, buf, SLOT_B1);
+            if (ISSUE) dma(srcB[1], kn * kmulB, buf, SLOT_B1);
             if (G0) { read_a(buf, 1); lgkm0(); } else quad(vt, 0, 1, b1);
             BARRIER();                                                                   // slot 5
             if (G0) quad(vt, 1, 1, b1); else { read_a(buf, 1); lgkm0(); }
@@ -374,6 +386,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
             }
             return;
         }
+    }
+    if (EPI == EPI_SWIGLU && a.gu8) {
+        // gate / up in 8-row groups: accumulator block nb holds gate columns 8 nb' .. in lanes fg < 2 and their up partners in lanes fg >= 2
+        // (rows 4 fg + j of the 16-row tile): one cross-lane move pairs them, lanes fg < 2 finish four activated columns
+        // (v_permlane32_swap: lanes l and l + 32 trade two of their four values, so the lower half finishes columns 2, 3 and the upper half
+        //  columns 0, 1 of the group - two VALU swaps per fragment and the SiLU work on all 64 lanes; four ds_bpermute + half the lanes idle cost
+        //  the gate/up GEMM of the prefill 10 %)
+        typedef typename ET<OT>::v2 O2;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int ol = wc * 32 + nb * 8 + (fg & 1) * 4 + (fg < 2 ? 2 : 0);     // first of this lane's two columns in the 128-wide activated tile
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const f32x4 v = {(float)acc[nb][mb][0], (float)acc[nb][mb][1], (float)acc[nb][mb][2], (float)acc[nb][mb][3]};
+                // lower half gets (G2, U2) / (G3, U3), upper half (G0, U0) / (G1, U1)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[0]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[3]), __float_as_uint(v[1]), false, false);
+                O2 o;
+                o[0] = (OT)(rT<OT>(silu_f(rT<OT>(__uint_as_float(s0[0])))) * rT<OT>(__uint_as_float(s0[1])));
+                o[1] = (OT)(rT<OT>(silu_f(rT<OT>(__uint_as_float(s1[0])))) * rT<OT>(__uint_as_float(s1[1])));
+                *(O2*)(smem + (wr * 128 + mb * 16 + fr) * CLD + ol * 2) = o;
+            }
+        }
+        __syncthreads();
+        const int No = a.N >> 1, o0 = n0 >> 1;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 512 + tid, row = c >> 4, ch = c & 15;
+            const int m = m0 + row, oc = o0 + ch * 8;
+            if (m < a.M && oc < No) *(O8*)(C + (long)m * a.ldc + oc) = *(const O8*)(smem + row * CLD + ch * 16);
+        }
+        return;
     }
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
