@@ -537,7 +537,55 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
     load(wid * 16, kf, vv);
 
     int n;                                   // keys visible, the new token included at position n-1
-    if (a.P) {
+    if (a.P && !a.dq.sca) {
+        // 16-bit kinds (round 5): four consecutive dims per thread.  Round 4's form below (kept for the int8 kind, whose dequantisation owns single
+        // columns) had 384 threads fetch two scalars per slab - and eight slabs whatever ksplit was, the spare ones as dummies: 96 wave-wide 4-byte
+        // loads per block behind the 64 of the first K/V slice, on a CU that issues one load instruction per ~15 ns.  Now (G + 2) * 16 threads fetch
+        // 2 x ksplit 16-byte pieces: 16 instructions at ksplit = 4.  Same sums in the same order, same RoPE roundings: same bits.
+        typedef typename ET<T>::v4 V4;
+        const int N = (a.Hq + 2 * a.Hkv) * HD;
+        const int vi = tid >> 4, i4 = (tid & 15) * 4;        // vector (q heads.., k, v), first of this thread's dims in the first half
+        const bool act = tid < (G + 2) * 16;
+        const int col = act ? (vi < G ? (kvh * G + vi) : vi == G ? (a.Hq + kvh) : (a.Hq + a.Hkv + kvh)) * HD + i4 : 0;
+        f32x4 v1[8], v2[8];
+        if (act) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                if (ks < a.ksplit) {
+                    const float* p = a.P + ((long)ks * a.mpad + b) * N + col;
+                    v1[ks] = *(const f32x4*)p; v2[ks] = *(const f32x4*)(p + HALF);
+                }
+        }
+        n = min(max(a.kv_len[b], 1), a.ctx_max);      // (clamped: the cache / RoPE table rows of this block end at ctx_max)
+        if (act) {
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                if (ks < a.ksplit) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x1[e] += v1[ks][e]; x2[e] += v2[ks][e]; }
+                }
+            const int pos = n - 1;
+            f32x4 c = {1.f, 1.f, 1.f, 1.f}, sn = {0.f, 0.f, 0.f, 0.f};
+            if (vi <= G) { c = *(const f32x4*)(a.cs + (long)pos * HD + i4); sn = *(const f32x4*)(a.cs + (long)pos * HD + HALF + i4); }
+            V4 b1, b2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y1 = rT<T>(x1[e]), y2 = rT<T>(x2[e]);
+                float o1 = y1, o2 = y2;
+                if (vi <= G) {
+                    o1 = rT<T>(rT<T>(y1 * c[e]) + rT<T>(-y2 * sn[e]));
+                    o2 = rT<T>(rT<T>(y2 * c[e]) + rT<T>(y1 * sn[e]));
+                }
+                b1[e] = (T)o1; b2[e] = (T)o2;
+            }
+            const int row = vi < G ? vi : (vi == G ? GMAX : GMAX + 1);
+            *(V4*)&s_q[row][i4] = b1; *(V4*)&s_q[row][HALF + i4] = b2;
+            if (vi == G) { *(V4*)(Kc + (long)pos * HD + i4) = b1; *(V4*)(Kc + (long)pos * HD + HALF + i4) = b2; }
+            if (vi == G + 1) { *(V4*)(Vc + (long)pos * HD + i4) = b1; *(V4*)(Vc + (long)pos * HD + HALF + i4) = b2; }
+        }
+        __syncthreads();
+    } else if (a.P) {
         // QKV slab sum of this (segment, kv head): issued before kv_len is needed, so the two latencies overlap
         const int N = (a.Hq + 2 * a.Hkv) * HD;
         const int w = tid, vi = w / HALF, i = w % HALF;      // vector (q heads.., k, v), index in the first half; (G + 2) * 64 <= 384 threads
