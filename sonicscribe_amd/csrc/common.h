@@ -129,6 +129,7 @@ struct GemmI8 {
     // in defer_out (same row pitch as C; no outlier sum, no residual) and launch_i8_outlier_side finishes them with a dense fp16 MFMA
     // product over the gathered columns.  NULL: every list is walked in the epilogue (O(columns) scalar loads per output element).
     bf16_t* defer_out; int defer_thr;
+    const int8_t* wk;                 // k-major copy of W ([K][N]) for the outlier columns when GemmArgs.W is the fragment-tiled copy (GemmArgs.w_tiled); NULL: W is row-major
 };
 
 struct GemmArgs {

@@ -36,7 +36,7 @@ struct DevTensor {
 };
 
 // int8 mode (asr.py:169-210): a quantised Linear keeps row-wise int8 weights + row absmax instead of its 16-bit matrix
-struct QW { int8_t* cb = nullptr; float* scb = nullptr; int8_t* cbt = nullptr; int8_t* cbk = nullptr; };   // cbt: fragment-tiled copy, cbk: k-major copy (decode step)
+struct QW { int8_t* cb = nullptr; float* scb = nullptr; int8_t* cbt = nullptr; int8_t* cbk = nullptr; bool cb_rowmajor_kept = true; };   // cbt: fragment-tiled copy, cbk: k-major copy (decode step)
 struct EncLayerW { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; bf16_t *wqkv, *wo, *w1, *w2; QW qqkv, qo, q1, q2; };
 #define KT_SLOT_BLOCKS 512                                   // "ktrace" diagnostics: blocks recorded per kernel slot, 8 timestamps each
 struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          // row-major (prefill GEMM)
@@ -601,6 +601,7 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, SONIC_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
     (void)probe_hw_queues(device_id);                     // once per device and process; warns when streams will alias (see sonic_runtime_info)
     sonic_engine* e = new sonic_engine();
+    if (const char* v = getenv("SONIC_KEEP_ROWMAJOR")) e->opt_prefill_rowmajor = atoi(v) >= 2;   // =2: keep the row-major decoder weights AND read them (A/B of whole test runs)
     e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
     e->i8 = mode == SONIC_MODE_INT8; e->dt = (e->i8 || mode == SONIC_MODE_F16) ? DT_F16 : DT_BF16;
     int s = alloc_state(e);
@@ -827,6 +828,12 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
     HIPC(e, stream_sync(e));
     for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w16) { e->allocs.erase(it); break; }
     (void)hipFree(*w16); *w16 = nullptr; e->alloc_bytes -= (int64_t)N * K * 2;
+    if (q->cbt && q->cbk && !getenv("SONIC_KEEP_ROWMAJOR")) {
+        // the row-major int8 matrix was the prefill GEMM's operand and its outlier-column source: the tiled and the k-major copy serve both now
+        for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)q->cb) { e->allocs.erase(it); break; }
+        (void)hipFree(q->cb); q->cb = nullptr; q->cb_rowmajor_kept = false;
+        e->alloc_bytes -= (int64_t)(((size_t)N * K + 3) / 4 * 4); e->weight_bytes -= (int64_t)N * K;
+    }
     return SONIC_OK;
 }
 // concatenate row blocks of [rows_i][K] tensors
@@ -1000,12 +1007,14 @@ struct QkvVt { bf16_t* Vt; int n_split, seg_T, vt_ld; long vt_seg_stride; };
 static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const bf16_t* w16, const QW& q, const float* bias, bf16_t* C, long ldc,
                     int M, int N, int K, const bf16_t* R, long ldr, const QGroup& grp, const float* rope_cs = nullptr, int rope_T = 0, int rope_ncols = 0,
                     bool prequant = false, const QkvVt* vt = nullptr) {
-    if (!e->i8 || !q.cb) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return false; }
+    if (!e->i8 || !(q.cb || q.cbt)) { gemm(e, epi, X, ldx, w16, bias, C, ldc, M, N, K, R, ldr); return false; }
     const QuantActArgs qa = make_qa(e, X, ldx, M, K, grp);
     if (prequant) launch_quant_act_finish(qa, e->st);      // the LayerNorm that wrote X also wrote its codes, absmax and flags
     else launch_quant_act(qa, e->st);
     GemmArgs a{};
     a.A = (const bf16_t*)e->qa; a.lda = K; a.W = (const bf16_t*)q.cb; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = DT_F16;
+    // decoder projections: ONE int8 operand copy since round 5 - the fragment-tiled one of the decode step (+ the k-major copy for outlier columns)
+    if (q.cbt && q.cbk && (!e->opt_prefill_rowmajor || !q.cb_rowmajor_kept)) { a.W = (const bf16_t*)q.cbt; a.w_tiled = 1; a.q.wk = q.cbk; }
     a.q.sca = e->q_sca; a.q.scb = q.scb; a.q.x16 = X; a.q.ldx16 = ldx; a.q.oc_cnt = e->q_oc_cnt; a.q.oc_list = e->q_oc_list; a.q.oc_ld = e->q_kmax;
     a.q.row_group = grp.gmap; a.q.group_div = grp.gdiv;
     // int8 q|k|v: RoPE + V^T inside the GEMM's epilogue (round 3; the register form of the 16-bit kinds spilled beside the dequantisation, the int8

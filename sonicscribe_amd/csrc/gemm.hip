@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) 
                     const int seg = m / a.seg_T, t = m - seg * a.seg_T;
                     O4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[ni][mi][j], m + j, n, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (16-bit kinds only)
+                    for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[ni][mi][j], m + j, n, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (16-bit kinds only)
                     *(O4*)((OT*)a.Vt + (long)seg * a.vt_seg_stride + (long)(n - a.n_split) * a.vt_ld + t) = o;
                 }
             }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) 
                     O4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float g = gemm_lin<KD>(a, acc[2 * q][mi][j], m, ng + j, 0.f, rw, sbg[j]), u = gemm_lin<KD>(a, acc[2 * q + 1][mi][j], m, ng + 16 + j, 0.f, rw, sbu[j]);
+                        const float g = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[2 * q][mi][j], m, ng + j, 0.f, rw, sbg[j]), u = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[2 * q + 1][mi][j], m, ng + 16 + j, 0.f, rw, sbu[j]);
                         o[j] = (OT)(rT<OT>(silu_f(g)) * u);
                     }
                     *(O4*)(C + (long)m * a.ldc + oc) = o;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(GemmArgs a) 
             O4 o;
             float l[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) l[j] = gemm_lin<KD>(a, acc[ni][mi][j], m, n + j, bv[j], rw, sb[j]);
+            for (int j = 0; j < 4; ++j) l[j] = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[ni][mi][j], m, n + j, bv[j], rw, sb[j]);
             if (EPI == EPI_BIAS_RESID) {
                 if (rw.defer) {                                   // finished by launch_i8_outlier_side (outlier sum, then the residual)
 #pragma unroll

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int m = m0 + wr * 128 + mb * 16 + fg * 4 + j; m = m < a.M ? m : a.M - 1;
-                    o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (V^T tiles exist for 16-bit kinds only)
+                    o[j] = (OT)gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[nb][mb][j], m, nc, bv, I8Row{0.f, 0, 0, false}, 0.f);   // (V^T tiles exist for 16-bit kinds only)
                 }
                 *(O4*)(smem + nl * CLD + (wr * 128 + mb * 16 + fg * 4) * 2) = o;
             }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                     int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        *(OT*)(smem + (nl + j) * CLD + (wr * 128 + mb * 16 + fr) * 2) = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);
+                        *(OT*)(smem + (nl + j) * CLD + (wr * 128 + mb * 16 + fr) * 2) = (OT)gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);
                 }
             }
             __syncthreads();
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 int m = m0 + wr * 128 + mb * 16 + fr; m = m < a.M ? m : a.M - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g = gemm_lin<KD>(a, acc[2 * q][mb][j], m, ng + j, 0.f, rws[mb], sbg[j]), u = gemm_lin<KD>(a, acc[2 * q + 1][mb][j], m, ng + 16 + j, 0.f, rws[mb], sbu[j]);
+                    const float g = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[2 * q][mb][j], m, ng + j, 0.f, rws[mb], sbg[j]), u = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[2 * q + 1][mb][j], m, ng + 16 + j, 0.f, rws[mb], sbu[j]);
                     o[j] = (OT)(rT<OT>(silu_f(g)) * u);
                 }
                 *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + ol * 2) = o;
@@ -488,12 +488,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 const int cnt = rws[0].cnt;
                 const int* lst = a.q.oc_list + (long)rws[0].g * a.q.oc_ld;
                 const f16_t* xb = (const f16_t*)a.q.x16;
-                const int8_t* wb = (const int8_t*)a.W + (long)nc * a.K;
+                // W[nc + j][k]: from the row-major matrix (rows K apart, k contiguous) or, GemmI8.wk (W is the fragment-tiled copy), from the k-major one
+                // (rows contiguous, k N apart) - one loop, two strides
+                const int8_t* wb = a.q.wk ? a.q.wk + nc : (const int8_t*)a.W + (long)nc * a.K;
+                const int wsj = a.q.wk ? 1 : a.K, wsk = a.q.wk ? a.N : 1;
                 for (int i = 0; i < cnt; ++i) {
                     const int k = lst[i];
+                    const int8_t* wp = wb + (long)k * wsk;
                     float wd[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wd[j] = rT<f16_t>(__fmul_rn(__fmul_rn((float)wb[(long)j * a.K + k], sb[j]), INT8_DEQ_W));
+                    for (int j = 0; j < 4; ++j) wd[j] = rT<f16_t>(__fmul_rn(__fmul_rn((float)wp[j * wsj], sb[j]), INT8_DEQ_W));
 #pragma unroll
                     for (int mb = 0; mb < 8; ++mb) {
                         const float xv = (float)xb[xo[mb] + k];
@@ -530,8 +534,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 O4 o2;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float x1 = gemm_lin<KD>(a, acc[0][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);
-                    const float x2 = gemm_lin<KD>(a, acc[1][mb][j], m, nc + 16 + j, bv1[j], rws[mb], sb1[j]);
+                    const float x1 = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[0][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);
+                    const float x2 = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[1][mb][j], m, nc + 16 + j, bv1[j], rws[mb], sb1[j]);
                     o[j] = (OT)(rT<OT>(x1 * c4[j]) + rT<OT>(-x2 * s4[j]));
                     o2[j] = (OT)(rT<OT>(x2 * c4[j]) + rT<OT>(x1 * s4[j]));
                 }
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                         float l[4]; unsigned t[4]; int idx[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            l[j] = gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);                  // a bf16 value
+                            l[j] = gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);                  // a bf16 value
                             idx[j] = gelu_lut_index(l[j]);
                             t[j] = lut[gelu_lut_slot(l[j], idx[j])];
                         }
@@ -582,10 +586,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]));
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gelu_erf(gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]));
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);   // RESID: the linear's own output; R is added below
+                for (int j = 0; j < 4; ++j) o[j] = (OT)gemm_lin<KD, EPI != EPI_BIAS_GELU>(a, acc[nb][mb][j], m, nc + j, bv[j], rws[mb], sb[j]);   // RESID: the linear's own output; R is added below
             }
             *(O4*)(smem + (wr * 128 + mb * 16 + fr) * CLD + nl * 2) = o;
         }

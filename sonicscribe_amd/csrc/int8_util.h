@@ -353,6 +353,19 @@ __device__ __forceinline__ float i8_add_outliers(const GemmI8& q, const int8_t* 
     return rT<f16_t>(__fadd_rn(v, a2));
 }
 
+// the same sum with a stride between the k of one weight row: 1 = the row-major matrix (wc = W + n * K), N = the k-major copy (wc = wk + n) - the
+// prefill GEMMs of the decoder read the fragment-tiled weights since round 5 and their row-major int8 copy is gone.  (ONE loop for both: a second
+// copy of the list walk in every epilogue made the encoder's int8 fc1 kernel spill.)
+__device__ __forceinline__ float i8_add_outliers_k(const GemmI8& q, const int8_t* wc, int N, float sb, int g, int cnt, long m, float v) {
+    const f16_t* xr = (const f16_t*)q.x16 + m * q.ldx16;
+    float a2 = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+        const int k = q.oc_list[(long)g * q.oc_ld + i];
+        a2 = __fmaf_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn((float)wc[(long)k * N], sb), INT8_DEQ_W)), a2);
+    }
+    return rT<f16_t>(__fadd_rn(v, a2));
+}
+
 // Per-row metadata of an int8 GEMM epilogue, loaded once per row a lane touches (not per element)
 struct I8Row { float sa; int g, cnt; bool defer; };
 template <typename KD>
@@ -369,12 +382,17 @@ __device__ __forceinline__ I8Row i8_row(const GemmArgs& a, int m) {
 // Linear output of one accumulator element as a float that is exactly representable in the output type: 16-bit kinds round
 // acc + bias once; the int8 kind applies the LLM.int8 dequantisation (sonic_oracle.c linear_int8) and adds the outlier columns.
 // rw: the row's metadata (i8_row), sb: SCB[n] (int8 kind only).
-template <typename KD, typename AccE>
+// WK: the epilogue may meet GemmI8.wk (decoder projections; never the GELU epilogue - compiled into it, the second addressing form made the
+// encoder's int8 fc1 kernel keep its accumulators in scratch).
+template <typename KD, bool WK = true, typename AccE>
 __device__ __forceinline__ float gemm_lin(const GemmArgs& a, AccE accv, int m, int n, float bias, const I8Row& rw, float sb) {
     typedef typename KD::out OT;
     if constexpr (KD::I8) {
         float v = rT<f16_t>(fmaf((float)accv, __fmul_rn(__fmul_rn(rw.sa, sb), MM_DEQUANT_CONST), bias));
-        if (rw.cnt > 0) v = i8_add_outliers(a.q, (const int8_t*)a.W + (long)n * a.K, sb, rw.g, rw.cnt, m, v);
+        if (rw.cnt > 0) {
+            if (WK && a.q.wk) v = i8_add_outliers_k(a.q, a.q.wk + n, a.N, sb, rw.g, rw.cnt, m, v);
+            else v = i8_add_outliers(a.q, (const int8_t*)a.W + (long)n * a.K, sb, rw.g, rw.cnt, m, v);
+        }
         return v;
     } else {
         return rT<OT>((float)accv + bias);
