@@ -768,7 +768,7 @@ def main():
             try:
                 from sonicscribe_amd import synth as _synth
                 from sonicscribe_amd.asr import ASRModel
-                fm = ASRModel.from_synthetic(dims, seed=20260128, device=f"cuda:{device_index}", mode="native", max_batch=64, max_ctx=512, slots=3, continuous=True, decoders=2)
+                fm = ASRModel.from_synthetic(dims, seed=20260128, device=f"cuda:{device_index}", mode="native", max_batch=64, max_ctx=512, slots=4, continuous=True, decoders=3)
                 wavs = [(_synth.synth_pcm(i, SEG_SECONDS * 16000).astype(np.float32) / np.float32(32768.0))[None] for i in range(B)]
                 [f.result() for f in [fm.submit(w, 16000, a.max_new) for w in wavs]]                  # warm-up
                 t1 = time.perf_counter()
@@ -777,7 +777,7 @@ def main():
                 d1 = time.perf_counter() - t1
                 fm.close()
                 out["facade_bulk"] = {"value": 10 * B / d1, "unit": "20s-segments/sec", "segments": 10 * B, "wall_s": d1,
-                                      "note": "ASRModel(max_batch=64, slots=3, continuous=True, decoders=2).submit() x 320 host float tensors of 20 s, 150 tokens each: "
+                                      "note": "ASRModel(max_batch=64, slots=4, continuous=True, decoders=3).submit() x 320 host float tensors of 20 s, 150 tokens each: "
                                               "host-side normalisation, H2D, the bulk pipeline behind dispatch._ContinuousReplica, detokenised strings back; not the headline"}
             except Exception as ex:
                 out["facade_bulk"] = {"value": None, "note": f"not measured: {ex!r}"}

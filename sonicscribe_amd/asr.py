@@ -231,7 +231,7 @@ class ASRModel:
                 eng.set_option(k, int(v))
         self.model = self.models[0]                  # main.py:84-86 checks and deletes `.model`
         # continuous: `decoders` handles per replica run a greedy loop over max_batch rows each, the other handles prefill (>= 1).  Streaming:
-        # decoders=1, slots=2.  Bulk transcription of many segments: max_batch=64, decoders=2, slots=3 (the bench's pipeline shape).
+        # decoders=1, slots=2.  Bulk transcription of many segments: max_batch=64, decoders=3, slots=4 (the bench's pipeline shape since round 5; decoders=2, slots=3 before).
         self.continuous = bool(continuous)
         self.decoders = max(1, int(decoders)) if self.continuous else 0
         self.slots = max(self.decoders + 1 if self.continuous else 1, int(slots))
