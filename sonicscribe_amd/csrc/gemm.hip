@@ -693,7 +693,8 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
         asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t2) : "v"((lane ^ 32) << 2), "v"(t) : "memory");
         t = t + t2;
         const float sc = 1.0f / sqrtf(t / (float)K + nm.eps);            // lanes l and l + 32: the scale of row l
-        asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + (lane & 31) * 4), "v"(sc) : "memory");
+        // (a NaN whose bits equal the sentinel - NaN rows in, payload propagated - would read as "not yet": canonical NaN instead)
+        asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + (lane & 31) * 4), "v"(__float_as_uint(sc) == SENT ? 0x7FC00000u : __float_as_uint(sc)) : "memory");
     }
     KT(a, 1);
     if (NORM) {
@@ -710,7 +711,8 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(nw[kb * 2]), "=&v"(nw[kb * 2 + 1]) : "v"(nwlds + (kb * 64 + lc * 8) * 4) : "memory");
         {   // the row scales are there when no lane sees the sentinel (wave 0 wrote them ~1 us after entry)
             unsigned sv;
-            do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + (lane & 31) * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0);
+            int spins = 0;                             // (bounded: a wave 0 that never delivers must not hang the GPU; ~1 ms)
+            do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + (lane & 31) * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0 && ++spins < (1 << 16));
         }
 #pragma unroll
         for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));
@@ -958,7 +960,8 @@ __global__ __launch_bounds__(512) void skinny_gu64_kernel(SkinnyArgs a, T* act, 
             GU64_SS_SUM(0, ssv);
             GU64_SS_SUM(1, ssw);
 #undef GU64_SS_SUM
-            asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + lane * 4), "v"(lane < 32 ? sc[0] : sc[1]) : "memory");   // scale of row `lane`
+            const unsigned scb = __float_as_uint(lane < 32 ? sc[0] : sc[1]);            // scale of row `lane`
+            asm volatile("ds_write_b32 %0, %1" ::"v"(sclds + lane * 4), "v"(scb == SENT ? 0x7FC00000u : scb) : "memory");   // (a NaN with the sentinel's bits would read as "not yet")
         }
     }
     KTW(a, 1);
@@ -995,7 +998,8 @@ __global__ __launch_bounds__(512) void skinny_gu64_kernel(SkinnyArgs a, T* act, 
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(nw[kb * 2]), "=&v"(nw[kb * 2 + 1]) : "v"(nwlds + kb * 256 + lc * 32) : "memory");
         {   // the row scales are there when no lane sees the sentinel (wave 0 wrote them ~1 us after entry)
             unsigned sv;
-            do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + lane * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0);
+            int spins = 0;                             // (bounded: a wave 0 that never delivers must not hang the GPU; ~1 ms)
+            do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + lane * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0 && ++spins < (1 << 16));
         }
 #pragma unroll
         for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));
