@@ -60,6 +60,8 @@ struct LaunchOpts {
     int no_fused_gu = 0;       // decode: unfused o_proj / add+RMSNorm / gate-up path
     int no_fused_gu64 = 0;     // ... only for batches of 33 .. 64 rows (round 3's path there; A/B)
     int ktrace_wave = 0;       // in-kernel timeline of skinny_gu64_kernel: which wave stamps the inner points
+    int gu64_split_norm = 0;   // 33 .. 64 rows: RMSNorm by its own one-block-per-row kernel (rmsnorm_ss_kernel) + gate/up without the in-LDS norm.  0 = in the chunk graphs of
+                               // continuous decode loops only (they share the GPU by design: fewer CU-microseconds beat a shorter chain), 1 = always, -1 = never (A/B).  Same bits.
     int gu64_two_pass = 0;     // fused gate/up at 33 .. 64 rows: round 4's two passes of 32 rows instead of skinny_gu64_kernel (A/B)
     int o64_16rows = 0;        // fused o_proj at 33 .. 64 rows: 16-row blocks (round 4) instead of 32-row ones (A/B)
     int no_skinny48 = 0;       // decode skinny GEMM: never the 48-row x 512 blocks (A/B)

@@ -288,6 +288,39 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, 
     if (qo.q && !(dq.dbg & 2)) quant_emit_row<true>(yo, c < nv, c, row, qo, qpart, qparti);
 }
 
+// decode, 33 .. 64 rows: RMSNorm of the residual rows from the fused o_proj kernel's sum-of-squares partials - the arithmetic skinny_gu_kernel<NORM> does while it
+// stages X (same association of the partials: lane half h adds groups 16 h .. 16 h + 15 of a 2048-wide row in ascending order, then the halves are
+// added; same two roundings per element), once per row instead of once per gate/up block: at 64 rows that normalisation was ~9 us of VALU time on every
+// SIMD of 256 CUs.  One block per row, D / 8 threads.  SS: [region = row / 32][D / 64 groups][32 rows][4].
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_ss_kernel(const T* x, const float* SS, const float* w, T* y, int rows, int d, float eps) {
+    typedef typename ET<T>::v8 V8;
+    __shared__ float s_half[2], s_scale;
+    const int row = blockIdx.x, c = threadIdx.x, nv = d >> 3, ng = d >> 6, ssn = ng >> 1;
+    V8 t;
+    f32x4 w0, w1;
+    if (c < nv) { t = *(const V8*)(x + (long)row * d + c * 8); w0 = *(const f32x4*)(w + c * 8); w1 = *(const f32x4*)(w + c * 8 + 4); }
+    if (c < 2) {
+        const float* sp = SS + ((long)(row >> 5) * ng * 32 + (long)c * ssn * 32 + (row & 31)) * 4;
+        float th = 0.f;
+        for (int i = 0; i < ssn; ++i) { const f32x4 v = *(const f32x4*)(sp + (long)i * 128); th += v[0]; th += v[1]; th += v[2]; th += v[3]; }
+        s_half[c] = th;
+    }
+    __syncthreads();
+    if (c == 0) { const float tt = s_half[0] + s_half[1]; s_scale = 1.0f / sqrtf(tt / (float)d + eps); }
+    __syncthreads();
+    if (c < nv) {
+        const float rr = s_scale;
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = (T)(w0[j] * rT<T>((float)t[j] * rr)); o[4 + j] = (T)(w1[j] * rT<T>((float)t[4 + j] * rr)); }
+        *(V8*)(y + (long)row * d + c * 8) = o;
+    }
+}
+void launch_rmsnorm_ss(const bf16_t* x, const float* SS, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt) {
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(rmsnorm_ss_kernel<T>, dim3(rows), dim3(((d >> 3) + 63) / 64 * 64), 0, s, (const T*)x, SS, w, (T*)y, rows, d, eps));
+}
+
 // decode: act[r][c] = T(T(silu(T g)) * T u), gate/up rows interleaved in 16-row groups (as EPI_SWIGLU) or, gu8, in 8-row groups (the fused
 // gate/up kernel's weight copy, launch_tile_weights_gu8: the one decode copy of the projection since round 5)
 template <typename T>

@@ -52,6 +52,7 @@ struct sonic_engine {
     std::mutex mu;
     std::string err;
     std::vector<void*> allocs;
+    bool cap_svc = false;                           // a continuous loop's chunk graph is being captured (chunk_graph)
     int64_t weight_bytes = 0, alloc_bytes = 0;      // alloc_bytes: every live device allocation of this engine (sonic_memory_info)
     bool finalized = false;
 
@@ -1207,6 +1208,12 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1; oa.dt = dt; oa.kt = kt_slot(e, l, 2);
             launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
             SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt; ga.kt = kt_slot(e, l, 3);
+            if ((e->opts.gu64_split_norm > 0 || (e->opts.gu64_split_norm == 0 && e->cap_svc)) && R > 32 && D % 128 == 0 && D <= 2048) {
+                // 33 .. 64 rows: the rows are normalised ONCE by their own small kernel (from the same partials, in the same order: same bits) and
+                // gate/up stages them as they are - 256 blocks each normalising all 64 rows was the longest single piece of the 64-row step
+                launch_rmsnorm_ss(e->sx, e->ssq, L.ln2, e->shn, R, D, d.dec_rms_eps, e->st, dt);
+                ga.X = e->shn; launch_skinny_gu(ga, e->sact, e->st);
+            } else
             launch_skinny_gu_norm(ga, e->sact, e->ssq, D / 16, L.ln2, d.dec_rms_eps, e->st);
         } else {
         skinny(e, e->satt, e->QD, L.wo_t, e->slab, R, D, e->QD, &ks);
@@ -1455,17 +1462,22 @@ static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, co
 
 // A captured chunk of the greedy loop: `n` token steps for `R` rows as ONE hipGraph (kv_len / tok_pos / the token ids live on the device, so
 // the steps of a chunk need nothing from the host).
-static int chunk_graph(sonic_engine* e, int R, int n, hipGraphExec_t* out) {
-    auto it = e->graphs.find({R, n});
+// svc: the chunk belongs to a continuous decode loop (sonic_service_*), i.e. it runs beside a prefill slot and other loops by design - decode_step then
+// picks the forms that cost the fewest CU-microseconds rather than the shortest chain (gu64_split_norm).  Same bits either way; cached separately.
+static int chunk_graph(sonic_engine* e, int R, int n, hipGraphExec_t* out, bool svc = false) {
+    const std::pair<int, int> key{R + (svc ? 4096 : 0), n};
+    auto it = e->graphs.find(key);
     if (it != e->graphs.end()) { *out = it->second; return SONIC_OK; }
     hipGraph_t g = nullptr; hipGraphExec_t gx = nullptr;
     HIPC(e, hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
+    e->cap_svc = svc;
     for (int i = 0; i < n; ++i) decode_step(e, R, false);
+    e->cap_svc = false;
     HIPC(e, hipStreamEndCapture(e->st, &g));
     hipError_t r = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     HIPC(e, r);
-    e->graphs[{R, n}] = gx;
+    e->graphs[key] = gx;
     *out = gx;
     return SONIC_OK;
 }
@@ -1865,7 +1877,7 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     hipGraphExec_t gx = nullptr;                            // the chunk graphs exist before the first splice: nothing captures on this stream later
     for (int R = 16; ; R += 16) {                           // one per 16 rows (sonic_service_step runs as many rows as are occupied)
         const int r = R < e->Bm ? R : e->Bm;
-        TRY(chunk_graph(e, r, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx));
+        TRY(chunk_graph(e, r, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx, true));
         if (r >= e->Bm) break;
     }
     HIPC(e, stream_sync(e));
@@ -1954,7 +1966,7 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
                                                                                                             // behind the queue and finished rows are seen that many chunks late
             (void)hipGetLastError();
             hipGraphExec_t gx = nullptr;
-            TRY(chunk_graph(e, R, C, &gx));
+            TRY(chunk_graph(e, R, C, &gx, true));
             HIPC(e, hipGraphLaunch(gx, e->st));
             const int slot = (int)(e->svc_launched % CHK_RING);
             int* w = e->svc_h + (size_t)slot * SVC_WORDS;
@@ -2504,6 +2516,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "no_fused_gu")) { e->opts.no_fused_gu = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_fused_gu64")) { e->opts.no_fused_gu64 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "gu64_two_pass")) { e->opts.gu64_two_pass = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "gu64_split_norm")) { e->opts.gu64_split_norm = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "ktrace_wave")) { e->opts.ktrace_wave = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny768")) { e->opts.no_skinny768 = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "no_skinny48")) { e->opts.no_skinny48 = value; drop_graphs(e); return SONIC_OK; }

@@ -126,6 +126,7 @@ void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d,
                     const QuantActArgs* qa = nullptr);
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
                         int dt = DT_BF16, const DeqInfo* dq = nullptr, const QuantOut* qo = nullptr);
+void launch_rmsnorm_ss(const bf16_t* x, const float* SS, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt = DT_BF16);
 void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt = DT_BF16, int gu8 = 0);
 // int8 decode: int32 gate/up slabs (rows interleaved in 16-row groups as for EPI_SWIGLU) -> act (fp16) + its quantised form
 void launch_swiglu_quant(const float* P, int ksplit, int mpad, int ff, bf16_t* act, int rows, const DeqInfo& dq, const QuantOut& qo, hipStream_t s);

@@ -551,7 +551,8 @@ def test_fused_decode_rows_vs_unfused(R):
     if R > 32:
         # round 5: 33 .. 64 rows go through skinny_gu64_kernel (one sweep, four 16-row passes); round 4's two passes of 32 rows must give the same BITS
         # (and the fused o_proj's 32-row blocks the same bits as round 4's 16-row ones)
-        for opt in ("gu64_two_pass", "o64_16rows"):
+        # ... and the split form continuous loops use (RMSNorm by its own kernel from the same partials + gate/up without the in-LDS norm)
+        for opt in ("gu64_two_pass", "o64_16rows", "gu64_split_norm"):
             e.set_option(opt, 1)
             try:
                 ids_2, log_2 = e.transcribe_batch(segs, prompts, [n_new] * R, want_logits=True)
