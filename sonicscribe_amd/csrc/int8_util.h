@@ -353,9 +353,9 @@ __device__ __forceinline__ float i8_add_outliers(const GemmI8& q, const int8_t* 
     return rT<f16_t>(__fadd_rn(v, a2));
 }
 
-// the same sum with a stride between the k of one weight row: 1 = the row-major matrix (wc = W + n * K), N = the k-major copy (wc = wk + n) - the
-// prefill GEMMs of the decoder read the fragment-tiled weights since round 5 and their row-major int8 copy is gone.  (ONE loop for both: a second
-// copy of the list walk in every epilogue made the encoder's int8 fc1 kernel spill.)
+// the same sum with W[n][k] taken from the k-major copy (wc = wk + n, element k at wc[k * N]): the prefill GEMMs of the decoder read the fragment-tiled
+// weights since round 5 and their row-major int8 copy is gone.  Compiled only into the epilogues that can meet such an operand (gemm_lin<KD, WK>):
+// in the GELU epilogue the second list walk made the encoder's int8 fc1 kernel keep its accumulators in scratch.
 __device__ __forceinline__ float i8_add_outliers_k(const GemmI8& q, const int8_t* wc, int N, float sb, int g, int cnt, long m, float v) {
     const f16_t* xr = (const f16_t*)q.x16 + m * q.ldx16;
     float a2 = 0.f;
