@@ -13,8 +13,11 @@
 //     64-row loop stream the weights once).
 // No thread polls: every wait is a condition variable or a blocking HIP event inside the engine.  Only the C ABI of include/sonic_hip.h is used.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -52,6 +55,7 @@ struct sonic_pipeline {
     std::vector<std::shared_ptr<Batch>> all;             // every batch not yet collected by sonic_pipeline_wait (by ticket)
     std::vector<char> half;                              // per decoder: it has both running and free blocks
     int64_t next_ticket = 1, done_batches = 0, chunks = 0;
+    int64_t chunks_full = 0, chunks_part = 0; double prefill_wait_ms = 0, decoder_idle_ms = 0;   // diagnostics (SONIC_PIPE_STATS=1: printed by sonic_pipeline_destroy)
     bool stop = false;
     int failed = 0; std::string fail_msg;                // a decoding handle failed: nothing can complete any more
     std::string last_err;
@@ -87,7 +91,9 @@ void prefill_thread(sonic_pipeline* p, sonic_engine* h) {
         auto r = std::make_shared<Ready>(); r->b = b; r->src = h;
         p->ready.push_back(r);
         p->cv.notify_all();
+        const auto tw0 = std::chrono::steady_clock::now();
         p->cv.wait(lk, [&] { return r->taken || p->failed; });     // the handle's rows are the splice's source until a decoder has queued the copy
+        p->prefill_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         if (!r->taken) {                                            // the decode side died with this batch still in hand
             for (auto it = p->ready.begin(); it != p->ready.end(); ++it) if (*it == r) { p->ready.erase(it); break; }
             finish(p, b, p->failed, p->fail_msg);
@@ -143,7 +149,9 @@ void decode_thread(sonic_pipeline* p, int k) {
                     for (auto& b : p->all) if (b->status == -1) pending = true;
                     if (!pending) return;
                 }
+                const auto ti0 = std::chrono::steady_clock::now();
                 p->cv.wait(lk);
+                p->decoder_idle_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
             }
         }
         // ---- one chunk for the occupied rows; a second one before fetching when other blocks keep running
@@ -180,6 +188,7 @@ void decode_thread(sonic_pipeline* p, int k) {
         }
         std::unique_lock<std::mutex> lk(p->mu);
         p->chunks += steps;
+        (top == nb * B ? p->chunks_full : p->chunks_part) += steps;
     }
 }
 
@@ -281,6 +290,10 @@ SONIC_API int sonic_pipeline_destroy(sonic_pipeline* p) {
     }
     for (auto& t : p->threads) t.join();
     if (p->began) for (auto* d : p->dec) (void)sonic_service_end(d);
+    if (getenv("SONIC_PIPE_STATS"))
+        fprintf(stderr, "[sonic] pipeline: %lld batches, %lld chunks (%lld with every block of the loop occupied, %lld part-filled); prefill threads waited %.0f ms for a "
+                        "free block, decoding threads idled %.0f ms with nothing to step\n", (long long)p->done_batches, (long long)p->chunks, (long long)p->chunks_full,
+                (long long)p->chunks_part, p->prefill_wait_ms, p->decoder_idle_ms);
     delete p;
     return SONIC_OK;
 }
