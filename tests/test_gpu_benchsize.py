@@ -125,6 +125,9 @@ def test_bench_config_full_depth_vs_oracle(orc):
     B, n_new, n_samples = 32, 3, 320000
     e = Engine(d, 0, max_batch=B, max_ctx=512)
     e.load_synthetic(SEED)
+    # one copy of every decoder projection since round 5 (the prefill GEMMs read the decode step's fragment-tiled weights): the bf16 model's 2.25 G
+    # parameters + the tiled lm_head copy of the tied embedding + fp32 biases / norm weights - 4.21 GiB, where rounds 1-4 held 8.03
+    assert e.weight_bytes() < 4.35 * 2 ** 30, e.weight_bytes() / 2 ** 30
     segs = [synth.synth_pcm(i, n_samples) for i in range(B)]
     prompt = tiny_prompt(n_samples, d)
     rng = np.random.default_rng(31)

@@ -414,6 +414,7 @@ def test_int8_bench_config_full_depth_vs_oracle(orc):
     B, n_new, n_samples = 64, 2, 320000
     e = Engine(d, 0, MODE_INT8, max_batch=B, max_ctx=512)
     e.load_synthetic(SEED)
+    assert e.weight_bytes() < 3.7 * 2 ** 30, e.weight_bytes() / 2 ** 30      # round 5: the decoder's row-major int8 matrices are gone (3.60 GiB; 4.85 before)
     segs = [synth.synth_pcm(i, n_samples) for i in range(B)]
     prompt = _prompt(n_samples, d)
     rng = np.random.default_rng(77)
