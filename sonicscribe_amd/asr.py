@@ -177,7 +177,7 @@ class AudioStream:
 class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
                  cpu_threads: Optional[int] = None, cpu_interop_threads: Optional[int] = None,
-                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, continuous: bool = DEFAULT_CONTINUOUS, decoders: int = 1, _dims: Optional[ModelDims] = None,
+                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, continuous: bool = DEFAULT_CONTINUOUS, decoders: int = 1, bulk: bool = False, _dims: Optional[ModelDims] = None,
                  _synthetic_seed: Optional[int] = None, _allow_synthetic_prompt: bool = False, _options: Optional[Dict[str, int]] = None):
         if mode not in ["native", "int8"]:
             raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
@@ -232,12 +232,15 @@ class ASRModel:
         self.model = self.models[0]                  # main.py:84-86 checks and deletes `.model`
         # continuous: `decoders` handles per replica run a greedy loop over max_batch rows each, the other handles prefill (>= 1).  Streaming:
         # decoders=1, slots=2.  Bulk transcription of many segments: max_batch=64, decoders=3, slots=4 (the bench's pipeline shape since round 5; decoders=2, slots=3 before).
-        self.continuous = bool(continuous)
+        # bulk=True (file mode: deep queues of whole segments): the same handles behind the library's native pipeline (dispatch._BulkReplica ->
+        # csrc/pipeline.cpp); implies continuous decode loops.  max_batch=64, decoders=3, slots=4 is the bench's shape.
+        self.bulk = bool(bulk)
+        self.continuous = bool(continuous) or self.bulk
         self.decoders = max(1, int(decoders)) if self.continuous else 0
         self.slots = max(self.decoders + 1 if self.continuous else 1, int(slots))
         self._slot_engines = [[eng.slot() for _ in range(self.slots - 1)] for eng in self.models]     # same weights, further batches in flight
         self._dispatcher = Dispatcher(self.models, slots=self._slot_engines, continuous=self.continuous, decoders=self.decoders or 1,
-                                      adaptive_tiles="gemm_small_eff" not in (_options or {}))
+                                      adaptive_tiles="gemm_small_eff" not in (_options or {}), bulk=self.bulk)
         print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
               f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s), {self.slots} batch slot(s) each)")
 
@@ -338,7 +341,7 @@ class ASRModel:
         v = di["hip_runtime_version"]
         info.update({"cuda_version": f"HIP {v // 10000000}.{(v // 100000) % 100}.{v % 100000}", "gpu_name": di["name"],
                      "gpu_memory_total_mb": di["total_bytes"] / 1024 ** 2})
-        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])), "slots_per_replica": self.__dict__.get("slots", 1), "continuous": self.__dict__.get("continuous", False),
+        info.update({"engine": "sonicscribe_amd/gfx950", "replicas": len(self.__dict__.get("models", [])), "slots_per_replica": self.__dict__.get("slots", 1), "continuous": self.__dict__.get("continuous", False), "bulk": self.__dict__.get("bulk", False),
                      "weights_mb": self.model.weight_bytes() / 1024 ** 2 if hasattr(self, "model") else 0.0})
         return info
 

@@ -447,3 +447,80 @@ def test_bulk_pipeline_pairs_batches_and_checks_every_row():
     assert not pool.decoder.on and not dec2.on
     with pytest.raises(ValueError):
         ContinuousPipeline([], [pre])
+
+
+class StubNativePipeline:
+    """Stands in for pipeline.NativePipeline (the library's sonic_pipeline_*): tickets complete after `delay`, a batch that holds a 13-sample window
+    fails as a whole with the engine's message, rows 'decode' like StubEngine's."""
+
+    def __init__(self, decoders, prefills, block):
+        self.decoders, self.prefills, self.block = list(decoders), list(prefills), block
+        self.batches_in_flight = len(self.decoders) * 2 + len(self.prefills)
+        self.submitted, self.closed, self.delay = [], False, 0.002
+        self.results, self.lock = {}, threading.Lock()
+
+    def submit(self, prompts, max_new, segments=None, req_win=None):
+        if self.closed:
+            raise RuntimeError("pipeline is closed")
+        assert len(prompts) <= self.block and len(segments) <= self.block and req_win[0] == 0 and req_win[-1] == len(segments)
+        with self.lock:
+            t = len(self.submitted) + 1
+            self.submitted.append((len(segments), list(max_new)))
+        rows, err = [], None
+        for r in range(len(prompts)):
+            w = segments[req_win[r]:req_win[r + 1]]
+            if any(len(x) == 13 for x in w):
+                err = RuntimeError("Audio features and audio tokens do not match")
+            rows.append(np.asarray([int(sum(int(x.sum()) for x in w)) % 1000, len(prompts[r]), max_new[r]], np.int32))
+        self.results[t] = (time.perf_counter() + self.delay, rows, err)
+        return t
+
+    def wait(self, ticket):
+        due, rows, err = self.results.pop(ticket)
+        time.sleep(max(0.0, due - time.perf_counter()))
+        if err is not None:
+            raise err
+        return rows
+
+    def close(self):
+        self.closed = True
+
+
+def test_bulk_replica_groups_requests_into_native_pipeline_batches():
+    """Dispatcher(bulk=True) -> dispatch._BulkReplica: requests become batches of up to `block` windows (oldest first, one step class per batch), go to
+    the (stub) native pipeline, and every future gets its own row back; a request that fails its batch fails alone; close() drains."""
+    eng, slots = StubEngine(max_batch=64), [StubEngine(64) for _ in range(3)]
+    d = Dispatcher([eng], slots=[slots], bulk=True, decoders=3, pipeline_factory=StubNativePipeline)
+    rep = d.replicas[0]
+    pipe = rep.pipe
+    assert len(pipe.decoders) == 3 and len(pipe.prefills) == 1 and pipe.block == 32
+    fs = [d.submit([seg(i)], [1, 2, 3], 150) for i in range(80)] + [d.submit([seg(200 + i)], [1], 15) for i in range(5)]
+    for i, f in enumerate(fs[:80]):
+        assert f.result(timeout=10).tolist() == [(i * 16) % 1000, 3, 150]
+    for i, f in enumerate(fs[80:]):
+        assert f.result(timeout=10).tolist() == [((200 + i) * 16) % 1000, 1, 15]
+    sizes = [n for n, _ in pipe.submitted]
+    assert sum(sizes) == 85 and max(sizes) <= 32 and len(sizes) <= 6                       # full blocks while the queue is deep
+    assert all(len(set(mn)) == 1 for _, mn in pipe.submitted)                              # a 15-token request never rides a 150-token batch
+    # one bad request (the engine's validation error fails the whole ticket): its neighbours are resubmitted one by one and succeed
+    n0 = len(pipe.submitted)
+    good = [d.submit([seg(3)], [1], 150), d.submit([seg(4)], [1], 150)]
+    bad = d.submit([seg(5, n=13)], [1], 150)
+    assert [f.result(timeout=10).tolist() for f in good] == [[48, 1, 150], [64, 1, 150]]
+    with pytest.raises(RuntimeError, match="do not match"):
+        bad.result(timeout=10)
+    assert len(pipe.submitted) >= n0 + 1
+    # a multi-window request keeps its windows together; one that cannot fit into a block is refused
+    two = d.submit([seg(1), seg(2)], [1, 2], 150)
+    assert two.result(timeout=10).tolist() == [48, 2, 150]
+    with pytest.raises(ValueError, match="windows"):
+        d.submit([seg(1)] * 33, [1], 150).result(timeout=10)
+    with pytest.raises(TypeError):
+        d.submit([object()], [1], 150)                                                     # device ring slices belong to the row-level dispatcher
+    t0 = time.perf_counter()
+    d.close()
+    assert time.perf_counter() - t0 < 5.0 and pipe.closed and not any(t.is_alive() for t in rep.threads)
+    with pytest.raises(RuntimeError):
+        d.submit([seg(1)], [1], 150)
+    with pytest.raises(ValueError):
+        Dispatcher([StubEngine(64)], slots=[[StubEngine(64)]], bulk=True, decoders=3, pipeline_factory=StubNativePipeline)   # no prefill slot left

@@ -220,6 +220,32 @@ def test_asrmodel_two_decoders_of_64_rows_bulk_shape():
     ref.close(); bulk.close()
 
 
+def test_asrmodel_bulk_mode_runs_on_the_native_pipeline():
+    """ASRModel(bulk=True): the facade's file mode behind the LIBRARY's pipeline (dispatch._BulkReplica -> pipeline.NativePipeline -> csrc/pipeline.cpp):
+    three decoding handles over 64 rows + one prefill slot on one weight copy; 200 requests of mixed length and budget (two step classes, a
+    two-window request, a bad one) from the caller's thread - every transcript equal to the one-slot batch model's, the bad request fails alone."""
+    from sonicscribe_amd.asr import ASRModel
+    from sonicscribe_amd.dispatch import _BulkReplica
+    d = replace(spec.TINY, eos_ids=())
+    ref = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=1024, slots=1, continuous=False)
+    bulk = ASRModel.from_synthetic(d, device="cuda:0", max_batch=64, max_ctx=1024, slots=4, decoders=3, bulk=True)
+    rep = bulk._dispatcher.replicas[0]
+    assert isinstance(rep, _BulkReplica) and len(rep.pipe.decoders) == 3 and len(rep.pipe.prefills) == 1 and bulk.get_model_info()["continuous"] is True
+    wavs = [synth.synth_pcm(1500 + i, 16000 * (1 + i % 5)).astype(np.float32) / 32768.0 for i in range(50)]
+    wavs[7] = synth.synth_pcm(1507, 16000 * 34).astype(np.float32) / 32768.0                  # 34 s: two 30 s windows in one request
+    budgets = [(8 + (i * 11) % 8) if i % 3 == 0 else (20 + (i * 7) % 40) for i in range(50)]   # step classes <= 16 and <= 64
+    want = [ref.transcribe(w[None], 16000, max_new_tokens=b) for w, b in zip(wavs, budgets)]
+    futs = [bulk.submit(wavs[i % 50][None], 16000, budgets[i % 50]) for i in range(200)]
+    got = [f.result(timeout=300) for f in futs]
+    assert got == [want[i % 50] for i in range(200)]
+    st = rep.pipe.stats()
+    assert st["batches"] >= 200 // 32 and rep.load() == 0
+    with pytest.raises(Exception):
+        bulk.submit(wavs[0][None], 16000, 2000).result(timeout=60)                            # prompt + budget beyond max_ctx: fails alone ...
+    assert bulk.submit(wavs[1][None], 16000, budgets[1]).result(timeout=60) == want[1]        # ... and the pipeline goes on
+    ref.close(); bulk.close()
+
+
 @pytest.mark.parametrize("dims", [replace(spec.TINY, eos_ids=()), FULLW], ids=["tiny", "fullwidth"])
 def test_back_to_back_enqueued_prefills_keep_their_own_plans(dims):
     """sonic_prefill_enqueue returns with the prompt plan's host-to-device copies still queued behind the encoder; a second enqueue on
