@@ -39,7 +39,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table (tests/test_host_logic.py checks
  * `nm -D` against this header).  SONIC_ABI_VERSION moves whenever a signature or a struct layout below changes. */
 #define SONIC_API __attribute__((visibility("default")))
-#define SONIC_ABI_VERSION 6
+#define SONIC_ABI_VERSION 7
 SONIC_API int sonic_abi_version(void);
 
 typedef struct sonic_engine sonic_engine;
@@ -120,6 +120,8 @@ SONIC_API int sonic_memory_info(sonic_engine* e, int64_t* allocated_bytes, int64
  * sonic_slot_count: the owner plus its live slots. */
 SONIC_API int sonic_slot_create(sonic_engine* owner_or_slot, sonic_engine** slot_out);
 SONIC_API int sonic_slot_count(sonic_engine* e);
+/* row / context capacity, mode, device and the identity of the weight copy (equal for an engine and all of its slots) of a handle; any out pointer may be NULL */
+SONIC_API int sonic_engine_info(sonic_engine* e, int32_t* max_batch, int32_t* max_ctx, int32_t* mode, int32_t* device_id, const void** weights_id);
 
 /* ---- the bulk pipeline as native threads (round 5) ----
  * What sonicscribe_amd/pipeline.py's host loop does (round 4: Python threads over the calls above, polling) inside the library: one thread per

@@ -207,6 +207,8 @@ struct SkinnyArgs {
     const float* x_amax;             // i8 only, optional: X holds the UNQUANTISED fp16 rows and x_amax[row][0..3] partial maxima (written by the
                                      // producer's blocks) of their absmax without the elements >= 6.0: the kernel quantises its X slice while
                                      // staging it - int8 = rn(x * 127 / absmax), 0 for outliers (LLM.int8 row-wise)
+    int* err;                        // optional device error word (engine: n_active[1]): a kernel that gives up on an in-kernel wait ORs 1 into it; the greedy
+                                     // kernel turns it into a negative running-row count, which every host-side check reads as a failed step
     long long* kt;                   // diagnostics: per-block timestamps [block][8] (100 MHz wall clock), null in production
     int kt_thread;                   // ... the thread that stamps the inner points of skinny_gu64_kernel (0, 64 .. 448: one wave's view each; option ktrace_wave)
 };

@@ -607,6 +607,9 @@ __global__ __launch_bounds__(1024) void greedy_kernel(GreedyArgs a) {
             for (int e = 0; e < a.n_eos; ++e) stop |= (tok == a.eos[e]);
             if (stop) { a.finished[b] = 1; atomicSub(a.n_active, 1); } else running = true;
         }
+        // device error word (SkinnyArgs.err = n_active[1]): a kernel of this step gave up on an in-kernel wait, its outputs are garbage.  The count of
+        // running rows goes (and stays) far below zero: the loop stops at its next check and the host fails the batch (DEV_ERR_ACTIVE in engine.cpp)
+        if (a.dev_err && b == 0 && *a.dev_err) atomicMin(a.n_active, -(1 << 24));
         // Only a row that keeps running advances its context.  A finished row stays where it is (its later steps rewrite the same
         // cache slot and are discarded), so kv_len never exceeds prompt + max_new - 1 < max_ctx whatever the other rows' budgets are:
         // before, a [long prompt, small budget] row riding a [short prompt, large budget] batch walked past its cache region.

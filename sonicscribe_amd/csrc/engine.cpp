@@ -24,6 +24,7 @@
 
 #define T_PAD_ALIGN 64
 #define CHK_RING 64            // check events / pinned n_active words of the decode loop
+#define DEV_ERR_ACTIVE (-(1 << 23))   // a running-row count below this: the device error word was set (greedy_kernel), the step's outputs are invalid
 #define SVC_WORDS 132           // per check of the continuous loop: finished[64], n_new[64], n_active, padding
 #define CHK_MAX_AHEAD 32       // deepest lookahead in chunks (a host that is frozen for tens of ms at a time - CPU quota, a busy event loop)
 
@@ -645,6 +646,17 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     *out = e;
     return SONIC_OK;
 }
+// what a caller that was handed engine pointers (sonic_pipeline_create) has to know about them: row capacity, context capacity, mode, device and
+// the identity of the weight copy (the owner's address: equal for an engine and all of its slots)
+extern "C" int sonic_engine_info(sonic_engine* e, int32_t* max_batch, int32_t* max_ctx, int32_t* mode, int32_t* device_id, const void** weights_id) {
+    if (!e) return SONIC_ERR_INVALID;
+    if (max_batch) *max_batch = e->Bm;
+    if (max_ctx) *max_ctx = e->max_ctx;
+    if (mode) *mode = e->mode;
+    if (device_id) *device_id = e->device;
+    if (weights_id) *weights_id = e->owner ? (const void*)e->owner : (const void*)e;
+    return SONIC_OK;
+}
 extern "C" int sonic_slot_count(sonic_engine* e) {
     if (!e) return 0;
     sonic_engine* root = e->owner ? e->owner : e;
@@ -1173,7 +1185,7 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     GreedyArgs g{};
     g.logits = e->lslab; g.ksplit = skinny_pick_ksplit(d.vocab, d.dec_d); g.mpad = ((R + 15) / 16) * 16; g.V = d.vocab; g.B = R; g.table = e->embed; g.x = e->sx; g.d = d.dec_d;
     g.out_ids = e->out_ids; g.out_ld = e->out_cap; g.n_new = e->n_new; g.finished = e->finished; g.kv_len = e->kv_len; g.tok_pos = e->tok_pos;
-    g.max_new = e->max_new_d; g.n_active = e->n_active; g.n_eos = d.n_eos; g.pad_id = d.n_eos > 0 ? d.eos[0] : 0;
+    g.max_new = e->max_new_d; g.n_active = e->n_active; g.dev_err = e->n_active + 1; g.n_eos = d.n_eos; g.pad_id = d.n_eos > 0 ? d.eos[0] : 0;
     for (int i = 0; i < d.n_eos; ++i) g.eos[i] = d.eos[i];
     g.logits_dump = dump ? e->dump : nullptr; g.dump_stride_step = (long)R * d.vocab; g.step_counter = dump ? e->step_ctr : nullptr;
     g.norm_w = e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
@@ -1207,7 +1219,7 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             // two kernels instead of o_proj, add+RMSNorm, gate/up, SwiGLU
             SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1; oa.dt = dt; oa.kt = kt_slot(e, l, 2);
             launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
-            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt; ga.kt = kt_slot(e, l, 3);
+            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt; ga.kt = kt_slot(e, l, 3); ga.err = e->n_active + 1;
             if ((e->opts.gu64_split_norm > 0 || (e->opts.gu64_split_norm == 0 && e->cap_svc)) && R > 32 && D % 128 == 0 && D <= 2048) {
                 // 33 .. 64 rows: the rows are normalised ONCE by their own small kernel (from the same partials, in the same order: same bits) and
                 // gate/up stages them as they are - 256 blocks each normalising all 64 rows was the longest single piece of the 64-row step
@@ -1499,7 +1511,7 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
     const int C = e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1;
     int done = 0;
     int launched = 0, checked = 0, last_grow = 0;   // chunks queued with a check behind them / checks the host has read
-    bool all_stopped = false, starved = false;
+    bool all_stopped = false, starved = false, dev_err = false;
     typedef std::chrono::steady_clock clk;
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     auto read_check = [&](bool block) -> int {  // 1: read (all_stopped updated), 0: not complete yet, < 0: error
@@ -1507,6 +1519,7 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
         if (!block) { const hipError_t q = hipEventQuery(e->chk_ev[i]); if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; } if (q != hipSuccess) return -1; }
         else { const auto t_w = clk::now(); if (hipEventSynchronize(e->chk_ev[i]) != hipSuccess) return -1; e->host_wait_ms += ms_since(t_w); }
         if (e->n_active_h[i] <= 0) all_stopped = true;
+        if (e->n_active_h[i] < DEV_ERR_ACTIVE) dev_err = true;
         ++checked;
         return 1;
     };
@@ -1545,6 +1558,7 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
         }
     }
     e->run_starved = e->run_starved || starved;
+    if (dev_err) return fail(e, SONIC_ERR_HIP, "a decode kernel gave up on an in-kernel wait: the batch's tokens are invalid");
     if (!all_stopped && done >= n_steps && e->steps_run + 1 < e->max_steps) {
         // the caller asked for fewer steps than the budget (sonic_decode_step) and synchronises next: read the outstanding checks now
         while (!all_stopped && checked < launched) if (read_check(true) < 0) return fail(e, SONIC_ERR_HIP, "decode loop: check event failed");
@@ -1953,6 +1967,7 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
         const int* w = e->svc_h + (size_t)i * SVC_WORDS;
         memcpy(e->svc_fin, w, 64 * 4); memcpy(e->svc_nn, w + 64, 64 * 4); e->svc_active = w[128];
         e->svc_seq = ++e->svc_checked;
+        if (e->svc_active < DEV_ERR_ACTIVE) return -2;
         return 1;
     };
     for (int c = 0; c <= n_chunks; ++c) {
@@ -1976,6 +1991,7 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
         }
         while (e->svc_checked < e->svc_launched) {
             const int r = read_check(e->svc_launched - e->svc_checked > e->lookahead);
+            if (r == -2) return fail(e, SONIC_ERR_HIP, "continuous decode loop: a decode kernel gave up on an in-kernel wait, the rows' tokens are invalid");
             if (r < 0) return fail(e, SONIC_ERR_HIP, "continuous decode loop: check event failed: %s", hipGetErrorString(hipGetLastError()));
             if (r == 0) break;
         }
@@ -2135,11 +2151,14 @@ static int fetch_locked(sonic_engine* e, int32_t* out_ids, int out_ld, int32_t* 
     const int R = e->R;
     if (R < 1) return fail(e, SONIC_ERR_INVALID, "nothing to fetch");
     std::vector<int> nn(64), kvl(64), tps(64), fin(64);
+    int act_err[2] = {0, 0};
+    HIPC(e, d2h_async(e, act_err, e->n_active, 2 * 4));
     HIPC(e, d2h_async(e, nn.data(), e->n_new, 64 * 4));
     HIPC(e, d2h_async(e, kvl.data(), e->kv_len, 64 * 4));
     HIPC(e, d2h_async(e, tps.data(), e->tok_pos, 64 * 4));
     HIPC(e, d2h_async(e, fin.data(), e->finished, 64 * 4));
     HIPC(e, stream_sync(e));
+    if (act_err[1] != 0) return fail(e, SONIC_ERR_HIP, "a decode kernel gave up on an in-kernel wait (device error word %d): the batch's tokens are invalid", act_err[1]);
     // invariants of the greedy controller: a running row's context grows by one per launch; a finished row stopped growing with the
     // launch that finished it (kv_len = prompt + tokens - 1), so no row ever leaves its [max_ctx] cache region
     for (int r = 0; r < R && r < (int)e->last_qlen.size(); ++r) {
@@ -2550,6 +2569,13 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
         if (value >= 0 && !e->kt) { TRY(dalloc(e, &e->kt, (size_t)8 * KT_SLOT_BLOCKS * 8)); }
         if (e->kt) zero_fill(e, e->kt, (size_t)8 * KT_SLOT_BLOCKS * 8 * 8);
         e->kt_layer = value; drop_graphs(e); return SONIC_OK;
+    }
+    if (!strcmp(key, "inject_dev_err")) {      // tests: set (1) / clear (0) the device error word a decode kernel raises when it gives up on an in-kernel wait
+        HIPC(e, hipSetDevice(e->device));
+        const int v = value ? 1 : 0;
+        HIPC(e, hipMemcpyAsync(e->n_active + 1, &v, 4, hipMemcpyHostToDevice, e->st));
+        HIPC(e, stream_sync(e));
+        return SONIC_OK;
     }
     if (!strcmp(key, "no_gelu_lut")) { e->opt_no_gelu_lut = value; return SONIC_OK; }      // GELU by arithmetic instead of the LDS table (A/B)
     return fail(e, SONIC_ERR_INVALID, "unknown option %s", key);

@@ -713,6 +713,8 @@ __global__ __launch_bounds__(512) void skinny_gu_kernel(SkinnyArgs a, T* act, in
             unsigned sv;
             int spins = 0;                             // (bounded: a wave 0 that never delivers must not hang the GPU; ~1 ms)
             do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + (lane & 31) * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0 && ++spins < (1 << 16));
+            // timed out: the sentinel (a NaN) would be used as the row scale - say so where the host looks
+            if (spins >= (1 << 16) && lane == 0 && a.err) atomicOr(a.err, 1);
         }
 #pragma unroll
         for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));
@@ -1000,6 +1002,8 @@ __global__ __launch_bounds__(512) void skinny_gu64_kernel(SkinnyArgs a, T* act, 
             unsigned sv;
             int spins = 0;                             // (bounded: a wave 0 that never delivers must not hang the GPU; ~1 ms)
             do { asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(sclds + lane * 4) : "memory"); } while (__builtin_amdgcn_ballot_w64(sv == SENT) != 0 && ++spins < (1 << 16));
+            // timed out: the sentinel (a NaN) would be used as the row scale - say so where the host looks
+            if (spins >= (1 << 16) && lane == 0 && a.err) atomicOr(a.err, 1);
         }
 #pragma unroll
         for (int i = 0; i < KBW * 2; ++i) asm volatile("" : "+v"(nw[i]));

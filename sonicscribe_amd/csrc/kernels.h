@@ -98,6 +98,7 @@ struct GreedyArgs {
     int* tok_pos;          // [B] position of the next token
     const int* max_new;    // [B]
     int* n_active;         // [1] rows still running (host polls)
+    const int* dev_err;    // optional: device error word; non-zero turns n_active negative (the host fails the batch)
     int eos[8]; int n_eos; int pad_id;
     float* logits_dump; long dump_stride_step; int* step_counter;  // optional: bf16-rounded logits per step [step][B][V]; counter per row [B]
     const float* norm_w; float norm_eps; bf16_t* y;   // optional: y[B][d] = RMSNorm(x) with the first decoder layer's input norm

@@ -78,7 +78,13 @@ void prefill_thread(sonic_pipeline* p, sonic_engine* h) {
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->cv.wait(lk, [&] { return p->stop || p->failed || !p->queue.empty(); });
-            if (p->failed) { while (!p->queue.empty()) { finish(p, p->queue.front(), p->failed, p->fail_msg); p->queue.pop_front(); } }
+            if (p->failed) {
+                // a decoding handle failed: submits are refused from now on (sonic_pipeline_submit returns p->failed), so what is queued is all there
+                // will ever be - fail it and sleep until destroy (the predicate above stays true, a `continue` here would spin)
+                while (!p->queue.empty()) { finish(p, p->queue.front(), p->failed, p->fail_msg); p->queue.pop_front(); }
+                p->cv.wait(lk, [&] { return p->stop; });
+                return;
+            }
             if (p->queue.empty()) { if (p->stop) return; continue; }
             b = p->queue.front(); p->queue.pop_front();
         }
@@ -201,6 +207,19 @@ SONIC_API int sonic_pipeline_create(sonic_engine* const* decoders, int n_dec, so
     if (!out) return SONIC_ERR_INVALID;
     *out = nullptr;
     if (!decoders || !prefills || n_dec < 1 || n_pre < 1 || block < 1 || block > 64 || rows_per_decoder < block || rows_per_decoder > 64) return SONIC_ERR_INVALID;
+    // every handle once, all on one weight copy and one device; a decoding handle holds rows_per_decoder rows, a prefill handle one block
+    {
+        const void* w0 = nullptr; int32_t dev0 = -1;
+        for (int i = 0; i < n_dec + n_pre; ++i) {
+            sonic_engine* h = i < n_dec ? decoders[i] : prefills[i - n_dec];
+            int32_t mb = 0, dev = 0; const void* wid = nullptr;
+            if (!h || sonic_engine_info(h, &mb, nullptr, nullptr, &dev, &wid) != SONIC_OK) return SONIC_ERR_INVALID;
+            for (int j = 0; j < i; ++j) if (h == (j < n_dec ? decoders[j] : prefills[j - n_dec])) return SONIC_ERR_INVALID;
+            if (i == 0) { w0 = wid; dev0 = dev; }
+            if (wid != w0 || dev != dev0) return SONIC_ERR_INVALID;
+            if (mb < (i < n_dec ? rows_per_decoder : block)) return SONIC_ERR_INVALID;
+        }
+    }
     sonic_pipeline* p = new sonic_pipeline();
     p->dec.assign(decoders, decoders + n_dec); p->pre.assign(prefills, prefills + n_pre);
     p->block = block; p->blocks_per_dec = rows_per_decoder / block;
@@ -278,7 +297,14 @@ SONIC_API int sonic_pipeline_stats(sonic_pipeline* p, int64_t* batches_done, int
     return SONIC_OK;
 }
 
-SONIC_API const char* sonic_pipeline_last_error(sonic_pipeline* p) { return p ? p->last_err.c_str() : ""; }
+// the message is copied under the lock into a buffer of the calling thread (other threads go on writing p->last_err)
+SONIC_API const char* sonic_pipeline_last_error(sonic_pipeline* p) {
+    static thread_local std::string mine;
+    if (!p) return "";
+    std::unique_lock<std::mutex> lk(p->mu);
+    mine = p->last_err;
+    return mine.c_str();
+}
 
 // waits for what was submitted, stops the threads, takes the decoding handles out of continuous mode (the handles themselves stay the caller's)
 SONIC_API int sonic_pipeline_destroy(sonic_pipeline* p) {

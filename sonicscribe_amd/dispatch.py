@@ -417,6 +417,7 @@ class _BulkReplica:
         self.max_in_flight = self.pipe.batches_in_flight + 2          # tickets submitted and not yet complete (bounds the host memory of a deep queue)
         self.q: List[Request] = []
         self.inflight: List[Any] = []                                 # (ticket, batch) in submission order
+        self.submitting = 0                                           # batches taken from q and not yet in `inflight` (inside pipe.submit)
         self.cv = threading.Condition()
         self.stop = False
         self.batches = 0
@@ -473,31 +474,39 @@ class _BulkReplica:
             with self.cv:
                 while not self.stop and (not self.q or len(self.inflight) >= self.max_in_flight):
                     self.cv.wait()
-                if self.stop and not self.q:
+                if self.stop:                                         # close() has failed what was still queued; nothing new is submitted
                     return
-                if sum(len(r.windows) for r in self.q) < self.block and not self.stop:
+                if sum(len(r.windows) for r in self.q) < self.block:
                     self.cv.wait(self.linger_s)                       # a bulk submission arrives request by request: give the batch a moment to fill
+                    if self.stop:
+                        return
                 batch = self._take()
+                if batch:
+                    self.submitting += 1                              # the complete loop must not leave while this batch is between q and inflight
             if not batch:
                 continue
             try:
                 ticket = self._submit(batch)
             except BaseException as ex:                               # refused at submission (closed pipeline, bad arguments): nobody else is affected
+                with self.cv:
+                    self.submitting -= 1
+                    self.cv.notify_all()
                 for r in batch:
                     self._finish(r, error=ex)
                 continue
             with self.cv:
                 self.inflight.append((ticket, batch))
+                self.submitting -= 1
                 self.batches += 1
                 self.cv.notify_all()
 
     def _complete_loop(self):
         while True:
             with self.cv:
-                while not self.inflight and not (self.stop and not self.q):
+                while not self.inflight and not (self.stop and self.submitting == 0):
                     self.cv.wait()
                 if not self.inflight:
-                    return
+                    return                                            # stopped, nothing in flight, nothing on its way into `inflight`
                 ticket, batch = self.inflight[0]
             try:
                 rows = self.pipe.wait(ticket)
@@ -521,15 +530,18 @@ class _BulkReplica:
                         self._finish(r, error=ex2)
 
     def close(self):
+        """Requests still queued fail at once (as in _ContinuousReplica.close); batches already handed to the pipeline - including one that is
+        inside pipe.submit right now - complete normally.  The native pipeline is destroyed only after both threads have left it."""
         with self.cv:
             self.stop = True
+            queued, self.q = self.q, []
             self.cv.notify_all()
-        for t in self.threads:
-            t.join(timeout=60)
-        self.pipe.close()
-        for r in self.q:
-            if not r.future.done():
+        for r in queued:
+            if not r.future.done() and r.future.set_running_or_notify_cancel():
                 r.future.set_exception(RuntimeError("ASR engine is closed"))
+        for t in self.threads:
+            t.join()                                                  # bounded by the batches in flight (at most max_in_flight), not by the queue
+        self.pipe.close()
 
 
 class Dispatcher:

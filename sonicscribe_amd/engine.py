@@ -31,10 +31,10 @@ EXPORTS = [
     "sonic_prefill", "sonic_decode_step", "sonic_device_info", "sonic_memory_info",
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
     "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_fetch_rows", "sonic_prefill_enqueue",
-    "sonic_runtime_info",
+    "sonic_runtime_info", "sonic_engine_info",
     "sonic_pipeline_create", "sonic_pipeline_submit", "sonic_pipeline_wait", "sonic_pipeline_stats", "sonic_pipeline_last_error", "sonic_pipeline_destroy",
 ]
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SonicDims(C.Structure):
@@ -144,6 +144,7 @@ def load_library():
     lib.sonic_test_linear_int8.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.sonic_slot_create.argtypes = [vp, C.POINTER(vp)]
     lib.sonic_slot_count.argtypes = [vp]
+    lib.sonic_engine_info.argtypes = [vp, ip, ip, ip, ip, C.POINTER(vp)]
     lib.sonic_run_staged_async.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
     lib.sonic_wait.argtypes = [vp, C.c_int, ip]
     lib.sonic_service_begin.argtypes = [vp]
@@ -257,6 +258,13 @@ class Engine:
 
     def slot_count(self) -> int:
         return int(self.lib.sonic_slot_count(self.h))
+
+    def info(self) -> dict:
+        """sonic_engine_info: what the library says about this handle (row / context capacity, mode, device, identity of its weight copy)."""
+        v = [C.c_int32() for _ in range(4)]
+        w = C.c_void_p()
+        self._check(self.lib.sonic_engine_info(self.h, *[C.byref(x) for x in v], C.byref(w)))
+        return {"max_batch": v[0].value, "max_ctx": v[1].value, "mode": v[2].value, "device": v[3].value, "weights_id": w.value}
 
     # -- plumbing
     def _check(self, rc: int):

@@ -524,3 +524,29 @@ def test_bulk_replica_groups_requests_into_native_pipeline_batches():
         d.submit([seg(1)], [1], 150)
     with pytest.raises(ValueError):
         Dispatcher([StubEngine(64)], slots=[[StubEngine(64)]], bulk=True, decoders=3, pipeline_factory=StubNativePipeline)   # no prefill slot left
+
+
+def test_bulk_replica_close_while_a_batch_is_inside_submit():
+    """close() 50 ms after 32 submits while pipe.submit takes 0.2 s.  The batch is between `q` and `inflight` when stop is set: the
+    complete loop must stay until it has been waited for; requests still queued fail at once; no future is left pending and no thread survives."""
+    class SlowSubmit(StubNativePipeline):
+        def submit(self, *a, **k):
+            time.sleep(0.2)
+            return super().submit(*a, **k)
+
+    for trial in range(3):
+        d = Dispatcher([StubEngine(64)], slots=[[StubEngine(64) for _ in range(3)]], bulk=True, decoders=3, pipeline_factory=SlowSubmit)
+        rep = d.replicas[0]
+        fs = [d.submit([seg(i)], [1], 150) for i in range(32)] + [d.submit([seg(100 + i)], [1], 15) for i in range(4)]
+        time.sleep(0.05)
+        d.close()
+        assert not any(t.is_alive() for t in rep.threads) and rep.pipe.closed
+        done = 0
+        for i, f in enumerate(fs):
+            assert f.done(), f"future {i} left pending by close() (trial {trial})"
+            if f.exception() is None:
+                assert f.result().tolist() == [((i if i < 32 else 68 + i) * 16) % 1000, 1, 150 if i < 32 else 15]
+                done += 1
+            else:
+                assert "closed" in str(f.exception())
+        assert done >= 32                                                  # the batch that was being submitted completed normally

@@ -83,3 +83,52 @@ def test_a_bad_request_fails_alone_and_destroy_completes_the_rest():
     pipe.close()
     assert all(np.array_equal(keep[2][r, :7], solo[r][:7]) and keep[3][r] == 7 for r in range(4))
     eng.close()
+
+
+def test_create_validates_handles_and_a_device_error_fails_the_batch_loudly():
+    """sonic_pipeline_create checks rows_per_decoder against every decoding handle's capacity, refuses a handle passed twice and handles of
+    different weight copies (sonic_engine_info); a decode kernel that gives up on an in-kernel wait raises the device error word, which turns the
+    step's running-row count negative - the batch (and, in a continuous loop, the pipeline) fails with a message instead of returning garbage."""
+    import ctypes as C
+    from sonicscribe_amd.engine import Engine
+    from sonicscribe_amd.pipeline import NativePipeline
+    dims = replace(spec.TINY, eos_ids=())
+    eng = Engine(dims, 0, 0, max_batch=4, max_ctx=512)
+    eng.load_synthetic(SEED)
+    pre = eng.slot()
+    other = Engine(dims, 0, 0, max_batch=4, max_ctx=512)
+    other.load_synthetic(SEED)
+    info = eng.info()
+    assert info["max_batch"] == 4 and info["max_ctx"] == 512 and info["mode"] == 0 and info["weights_id"] == pre.info()["weights_id"] != other.info()["weights_id"]
+    lib = eng.lib
+
+    def create(dec, prefills, block, rows):
+        d = (C.c_void_p * len(dec))(*[x.h for x in dec]); p = (C.c_void_p * len(prefills))(*[x.h for x in prefills]); h = C.c_void_p()
+        rc = lib.sonic_pipeline_create(d, len(dec), p, len(prefills), block, rows, C.byref(h))
+        if rc == 0:
+            lib.sonic_pipeline_destroy(h)
+        return rc
+    assert create([eng], [pre], 4, 4) == 0
+    assert create([eng], [pre], 4, 8) != 0            # rows_per_decoder above the handle's max_batch
+    assert create([eng], [eng], 4, 4) != 0            # one handle as decoder and prefill slot
+    assert create([eng], [other], 4, 4) != 0          # another weight copy
+    # device error word
+    seg = synth.synth_pcm(900, 16000 * 3)
+    prompt = prompt_for(dims, len(seg))
+    good = pre.transcribe_batch([seg], [prompt], [6])[0][0]
+    pre._set_option("inject_dev_err", 1)
+    with pytest.raises(RuntimeError, match="in-kernel wait"):
+        pre.transcribe_batch([seg], [prompt], [6])
+    pre._set_option("inject_dev_err", 0)
+    assert np.array_equal(pre.transcribe_batch([seg], [prompt], [6])[0][0], good)
+    pipe = NativePipeline([eng], [pre], block=4)
+    assert np.array_equal(pipe.wait(pipe.submit([prompt], [6], segments=[seg]))[0], good)
+    eng._set_option("inject_dev_err", 1)
+    t = pipe.submit([prompt], [30], segments=[seg])
+    with pytest.raises(RuntimeError, match="in-kernel wait"):
+        pipe.wait(t)
+    with pytest.raises(RuntimeError):
+        pipe.submit([prompt], [6], segments=[seg])   # a failed pipeline refuses new work; its prefill threads sleep until close (no spin)
+    pipe.close()
+    eng._set_option("inject_dev_err", 0)
+    other.close(); eng.close()
