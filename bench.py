@@ -59,6 +59,25 @@ BATCH = 32
 MAX_NEW = 150           # min(50 + 5*20, 200), transcription_manager.py:37
 SINGLE5_NEW = 75        # the same rule for a 5 s final (BASELINE config 1's segment)
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+DECODE_CHUNK_STEPS = 2      # token steps per captured decode graph (engine default, option decode_chunk)
+
+
+def segment_flops(d, prompt_len: int) -> dict:
+    """Algorithmic FLOPs of one segment: conv stem + encoder layers + projector (`encoder`, with its GEMM / attention split) and the prompt
+    forward of the decoder (`prefill`: every linear over prompt_len tokens, causal attention, lm_head on the last position)."""
+    T2, T = d.n_frames, d.enc_T
+    conv = 2.0 * T2 * d.enc_d * 3 * d.n_mels + 2.0 * T * d.enc_d * 3 * d.enc_d
+    qkvo = 4 * 2.0 * T * d.enc_d * d.enc_d
+    att = 2 * 2.0 * T * T * d.enc_d
+    mlp = 2 * 2.0 * T * d.enc_d * d.enc_ff
+    ta = T // d.merge
+    proj = ta * 2.0 * (d.proj_in * d.proj_mid + d.proj_mid * d.dec_d)      # linear_1: merge * enc_d -> 2 * dec_d, linear_2 -> dec_d
+    enc_gemm = conv + d.enc_layers * (qkvo + mlp) + proj
+    enc_att = d.enc_layers * att
+    qd, kvd = d.dec_heads * d.dec_head_dim, d.dec_kv_heads * d.dec_head_dim
+    lin = d.dec_layers * (d.dec_d * (qd + 2 * kvd) + qd * d.dec_d + 3 * d.dec_d * d.dec_ff)
+    pre = 2.0 * prompt_len * lin + d.dec_layers * 2 * 2.0 * (prompt_len * (prompt_len + 1) / 2) * qd + 2.0 * d.vocab * d.dec_d
+    return {"encoder": enc_gemm + enc_att, "encoder_gemm": enc_gemm, "encoder_attention": enc_att, "prefill": pre}
 
 
 def host_cpu_quota():
@@ -483,6 +502,10 @@ def main():
             raise SystemExit("--pipeline rows must be a multiple of --batch and at most 64")
     eng = Engine(dims, device_index, MODE_INT8 if a.mode == "int8" else MODE_NATIVE, max_batch=max(B, pipe_cfg[1]) if pipe_cfg else B, max_ctx=512)
     eng.load_synthetic(20260128)
+    global DECODE_CHUNK_STEPS
+    for kv in a.opt:
+        if kv.startswith("decode_chunk="):
+            DECODE_CHUNK_STEPS = max(1, min(64, int(kv.split("=")[1])))
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
@@ -660,6 +683,34 @@ def main():
         kv_bytes = B * d_.dec_layers * 2 * kvd * 2 * avg_ctx
         dec_ms = stage["decode_ms"] / a.steps / n_dec
         dec_gbs = (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        # Headline leg, honest accounting: a decode loop streams the weights ONCE per token step whatever number of its rows are
+        # occupied (two batches of 32 in one 64-row loop share them), every batch reads its own KV.  The steps the loops really ran are counted by
+        # the pipeline (decode chunks queued x steps per chunk); without the pipeline every batch runs its own chain.
+        if pipe_info:
+            loop_steps = pipe_info["decode_chunks_queued"] * max(1, DECODE_CHUNK_STEPS)
+            dec_bytes_leg = loop_steps * w_bytes + a.steps * n_dec * kv_bytes
+            if_note = (f"{loop_steps} decode-loop token steps queued by the pipeline x weight bytes (once per loop step, shared by the batches riding the loop) + "
+                       f"{a.steps} batches x {n_dec} steps x KV bytes, over the wall time of the headline leg (encoder and prefill of other batches run concurrently)")
+        else:
+            loop_steps = a.steps * n_dec
+            dec_bytes_leg = loop_steps * (w_bytes + kv_bytes)
+            if_note = "every batch runs its own chain: algorithmic decode bytes of all timed batches / wall time of the headline leg"
+        in_flight_obj = {"batches_in_flight": in_flight_n, "achieved": dec_bytes_leg / dt / 1e9, "unit": "GB/s", "frac": dec_bytes_leg / dt / 1e9 / PEAK_HBM_GBS,
+                         "decode_loop_steps": loop_steps, "bytes": dec_bytes_leg, "note": if_note}
+        # whole step against the two rooflines it is made of: encoder + projector + prefill on the matrix pipe, the decode loop + mel on HBM;
+        # the serial bound adds them (nothing overlaps), the overlapped bound takes the larger one
+        seg_flops = segment_flops(d_, len(prompt))
+        mfma_ms = B * (seg_flops["encoder"] + seg_flops["prefill"]) / (PEAK_BF16_TFLOPS * (2.0 if a.mode == "int8" else 1.0) * 1e12) * 1e3
+        hbm_bytes_batch = dec_bytes_leg / a.steps + B * (n_samples * 2 + 128 * 3000 * 2)
+        hbm_ms = hbm_bytes_batch / (PEAK_HBM_GBS * 1e9) * 1e3
+        whole_step = {"mfma_ms_at_peak": mfma_ms, "hbm_ms_at_peak": hbm_ms, "measured_ms_per_step": dt / a.steps * 1e3,
+                      "serial_bound_ms": mfma_ms + hbm_ms, "overlapped_bound_ms": max(mfma_ms, hbm_ms),
+                      "frac_of_serial_bound": (mfma_ms + hbm_ms) / (dt / a.steps * 1e3), "frac_of_overlapped_bound": max(mfma_ms, hbm_ms) / (dt / a.steps * 1e3),
+                      "flops_per_batch": B * (seg_flops["encoder"] + seg_flops["prefill"]), "hbm_bytes_per_batch": hbm_bytes_batch,
+                      "mfma_frac_in_leg": B * (seg_flops["encoder"] + seg_flops["prefill"]) / (dt / a.steps) / 1e12 / (PEAK_BF16_TFLOPS * (2.0 if a.mode == "int8" else 1.0)),
+                      "segment_flops": seg_flops,
+                      "note": "per batch of the headline leg: FLOPs of encoder + projector + prompt forward at the dense MFMA peak, decode-loop + log-mel bytes at the HBM peak "
+                              "(weights charged once per decode-loop step), against the measured wall time per batch"}
         out = {
             "metric": "20s-segments/sec/node + RTF, GLM-ASR-Nano bf16, batch=32, 1/2/4/8 MI355X" if a.mode == "native" and B == BATCH else
                       f"20s-segments/sec/node + RTF, GLM-ASR-Nano {a.mode}, batch={B} (BASELINE config {4 if a.mode == 'int8' else 2} variant)",
@@ -693,6 +744,7 @@ def main():
             "batches_in_flight_slots": {"value": value_slots, "unit": "20s-segments/sec", "ms_per_step": dt_slots / a.steps * 1e3, "steps": a.steps, "slots": n_slots,
                                         "bit_identical_to_single_batch": slots_identical},
             "stages_ms_per_step": {k: stage[k] / a.steps for k in ("mel_ms", "encoder_ms", "prefill_ms", "decode_ms")},
+            "whole_step": whole_step,
             # The time-dominant part of a step is the greedy decode loop (~2/3 of it): every token step streams the decoder's weights,
             # the tied lm_head and each sequence's KV cache exactly once -- HBM-bound.  One "launch" here is one token step (one hipGraph
             # replay of the captured kernel chain); its duration is measured live: HIP events on the engine stream around the decode
@@ -703,18 +755,23 @@ def main():
                          "measured_in": "single_batch leg (the chain alone on the GPU); in_flight below is the whole-GPU rate of the headline leg",
                          # headline leg: every batch streams the same algorithmic decode bytes; divided by the WHOLE wall time (encoder and prefill
                          # of the other slot included), i.e. a lower bound of the HBM rate while several chains overlap
-                         "in_flight": {"batches_in_flight": in_flight_n, "achieved": a.steps * n_dec * (w_bytes + kv_bytes) / dt / 1e9, "unit": "GB/s",
-                                       "frac": a.steps * n_dec * (w_bytes + kv_bytes) / dt / 1e9 / PEAK_HBM_GBS,
-                                       "note": "algorithmic decode bytes of all timed batches / wall time of the headline leg"},
+                         "in_flight": in_flight_obj,
                          "bytes_per_launch": w_bytes + kv_bytes, "avg_launch_ms": dec_ms, "launches_timed": n_dec * a.steps,
                          "algorithmic_bytes": {"weights": w_bytes, "kv_cache_avg": kv_bytes}},
         }
-        for prof in ("round5_pmc_decode.json", "round4_pmc_decode.json", "round3_pmc_decode.json", "round2_pmc_decode.json"):     # newest committed PMC passes; labelled with their own commit
+        # `traffic`: HBM bytes per launch (= per token step) from the PMC counters.  Counters cannot be read inside this run (rocprofv3 --pmc serialises the
+        # kernels); the value is the newest committed pass of THIS command line's decode chain (tools/round_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate
+        # runs, FETCH_SIZE doubled as the guide prescribes for gfx950), taken at the same --max-new so the contexts match; a pass of another batch size, mode
+        # or token budget is quoted under traffic_from_profile only and `traffic` stays null
+        for prof in ("round6_pmc_decode.json", "round5_pmc_decode.json", "round4_pmc_decode.json", "round3_pmc_decode.json", "round2_pmc_decode.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     pm = json.load(f)
-                out["roofline"]["traffic_from_profile"] = {k: pm[k] for k in ("hbm_bytes_per_token_step", "fetch_bytes_x2", "write_bytes", "note", "source", "commit") if k in pm}
+                out["roofline"]["traffic_from_profile"] = {k: pm[k] for k in ("hbm_bytes_per_token_step", "fetch_bytes_x2", "write_bytes", "note", "source", "commit", "max_new", "batch", "mode") if k in pm}
                 out["roofline"]["traffic_from_profile"]["file"] = "profiles/" + prof
+                if pm.get("max_new") == a.max_new and pm.get("batch", BATCH) == B and pm.get("mode", "native") == a.mode and a.dims == "full":
+                    out["roofline"]["traffic"] = pm["hbm_bytes_per_token_step"]
+                    out["roofline"]["traffic_over_algorithmic"] = pm["hbm_bytes_per_token_step"] / (w_bytes + kv_bytes)
                 break
             except Exception:
                 pass

@@ -61,7 +61,12 @@ enum { SONIC_MODE_NATIVE = 0 /* bf16, asr.py mode="native" */, SONIC_MODE_INT8 =
         * the fused decode kernels skinny_o / skinny_gu the bf16 headline runs), no quantisation.  Not an asr.py mode: it exists so that layouts,
         * epilogues, RoPE, masking, KV append and the greedy controller can be checked at fp16's 8x finer rounding against the reference's fp32
         * arithmetic (tests/test_gpu_fp16_mode.py) */
-       SONIC_MODE_F16 = 2 };
+       SONIC_MODE_F16 = 2,
+       /* test only: the fp32 KIND of every stage (csrc/f32kind.hip) - fp32 weights, activations and accumulation behind the same request plan, PCM
+        * staging, log-mel kernel, prompt assembly, KV bookkeeping and greedy controller (greedy_kernel<float>).  It exists to show north_star's
+        * "within 1e-3 on logits" literally on the GPU (tests/test_gpu_fp32_mode.py against tests/golden/\*_fp32.npz); the product kinds keep the
+        * reference's bf16 / fp16 op-boundary roundings and cannot.  No slots, no continuous decoding, no graphs; speed is irrelevant. */
+       SONIC_MODE_F32 = 3 };
 enum { SONIC_DTYPE_F32 = 0, SONIC_DTYPE_BF16 = 1 };
 
 /* Model dimensions (defaults: HF:configuration_glmasr.py:44-54,86-103). */

@@ -18,7 +18,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 // Activation / weight element type of an engine: bf16 (mode "native", asr.py:61) or IEEE half (mode "int8": the reference runs its
 // non-quantised ops in torch.float16, asr.py:61,296).  Buffers are typed bf16_t* throughout the host code (2-byte storage); kernels
 // are templated on T and reinterpret.  DT_* is the runtime tag the launchers switch on.
-enum { DT_BF16 = 0, DT_F16 = 1 };
+enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };   // DT_F32: only the greedy controller is instantiated for it (SONIC_MODE_F32, f32kind.hip)
 template <typename T> struct ET;
 template <> struct ET<bf16_t> {
     typedef bf16x8 v8; typedef bf16x4 v4; typedef bf16x2 v2;
@@ -28,6 +28,8 @@ template <> struct ET<f16_t> {
     typedef f16x8 v8; typedef f16x4 v4; typedef f16x2 v2;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <> struct ET<float> { typedef f32x8 v8; typedef f32x4 v4; };
 template <typename T> __device__ __forceinline__ float rT(float x) { return (float)((T)x); }   // round-trip through the element type (RNE)
 // fp16: the fp32 value must exist before it is rounded to half.  Without the barrier hipcc folds `fma -> f16` into one
 // v_fma_mixlo_f16 (a single rounding of the exact result); torch / CUDA round the op's fp32 result and then convert (two roundings),

@@ -694,7 +694,7 @@ __global__ void synth_fill_kernel(unsigned long long key, long n, float scale, f
     const float r = __fsub_rn(__fmul_rn((float)bits, 0x1p-23f), 1.0f);
     const float v = __fadd_rn(offset, __fmul_rn(r, scale));
     if (out_bf) out_bf[i] = f2bf(v);
-    if (out_f32) out_f32[i] = rbf(v);
+    if (out_f32) out_f32[i] = out_bf ? rbf(v) : v;      // fp32 alone: the generator's exact value (synth.synth_fill(..., bf16=False))
 }
 
 // ---------------------------------------------------------------- launchers
@@ -744,6 +744,7 @@ void launch_assemble_embeds(const int* src, const bf16_t* table, const bf16_t* a
     if (n_tok > 0) hipLaunchKernelGGL(assemble_embeds_kernel, dim3(n_tok), dim3(256), 0, s, src, table, audio, x, n_tok, d);
 }
 void launch_greedy(const GreedyArgs& a, hipStream_t s) {
+    if (a.dt == DT_F32) { hipLaunchKernelGGL(greedy_kernel<float>, dim3(a.B), dim3(1024), 0, s, a); return; }   // SONIC_MODE_F32: fp32 logits, table and rows
     DT_SWITCH(a.dt, T, hipLaunchKernelGGL(greedy_kernel<T>, dim3(a.B), dim3(1024), 0, s, a));
 }
 void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s, int dt) {

@@ -44,11 +44,28 @@ struct DecLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *wgu, *wdown;          /
                    bf16_t *wqkv_t, *wo_t, *wgu_t, *wgu_t8, *wdown_t;                    // fragment-tiled copies (decode skinny GEMM)
                    QW qqkv, qo, qgu, qdown; };
 
+// SONIC_MODE_F32 (test only, f32kind.hip): fp32 weights as loaded (torch Linear layout, nothing packed but the conv taps) and fp32 activation buffers
+struct F32EncL { float *ln1w, *ln1b, *wq, *bq, *wk, *wv, *bv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2; };
+struct F32DecL { float *ln1, *wq, *wk, *wv, *wo, *ln2, *wg, *wu, *wd; };
+struct F32State {
+    std::map<std::string, float*> raw;               // name -> device tensor (owned by the engine's alloc list)
+    float *conv1w = nullptr, *conv1b = nullptr, *conv2w = nullptr, *conv2b = nullptr, *enc_nw = nullptr, *enc_nb = nullptr;
+    float *pj1w = nullptr, *pj1b = nullptr, *pj2w = nullptr, *pj2b = nullptr, *embed = nullptr, *dec_nw = nullptr;
+    std::vector<F32EncL> enc; std::vector<F32DecL> dec;
+    // encoder: time-major padded features, conv1 output (padded), residual stream, norm output, q / k / v, attention output, MLP, projector
+    float *featT = nullptr, *h1 = nullptr, *x = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *ff = nullptr, *ph = nullptr, *pe = nullptr;
+    // decoder: token rows of the prefill (or the R rows of a token step), KV cache [layer][seq][ctx][KD], logits [64][vocab]
+    float *dx = nullptr, *dhn = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *datt = nullptr, *dg = nullptr, *du = nullptr, *dact = nullptr;
+    float *Kc = nullptr, *Vc = nullptr, *logits = nullptr, *hlast = nullptr;
+};
+
 struct sonic_engine {
     sonic_dims d;
     int device = 0, mode = 0, Bm = 0, max_ctx = 0;
     int dt = DT_BF16;          // activation / 16-bit weight element type: bf16 (native) or fp16 (int8 mode, asr.py:61)
     bool i8 = false;           // LLM.int8 linears
+    bool f32 = false;          // SONIC_MODE_F32: the fp32 kind of every stage (test only; F32State, f32kind.hip)
+    F32State* f = nullptr;
     hipStream_t st = nullptr;
     std::mutex mu;
     std::string err;
@@ -346,7 +363,7 @@ static int build_constants(sonic_engine* e) {
     e->lc = LogmelConst{dwin, dct, dst, dlo, dcnt, doff, dw};
 
     // RoPE tables: cos/sin computed in fp32 and cast to the activation dtype (modeling_glmasr.py:95-106)
-    auto round_act = [&](float x) -> float { return e->dt == DT_F16 ? (float)(_Float16)x : bf16_round_host(x); };
+    auto round_act = [&](float x) -> float { return e->f32 ? x : e->dt == DT_F16 ? (float)(_Float16)x : bf16_round_host(x); };
     auto rope_table = [&](int n_pos, int rd, float theta, float** out) -> int {
         const int half = rd / 2;
         std::vector<float> t((size_t)n_pos * rd);
@@ -503,6 +520,7 @@ static hipError_t create_stream(hipStream_t* st) {
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 // Everything an engine (or a slot) owns besides weights and constants: its stream, PCM staging, activation buffers, KV cache, decode-step
+static int f32_alloc(sonic_engine* e);
 // buffers, control words, events.
 static int alloc_state(sonic_engine* e) {
     if (hipSetDevice(e->device) != hipSuccess) { e->err = "hipSetDevice failed"; return SONIC_ERR_HIP; }
@@ -593,7 +611,7 @@ static int alloc_state(sonic_engine* e) {
 extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int max_batch, int max_ctx, sonic_engine** out) {
     if (!dims || !out) return fail(nullptr, SONIC_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8 && mode != SONIC_MODE_F16) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
+    if (mode != SONIC_MODE_NATIVE && mode != SONIC_MODE_INT8 && mode != SONIC_MODE_F16 && mode != SONIC_MODE_F32) return fail(nullptr, SONIC_ERR_INVALID, "mode must be either 'native' or 'int8'");
     g_opts = LaunchOpts{};
     TRY(check_dims(*dims, max_batch, max_ctx, mode));
     if (mode == SONIC_MODE_INT8 && (dims->dec_ff > 8192 || dims->enc_d % 128 || dims->enc_ff % 128 || (dims->dec_heads * dims->dec_head_dim) % 128))
@@ -606,7 +624,10 @@ extern "C" int sonic_create(const sonic_dims* dims, int device_id, int mode, int
     if (const char* v = getenv("SONIC_KEEP_ROWMAJOR")) e->opt_prefill_rowmajor = atoi(v) >= 2;   // =2: keep the row-major decoder weights AND read them (A/B of whole test runs)
     e->d = *dims; e->device = device_id; e->mode = mode; e->Bm = max_batch; e->max_ctx = max_ctx;
     e->i8 = mode == SONIC_MODE_INT8; e->dt = (e->i8 || mode == SONIC_MODE_F16) ? DT_F16 : DT_BF16;
+    e->f32 = mode == SONIC_MODE_F32;
+    if (e->f32) e->f = new F32State();
     int s = alloc_state(e);
+    if (s == SONIC_OK && e->f32) s = f32_alloc(e);
     if (s == SONIC_OK) s = build_constants(e);
     if (s == SONIC_OK && stream_sync(e) != hipSuccess) { e->err = "stream sync failed"; s = SONIC_ERR_HIP; }
     if (s != SONIC_OK) { g_create_err = e->err; sonic_destroy(e); return s; }
@@ -626,6 +647,7 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     std::lock_guard<std::mutex> lk(root->mu);
     (void)hipGetLastError();
     if (!root->finalized) return fail(nullptr, SONIC_ERR_INVALID, "sonic_slot_create needs an engine whose weights are finalized");
+    if (root->f32) return fail(nullptr, SONIC_ERR_UNSUPPORTED, "SONIC_MODE_F32 is a test kind: no slots");
     g_opts = root->opts;
     sonic_engine* e = new sonic_engine();
     e->d = root->d; e->device = root->device; e->mode = root->mode; e->Bm = root->Bm; e->max_ctx = root->max_ctx; e->i8 = root->i8; e->dt = root->dt;
@@ -705,6 +727,7 @@ extern "C" void sonic_destroy(sonic_engine* e) {
     if (e->sync_ev) (void)hipEventDestroy(e->sync_ev);
     for (auto& v : e->gemm_ev) if (v) (void)hipEventDestroy(v);
     if (e->st) (void)hipStreamDestroy(e->st);
+    delete e->f;                                        // (its device buffers were in e->allocs)
     delete e;
 }
 
@@ -776,6 +799,22 @@ extern "C" int sonic_load_tensor(sonic_engine* e, const char* name, const void* 
     bool known = false;
     for (auto& it : inventory(e->d)) if (it.name == name) { known = true; if (it.shape != shp) return fail(e, SONIC_ERR_INVALID, "tensor %s: unexpected shape", name); }
     if (!known) return fail(e, SONIC_ERR_INVALID, "unknown tensor name %s", name);
+    if (e->f32) {      // fp32 kind: the tensor stays fp32 (a bf16 source is widened exactly)
+        const size_t n = numel(shp);
+        float*& dst = e->f->raw[name];
+        if (!dst) TRY(dalloc(e, &dst, n, false));
+        if (dtype == SONIC_DTYPE_F32) HIPC(e, h2d(e, dst, data, n * 4));
+        else if (dtype == SONIC_DTYPE_BF16) {
+            bf16_t* tmp = nullptr;
+            HIPC(e, hipMalloc((void**)&tmp, n * 2));
+            hipError_t r = h2d(e, tmp, data, n * 2);
+            if (r == hipSuccess) { launch_bf16_to_f32(tmp, dst, (long)n, e->st, DT_BF16); r = stream_sync(e); }
+            (void)hipFree(tmp);
+            HIPC(e, r);
+        } else return fail(e, SONIC_ERR_INVALID, "dtype must be f32 or bf16");
+        e->weight_bytes += (int64_t)n * 4;
+        return SONIC_OK;
+    }
     DevTensor* t;
     TRY(raw_alloc(e, name, shp, &t));
     if (dtype == SONIC_DTYPE_BF16) {
@@ -797,14 +836,17 @@ extern "C" int sonic_load_synthetic(sonic_engine* e, uint64_t seed) {
     ENTER(e);
     if (e->finalized) return fail(e, SONIC_ERR_INVALID, "weights already finalized");
     for (auto& it : inventory(e->d)) {
-        DevTensor* t;
-        TRY(raw_alloc(e, it.name, it.shape, &t));
+        DevTensor* t = nullptr;
+        float* t32 = nullptr;
+        if (e->f32) { float*& dst = e->f->raw[it.name]; if (!dst) TRY(dalloc(e, &dst, numel(it.shape), false)); t32 = dst; e->weight_bytes += (int64_t)numel(it.shape) * 4; }
+        else TRY(raw_alloc(e, it.name, it.shape, &t));
         float scale = 0.1f, offset = 0.f;
         if (it.kind == 0) { double fi = 1; for (size_t i = 1; i < it.shape.size(); ++i) fi *= (double)it.shape[i]; scale = (float)sqrt(3.0 / fi); }
         else if (it.kind == 1) scale = (float)sqrt(3.0 / (double)it.shape[1]);
         else if (it.kind == 3) offset = 1.0f;
         const uint64_t key = mix64h(seed * 0x9E3779B97F4A7C15ULL + fnv1a64h(it.name.c_str()));
-        launch_synth_fill(key, (long)t->n, scale, offset, t->p, nullptr, e->st);
+        if (e->f32) launch_synth_fill(key, (long)numel(it.shape), scale, offset, nullptr, t32, e->st);     // the generator's exact fp32 values (synth.py bf16=False)
+        else launch_synth_fill(key, (long)t->n, scale, offset, t->p, nullptr, e->st);
     }
     HIPC(e, stream_sync(e));
     return SONIC_OK;
@@ -866,10 +908,12 @@ static int keep_raw(sonic_engine* e, const std::string& name, bf16_t** out) {
     return SONIC_OK;
 }
 
+static int f32_finalize(sonic_engine* e);
 extern "C" int sonic_finalize_weights(sonic_engine* e) {
     if (!e) return SONIC_ERR_INVALID;
     ENTER(e);
     if (e->finalized) return SONIC_OK;
+    if (e->f32) return f32_finalize(e);
     const sonic_dims& d = e->d;
     const std::string at = "model.audio_tower.", pj = "model.multi_modal_projector.", lm = "model.language_model.";
     e->weight_bytes = 0;
@@ -1188,7 +1232,7 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
     g.max_new = e->max_new_d; g.n_active = e->n_active; g.dev_err = e->n_active + 1; g.n_eos = d.n_eos; g.pad_id = d.n_eos > 0 ? d.eos[0] : 0;
     for (int i = 0; i < d.n_eos; ++i) g.eos[i] = d.eos[i];
     g.logits_dump = dump ? e->dump : nullptr; g.dump_stride_step = (long)R * d.vocab; g.step_counter = dump ? e->step_ctr : nullptr;
-    g.norm_w = e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
+    g.norm_w = e->dec.empty() ? nullptr : e->dec[0].ln1; g.norm_eps = d.dec_rms_eps; g.y = e->dec.empty() ? nullptr : e->shn;        // the next step's first RMSNorm rides along (d <= 8192)
     g.force_ids = e->force_d; g.force_ld = e->force_ld;
     g.dt = e->dt;
     if (e->i8) g.qo = QuantOut{e->hn_q, d.dec_d, e->sca_hn, e->oc_hn, e->ol_hn, d.dec_d, e->ov_hn};     // layer 0's q/k/v input, quantised
@@ -1197,7 +1241,9 @@ static GreedyArgs greedy_args(sonic_engine* e, int R, bool dump) {
 
 // one decode step for R rows: sx ([R][d]) -> next token (generation/utils.py:2876-2943)
 static void decode_step_i8(sonic_engine* e, int R, bool dump);
+static void decode_step_f32(sonic_engine* e, int R, bool dump);
 static void decode_step(sonic_engine* e, int R, bool dump) {
+    if (e->f32) { decode_step_f32(e, R, dump); return; }
     if (e->i8) { decode_step_i8(e, R, dump); return; }
     const sonic_dims& d = e->d;
     const int D = d.dec_d, mpad = ((R + 15) / 16) * 16, dt = e->dt;
@@ -1414,6 +1460,200 @@ static int run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
     return SONIC_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ SONIC_MODE_F32 (test only): fp32 stages, f32kind.hip
+// The request plan (plan_requests), PCM staging, the log-mel kernel, the control words (kv_len / tok_pos / n_new / finished / out_ids / step logits dump /
+// teacher forcing) and the greedy controller (greedy_kernel<float>) are the engine's own; what is different is the arithmetic between them.
+static int f32_alloc(sonic_engine* e) {
+    F32State& f = *e->f;
+    const sonic_dims& d = e->d;
+    const int Bm = e->Bm, C = d.enc_d;
+    const size_t M = (size_t)Bm * e->T, tc = (size_t)e->tok_cap + 64;
+    int s;
+#define A(x) do { s = (x); if (s != SONIC_OK) return s; } while (0)
+    A(dalloc(e, &f.featT, (size_t)Bm * (d.n_frames + 2) * d.n_mels + 4 * (size_t)d.n_mels)); A(dalloc(e, &f.h1, (size_t)Bm * (d.n_frames + 2) * C + 4 * (size_t)C));
+    A(dalloc(e, &f.x, M * C)); A(dalloc(e, &f.ln, M * C)); A(dalloc(e, &f.q, M * C)); A(dalloc(e, &f.k, M * C)); A(dalloc(e, &f.v, M * C)); A(dalloc(e, &f.att, M * C));
+    A(dalloc(e, &f.ff, M * d.enc_ff)); A(dalloc(e, &f.ph, (size_t)Bm * e->Ta * 2 * d.dec_d)); A(dalloc(e, &f.pe, (size_t)Bm * e->Ta * d.dec_d));
+    A(dalloc(e, &f.dx, tc * d.dec_d)); A(dalloc(e, &f.dhn, tc * d.dec_d)); A(dalloc(e, &f.dq, tc * e->QD)); A(dalloc(e, &f.dk, tc * e->KD)); A(dalloc(e, &f.dv, tc * e->KD));
+    A(dalloc(e, &f.datt, tc * e->QD)); A(dalloc(e, &f.dg, tc * d.dec_ff)); A(dalloc(e, &f.du, tc * d.dec_ff)); A(dalloc(e, &f.dact, tc * d.dec_ff));
+    const size_t kvn = (size_t)d.dec_layers * Bm * e->max_ctx * e->KD;
+    A(dalloc(e, &f.Kc, kvn)); A(dalloc(e, &f.Vc, kvn));
+    A(dalloc(e, &f.logits, (size_t)64 * d.vocab)); A(dalloc(e, &f.hlast, (size_t)64 * d.dec_d));
+#undef A
+    return SONIC_OK;
+}
+static int f32_finalize(sonic_engine* e) {
+    F32State& f = *e->f;
+    const sonic_dims& d = e->d;
+    const std::string at = "model.audio_tower.", pj = "model.multi_modal_projector.", lm = "model.language_model.";
+    auto get = [&](const std::string& name, float** out) -> int {
+        auto it = f.raw.find(name);
+        if (it == f.raw.end() || !it->second) return fail(e, SONIC_ERR_INVALID, "missing weight tensor %s", name.c_str());
+        *out = it->second;
+        return SONIC_OK;
+    };
+    float *c1 = nullptr, *c2 = nullptr;
+    TRY(get(at + "conv1.weight", &c1)); TRY(get(at + "conv2.weight", &c2));
+    TRY(dalloc(e, &f.conv1w, (size_t)d.enc_d * d.n_mels * 3, false)); TRY(dalloc(e, &f.conv2w, (size_t)d.enc_d * d.enc_d * 3, false));
+    launch_f32_conv_w(c1, f.conv1w, d.enc_d, d.n_mels, e->st); launch_f32_conv_w(c2, f.conv2w, d.enc_d, d.enc_d, e->st);   // [C][Ci][3] -> tap-major [C][3][Ci]
+    TRY(get(at + "conv1.bias", &f.conv1b)); TRY(get(at + "conv2.bias", &f.conv2b));
+    f.enc.resize(d.enc_layers);
+    for (int i = 0; i < d.enc_layers; ++i) {
+        const std::string p = at + "layers." + std::to_string(i) + ".";
+        F32EncL& L = f.enc[i];
+        TRY(get(p + "input_layernorm.weight", &L.ln1w)); TRY(get(p + "input_layernorm.bias", &L.ln1b));
+        TRY(get(p + "self_attn.q_proj.weight", &L.wq)); TRY(get(p + "self_attn.q_proj.bias", &L.bq)); TRY(get(p + "self_attn.k_proj.weight", &L.wk));
+        TRY(get(p + "self_attn.v_proj.weight", &L.wv)); TRY(get(p + "self_attn.v_proj.bias", &L.bv));
+        TRY(get(p + "self_attn.o_proj.weight", &L.wo)); TRY(get(p + "self_attn.o_proj.bias", &L.bo));
+        TRY(get(p + "post_attention_layernorm.weight", &L.ln2w)); TRY(get(p + "post_attention_layernorm.bias", &L.ln2b));
+        TRY(get(p + "mlp.fc1.weight", &L.w1)); TRY(get(p + "mlp.fc1.bias", &L.b1)); TRY(get(p + "mlp.fc2.weight", &L.w2)); TRY(get(p + "mlp.fc2.bias", &L.b2));
+    }
+    TRY(get(at + "norm.weight", &f.enc_nw)); TRY(get(at + "norm.bias", &f.enc_nb));
+    TRY(get(pj + "linear_1.weight", &f.pj1w)); TRY(get(pj + "linear_1.bias", &f.pj1b)); TRY(get(pj + "linear_2.weight", &f.pj2w)); TRY(get(pj + "linear_2.bias", &f.pj2b));
+    TRY(get(lm + "embed_tokens.weight", &f.embed));
+    f.dec.resize(d.dec_layers);
+    for (int i = 0; i < d.dec_layers; ++i) {
+        const std::string p = lm + "layers." + std::to_string(i) + ".";
+        F32DecL& L = f.dec[i];
+        TRY(get(p + "input_layernorm.weight", &L.ln1)); TRY(get(p + "self_attn.q_proj.weight", &L.wq)); TRY(get(p + "self_attn.k_proj.weight", &L.wk));
+        TRY(get(p + "self_attn.v_proj.weight", &L.wv)); TRY(get(p + "self_attn.o_proj.weight", &L.wo)); TRY(get(p + "post_attention_layernorm.weight", &L.ln2));
+        TRY(get(p + "mlp.gate_proj.weight", &L.wg)); TRY(get(p + "mlp.up_proj.weight", &L.wu)); TRY(get(p + "mlp.down_proj.weight", &L.wd));
+    }
+    TRY(get(lm + "norm.weight", &f.dec_nw));
+    HIPC(e, stream_sync(e));
+    e->finalized = true;
+    return SONIC_OK;
+}
+static void f32_linear(sonic_engine* e, const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M, int N, int K, int epi = F32_EPI_NONE,
+                       const float* R = nullptr, long ldr = 0) {
+    F32Gemm g{};
+    g.A = X; g.lda = ldx; g.W = W; g.C = Y; g.ldc = ldy; g.bias = bias; g.R = R; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.epi = epi;
+    launch_f32_gemm(g, e->st);
+}
+// feats_f32 [W][n_mels][n_frames] -> pe [W * Ta][dec_d]   (modeling_glmasr.py:313-346, :380-408)
+static int f32_run_encoder(sonic_engine* e, int W, float* enc_layers_out, float* enc_out_host) {
+    F32State& f = *e->f;
+    const sonic_dims& d = e->d;
+    const int C = d.enc_d, T = e->T, M = W * T, H = d.enc_heads, hd = e->hd_e, NF = d.n_frames;
+    launch_f32_feats_tm(e->feats_f32, f.featT, W, d.n_mels, NF, e->st);
+    {   // conv stem: rows of the time-major padded input overlap (output t reads padded rows t .. t + 2; stride 2: 2t .. 2t + 2), taps-major weights
+        F32Gemm a{};
+        a.A = f.featT; a.lda = d.n_mels; a.sA1 = (long)(NF + 2) * d.n_mels; a.W = f.conv1w; a.bias = f.conv1b; a.C = f.h1 + C; a.ldc = C; a.sC1 = (long)(NF + 2) * C;
+        a.M = NF; a.N = C; a.K = 3 * d.n_mels; a.nb1 = W; a.epi = F32_EPI_GELU;
+        launch_f32_gemm(a, e->st);
+        launch_f32_zero_pad_rows(f.h1, W, NF, C, e->st);
+        F32Gemm b{};
+        b.A = f.h1; b.lda = 2L * C; b.sA1 = (long)(NF + 2) * C; b.W = f.conv2w; b.bias = f.conv2b; b.C = f.x; b.ldc = C; b.sC1 = (long)T * C;
+        b.M = T; b.N = C; b.K = 3 * C; b.nb1 = W; b.epi = F32_EPI_GELU;
+        launch_f32_gemm(b, e->st);
+    }
+    for (int l = 0; l < d.enc_layers; ++l) {
+        const F32EncL& L = f.enc[l];
+        launch_f32_layernorm(f.x, L.ln1w, L.ln1b, f.ln, M, C, d.enc_ln_eps, e->st);
+        f32_linear(e, f.ln, C, L.wq, L.bq, f.q, C, M, C, C);
+        f32_linear(e, f.ln, C, L.wk, nullptr, f.k, C, M, C, C);                       // k_proj has no bias (modeling_glmasr.py:184)
+        f32_linear(e, f.ln, C, L.wv, L.bv, f.v, C, M, C, C);
+        launch_f32_rope(f.q, C, M, H, hd, d.enc_rotary_dim, e->enc_cs, nullptr, T, e->st);
+        launch_f32_rope(f.k, C, M, H, hd, d.enc_rotary_dim, e->enc_cs, nullptr, T, e->st);
+        F32Attn a{};
+        a.Q = f.q; a.ldq = C; a.K = f.k; a.V = f.v; a.ldkv = C; a.seq_stride = (long)T * C; a.O = f.att; a.ldo = C; a.seq = nullptr; a.seq_div = T;
+        a.pos = nullptr; a.lim_const = T; a.lim_max = T; a.hd = hd; a.grp = 1; a.scale = 1.0f / sqrtf((float)hd);
+        launch_f32_attn(a, M, H, e->st);
+        f32_linear(e, f.att, C, L.wo, L.bo, f.x, C, M, C, C, F32_EPI_RESID, f.x, C);
+        launch_f32_layernorm(f.x, L.ln2w, L.ln2b, f.ln, M, C, d.enc_ln_eps, e->st);
+        f32_linear(e, f.ln, C, L.w1, L.b1, f.ff, d.enc_ff, M, d.enc_ff, C, F32_EPI_GELU);
+        f32_linear(e, f.ff, d.enc_ff, L.w2, L.b2, f.x, C, M, C, d.enc_ff, F32_EPI_RESID, f.x, C);
+        if (enc_layers_out) {
+            HIPC(e, stream_sync(e));
+            for (int b = 0; b < W; ++b) HIPC(e, d2h(e, enc_layers_out + ((size_t)b * d.enc_layers + l) * T * C, f.x + (size_t)b * T * C, (size_t)T * C * 4));
+        }
+    }
+    launch_f32_layernorm(f.x, f.enc_nw, f.enc_nb, f.ln, M, C, d.enc_ln_eps, e->st);
+    if (enc_out_host) { HIPC(e, stream_sync(e)); HIPC(e, d2h(e, enc_out_host, f.ln, (size_t)M * C * 4)); }
+    const int Mp = W * e->Ta, PI = C * d.merge, PM = 2 * d.dec_d;                       // the 4-frame merge is a view: [M][C] == [W * Ta][4C]
+    f32_linear(e, f.ln, PI, f.pj1w, f.pj1b, f.ph, PM, Mp, PM, PI, F32_EPI_GELU);
+    f32_linear(e, f.ph, PM, f.pj2w, f.pj2b, f.pe, d.dec_d, Mp, d.dec_d, PM);
+    return SONIC_OK;
+}
+// the decoder layers over n_tok token rows of f.dx: token t belongs to sequence seq[t] and sits at position pos[t] (prefill: the prompt rows of all
+// requests; token step: one row per request).  Keys / values are appended before the attention, which sees positions 0 .. pos[t] (llama:217-324)
+static void f32_decoder_layers(sonic_engine* e, int n_tok, const int* seq, const int* pos) {
+    F32State& f = *e->f;
+    const sonic_dims& d = e->d;
+    const int D = d.dec_d, QD = e->QD, KD = e->KD, hd = d.dec_head_dim, FF = d.dec_ff;
+    const long seq_stride = (long)e->max_ctx * KD;
+    for (int l = 0; l < d.dec_layers; ++l) {
+        const F32DecL& L = f.dec[l];
+        float* Kl = f.Kc + (size_t)l * e->Bm * seq_stride; float* Vl = f.Vc + (size_t)l * e->Bm * seq_stride;
+        launch_f32_rmsnorm(f.dx, L.ln1, f.dhn, n_tok, D, d.dec_rms_eps, nullptr, e->st);
+        f32_linear(e, f.dhn, D, L.wq, nullptr, f.dq, QD, n_tok, QD, D);
+        f32_linear(e, f.dhn, D, L.wk, nullptr, f.dk, KD, n_tok, KD, D);
+        f32_linear(e, f.dhn, D, L.wv, nullptr, f.dv, KD, n_tok, KD, D);
+        launch_f32_rope(f.dq, QD, n_tok, d.dec_heads, hd, hd, e->dec_cs, pos, 0, e->st);
+        launch_f32_rope(f.dk, KD, n_tok, d.dec_kv_heads, hd, hd, e->dec_cs, pos, 0, e->st);
+        launch_f32_kv_append(f.dk, f.dv, Kl, Vl, seq, pos, n_tok, KD, seq_stride, e->st);
+        F32Attn a{};
+        a.Q = f.dq; a.ldq = QD; a.K = Kl; a.V = Vl; a.ldkv = KD; a.seq_stride = seq_stride; a.O = f.datt; a.ldo = QD; a.seq = seq; a.seq_div = 1;
+        a.pos = pos; a.lim_const = 0; a.lim_max = e->max_ctx; a.hd = hd; a.grp = d.dec_heads / d.dec_kv_heads; a.scale = 1.0f / sqrtf((float)hd);
+        launch_f32_attn(a, n_tok, d.dec_heads, e->st);
+        f32_linear(e, f.datt, QD, L.wo, nullptr, f.dx, D, n_tok, D, QD, F32_EPI_RESID, f.dx, D);
+        launch_f32_rmsnorm(f.dx, L.ln2, f.dhn, n_tok, D, d.dec_rms_eps, nullptr, e->st);
+        f32_linear(e, f.dhn, D, L.wg, nullptr, f.dg, FF, n_tok, FF, D);
+        f32_linear(e, f.dhn, D, L.wu, nullptr, f.du, FF, n_tok, FF, D);
+        launch_f32_swiglu(f.dg, f.du, f.dact, (long)n_tok * FF, e->st);
+        f32_linear(e, f.dact, FF, L.wd, nullptr, f.dx, D, n_tok, D, FF, F32_EPI_RESID, f.dx, D);
+        if (e->taps_on && e->taps) (void)hipMemcpyAsync((float*)e->taps + (size_t)(l + 1) * e->tok_cap * D, f.dx, (size_t)n_tok * D * 4, hipMemcpyDeviceToDevice, e->st);
+    }
+}
+static GreedyArgs f32_greedy_args(sonic_engine* e, int R, bool dump) {
+    GreedyArgs g = greedy_args(e, R, dump);
+    g.logits = e->f->logits; g.ksplit = 1; g.mpad = 64; g.table = (const bf16_t*)e->f->embed; g.x = (bf16_t*)e->f->dx; g.y = nullptr; g.norm_w = nullptr; g.dt = DT_F32;
+    g.qo = QuantOut{};
+    return g;
+}
+// final norm of the rows `last_row` (null: rows 0 .. R-1) + tied lm_head -> f.logits [R][vocab]
+static void f32_lm_head(sonic_engine* e, int R, const int* last_row) {
+    F32State& f = *e->f;
+    const sonic_dims& d = e->d;
+    launch_f32_rmsnorm(f.dx, f.dec_nw, f.hlast, R, d.dec_d, d.dec_rms_eps, last_row, e->st);
+    f32_linear(e, f.hlast, d.dec_d, f.embed, nullptr, f.logits, d.vocab, R, d.vocab, d.dec_d);
+}
+static int f32_run_prefill(sonic_engine* e, int R, const HostPlan& hp) {
+    F32State& f = *e->f;
+    const sonic_dims& d = e->d;
+    const int D = d.dec_d, M = hp.n_tok;
+    {
+        int* h = e->plan_h; size_t o = 0;
+        auto put = [&](int* dst, const int* srcv, size_t n) -> hipError_t {
+            memcpy(h + o, srcv, n * 4);
+            hipError_t r = hipMemcpyAsync(dst, h + o, n * 4, hipMemcpyHostToDevice, e->st);
+            o += n; return r;
+        };
+        HIPC(e, put(e->src, hp.src.data(), (size_t)M)); HIPC(e, put(e->tok_seq, hp.tok_seq.data(), (size_t)M)); HIPC(e, put(e->tok_pos_pf, hp.tok_pos.data(), (size_t)M));
+        HIPC(e, put(e->q_off, hp.q_off.data(), (size_t)R)); HIPC(e, put(e->q_len, hp.q_len.data(), (size_t)R)); HIPC(e, put(e->kv_len, hp.q_len.data(), (size_t)R));
+        HIPC(e, put(e->last_row, hp.last_row.data(), (size_t)R)); HIPC(e, put(e->max_new_d, hp.max_new.data(), (size_t)R));
+        HIPC(e, put(e->n_active, &R, 1));
+        HIPC(e, hipEventRecord(e->plan_ev[e->plan_idx], e->st));
+        e->plan_busy[e->plan_idx] = true;
+    }
+    launch_fill_i32(e->n_new, 0, 64, e->st); launch_fill_i32(e->finished, 0, 64, e->st); launch_fill_i32(e->step_ctr, 0, 64, e->st);
+    launch_f32_assemble(e->src, f.embed, f.pe, f.dx, M, D, e->st);
+    e->last_ntok = M;
+    if (e->taps_on) {
+        if (!e->taps) HIPC(e, hipMalloc((void**)&e->taps, (size_t)(d.dec_layers + 1) * e->tok_cap * D * 4));
+        HIPC(e, hipMemcpyAsync(e->taps, f.dx, (size_t)M * D * 4, hipMemcpyDeviceToDevice, e->st));
+    }
+    f32_decoder_layers(e, M, e->tok_seq, e->tok_pos_pf);
+    f32_lm_head(e, R, e->last_row);            // logits of the last prompt position only (logits_to_keep = 1, generation/utils.py:2612-2616)
+    return SONIC_OK;
+}
+// one token step for R rows (generation/utils.py:2876-2943): the rows' input embeddings are in f.dx (greedy_kernel<float> left them there)
+static void decode_step_f32(sonic_engine* e, int R, bool dump) {
+    f32_decoder_layers(e, R, e->seq_iota, e->tok_pos);
+    f32_lm_head(e, R, nullptr);
+    launch_greedy(f32_greedy_args(e, R, dump), e->st);
+}
+
 // log-mel -> encoder -> projector -> prefill -> first greedy token (generation/utils.py:2612-2616, 2876-2943 for the first step)
 static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, const int32_t* prompt_ids, const int64_t* prompt_off,
                               const int32_t* max_new, bool want_logits) {
@@ -1447,6 +1687,18 @@ static int run_to_first_token(sonic_engine* e, const int32_t* req_win, int R, co
     } else e->dump_steps = 0;
     e->run_logits = want_logits;
 
+    if (e->f32) {
+        (void)hipEventRecord(e->ev[0], e->st);
+        TRY(run_mel(e, e->W, true));
+        (void)hipEventRecord(e->ev[1], e->st);
+        TRY(f32_run_encoder(e, e->W, nullptr, nullptr));
+        (void)hipEventRecord(e->ev[2], e->st);
+        TRY(f32_run_prefill(e, R, hp));
+        launch_greedy(f32_greedy_args(e, R, want_logits), e->st);
+        (void)hipEventRecord(e->ev[3], e->st);
+        e->steps_run = 0; e->greedy_calls = 1;
+        return SONIC_OK;
+    }
     (void)hipEventRecord(e->ev[0], e->st);
     TRY(run_mel(e, e->W, false));
     (void)hipEventRecord(e->ev[1], e->st);
@@ -1507,7 +1759,7 @@ static int run_decode_steps(sonic_engine* e, int n_steps, int* done_out) {
     const int R = e->R, left = e->max_steps - 1 - e->steps_run;
     if (n_steps > left) n_steps = left;
     const bool want_logits = e->run_logits;
-    const bool use_graph = !want_logits && !e->opt_no_graph && !e->force_d;
+    const bool use_graph = !want_logits && !e->opt_no_graph && !e->force_d && !e->f32;
     const int C = e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1;
     int done = 0;
     int launched = 0, checked = 0, last_grow = 0;   // chunks queued with a check behind them / checks the host has read
@@ -1880,6 +2132,7 @@ __global__ void service_reset_kernel(int* kv_len, int* tok_pos, int* n_new, int*
 }
 
 extern "C" int sonic_service_begin(sonic_engine* e) {
+    if (e && e->f32) return SONIC_ERR_UNSUPPORTED;
     if (!e) return SONIC_ERR_INVALID;
     ENTER(e);
     if (!e->finalized) return fail(e, SONIC_ERR_INVALID, "weights not finalized");
@@ -2250,6 +2503,15 @@ extern "C" int sonic_encode(sonic_engine* e, const float* feats, const int32_t* 
     if (B < 1 || B > e->Bm) return fail(e, SONIC_ERR_INVALID, "batch out of range");
     const sonic_dims& d = e->d;
     const size_t n = (size_t)B * d.n_mels * d.n_frames;
+    if (e->f32) {
+        if (!e->feats_f32) HIPC(e, hipMalloc((void**)&e->feats_f32, (size_t)e->Bm * d.n_mels * d.n_frames * 4));
+        HIPC(e, h2d(e, e->feats_f32, feats, n * 4));
+        TRY(f32_run_encoder(e, B, enc_layers_out, enc_out));
+        HIPC(e, stream_sync(e)); HIPC(e, hipGetLastError());
+        if (embeds_out) HIPC(e, d2h(e, embeds_out, e->f->pe, (size_t)B * e->Ta * d.dec_d * 4));
+        if (n_audio_out) for (int b = 0; b < B; ++b) n_audio_out[b] = keep_rows(d, n_valid_frames[b]);
+        return SONIC_OK;
+    }
     float* tmp = nullptr;
     HIPC(e, hipMalloc((void**)&tmp, n * 4));
     hipError_t r = h2d(e, tmp, feats, n * 4);
@@ -2586,6 +2848,19 @@ extern "C" int sonic_debug_read(sonic_engine* e, const char* name, int index, fl
     if (!e || !name || !out) return SONIC_ERR_INVALID;
     ENTER(e);
     const sonic_dims& d = e->d;
+    if (e->f32) {                                  // fp32 kind: its buffers are fp32 already
+        const float* s32 = nullptr; size_t cap32 = 0;
+        if (!strcmp(name, "prefill_tap")) { if (!e->taps) return fail(e, SONIC_ERR_INVALID, "no taps recorded"); s32 = (const float*)e->taps + (size_t)index * e->tok_cap * d.dec_d; cap32 = (size_t)e->tok_cap * d.dec_d; }
+        else if (!strcmp(name, "pe")) { s32 = e->f->pe; cap32 = (size_t)e->Bm * e->Ta * d.dec_d; }
+        else if (!strcmp(name, "dx")) { s32 = e->f->dx; cap32 = (size_t)e->tok_cap * d.dec_d; }
+        else if (!strcmp(name, "enc_x")) { s32 = e->f->ln; cap32 = (size_t)e->Bm * e->T * d.enc_d; }
+        else if (!strcmp(name, "h1")) { s32 = e->f->h1; cap32 = (size_t)e->Bm * (d.n_frames + 2) * d.enc_d; }
+        else return fail(e, SONIC_ERR_INVALID, "unknown buffer %s", name);
+        if (n < 0 || (size_t)n > cap32) return fail(e, SONIC_ERR_INVALID, "read of %lld elements exceeds buffer %s", (long long)n, name);
+        HIPC(e, stream_sync(e));
+        HIPC(e, d2h(e, out, s32, (size_t)n * 4));
+        return SONIC_OK;
+    }
     const bf16_t* src = nullptr; size_t cap = 0;
     if (!strcmp(name, "prefill_tap")) { if (!e->taps) return fail(e, SONIC_ERR_INVALID, "no taps recorded"); src = e->taps + (size_t)index * e->tok_cap * d.dec_d; cap = (size_t)e->tok_cap * d.dec_d; }
     else if (!strcmp(name, "pe")) { src = e->pe; cap = (size_t)e->Bm * e->Ta * d.dec_d; }

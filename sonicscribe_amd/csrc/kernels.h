@@ -177,3 +177,36 @@ void launch_tile_weights_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream
 void launch_transpose_i8(const int8_t* w, int8_t* wt, int N, int K, hipStream_t s);     // wt[k][n] = w[n][k]
 // int8 encoder: V columns [col0, col0 + C) of the row-major QKV matrix -> V^T [seg][C][vt_ld]
 void launch_transpose_v(const bf16_t* qkv, long ld, int col0, bf16_t* vt, int n_seg, int T, int C, int vt_ld, long vt_seg_stride, hipStream_t s);
+
+// ---- SONIC_MODE_F32 (test only; f32kind.hip): plain fp32 stages behind the same C ABI ----
+enum { F32_EPI_NONE = 0, F32_EPI_GELU = 1, F32_EPI_RESID = 2 };
+struct F32Gemm {
+    const float* A; long lda, sA1, sA2;        // A[b][m][k]: rows K-contiguous, row stride lda (overlapping rows allowed), batch offsets per level
+    const float* W; long swn, swk, sW1, sW2;   // W[b][n * swn + k * swk]; swn = swk = 0 means torch Linear layout (swn = K, swk = 1)
+    float* C; long ldc, sC1, sC2;
+    const float* bias;                         // [N] or null
+    const float* R; long ldr;                  // F32_EPI_RESID: C = R + (acc + bias)
+    int M, N, K, nb1, nb2;                     // batch = nb1 * nb2 (0 = 1)
+    float scale;                               // acc * scale before the bias (0 = 1)
+    int epi;
+};
+void launch_f32_gemm(const F32Gemm& g, hipStream_t s);
+struct F32Attn {
+    const float* Q; long ldq;                  // [n_tok][Hq * hd]
+    const float* K; const float* V; long ldkv, seq_stride;   // [seq][key][Hkv * hd]
+    float* O; long ldo;
+    const int* seq; int seq_div;               // sequence of token t: seq ? seq[t] : t / seq_div
+    const int* pos; int lim_const, lim_max;    // keys visible to token t: pos ? pos[t] + 1 : lim_const (both capped at lim_max, which sizes the LDS)
+    int hd, grp;                               // head dim (<= 256, divides 256), query heads per kv head
+    float scale;
+};
+void launch_f32_attn(const F32Attn& a, int n_tok, int heads, hipStream_t s);
+void launch_f32_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, float eps, hipStream_t s);
+void launch_f32_rmsnorm(const float* x, const float* w, float* y, int rows, int d, float eps, const int* row_map, hipStream_t s);
+void launch_f32_rope(float* x, long ld, int n_tok, int heads, int hd, int rd, const float* cs, const int* pos, int pos_mod, hipStream_t s);
+void launch_f32_feats_tm(const float* in, float* out, int W, int n_mels, int n_frames, hipStream_t s);
+void launch_f32_conv_w(const float* in, float* out, int C, int Ci, hipStream_t s);
+void launch_f32_zero_pad_rows(float* h, int W, int n_frames, int C, hipStream_t s);
+void launch_f32_assemble(const int* src, const float* table, const float* audio, float* x, int n_tok, int d, hipStream_t s);
+void launch_f32_kv_append(const float* kn, const float* vn, float* Kc, float* Vc, const int* seq, const int* pos, int n_tok, int kd, long seq_stride, hipStream_t s);
+void launch_f32_swiglu(const float* g, const float* u, float* act, long n, hipStream_t s);

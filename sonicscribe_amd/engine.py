@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsonic_hip.so")
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU = 0, 1, 2, 3
-MODE_NATIVE, MODE_INT8, MODE_F16 = 0, 1, 2
+MODE_NATIVE, MODE_INT8, MODE_F16, MODE_F32 = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 SONIC_ERR_MISMATCH, SONIC_ERR_UNSUPPORTED = 4, 5
 

@@ -8,7 +8,8 @@ since round 5 - the fused decode kernels skinny_o / skinny_gu that the bf16 head
   * against the oracle in FP32 mode with the same weights (bf16-valued, exact in fp16) = the reference's fp32 arithmetic (the oracle's fp32
     mode is pinned to transformers' fp32 generate() at 1e-3, tests/test_oracle_golden.py): what is left is fp16 activation rounding.
 A layout, mask, position, RoPE-pairing, KV-append or argmax bug shows at O(0.1-1) and at 1e-2 alike; this bound is 8-16 x tighter than bf16's.
-The fp32 kind (1e-3 literally) does not exist: every kernel's LDS image assumes 2-byte elements."""
+The fp32 kind (1e-3 literally) is tests/test_gpu_fp32_mode.py (SONIC_MODE_F32, round 6): its own plain-fp32 kernels behind the same plan / staging /
+controller, because every product kernel's LDS image assumes 2-byte elements; THIS file is what checks the product templates themselves below bf16."""
 from dataclasses import replace
 
 import numpy as np

@@ -116,19 +116,19 @@ def test_create_validates_handles_and_a_device_error_fails_the_batch_loudly():
     seg = synth.synth_pcm(900, 16000 * 3)
     prompt = prompt_for(dims, len(seg))
     good = pre.transcribe_batch([seg], [prompt], [6])[0][0]
-    pre._set_option("inject_dev_err", 1)
+    pre.set_option("inject_dev_err", 1)
     with pytest.raises(RuntimeError, match="in-kernel wait"):
         pre.transcribe_batch([seg], [prompt], [6])
-    pre._set_option("inject_dev_err", 0)
+    pre.set_option("inject_dev_err", 0)
     assert np.array_equal(pre.transcribe_batch([seg], [prompt], [6])[0][0], good)
     pipe = NativePipeline([eng], [pre], block=4)
     assert np.array_equal(pipe.wait(pipe.submit([prompt], [6], segments=[seg]))[0], good)
-    eng._set_option("inject_dev_err", 1)
+    eng.set_option("inject_dev_err", 1)
     t = pipe.submit([prompt], [30], segments=[seg])
     with pytest.raises(RuntimeError, match="in-kernel wait"):
         pipe.wait(t)
     with pytest.raises(RuntimeError):
         pipe.submit([prompt], [6], segments=[seg])   # a failed pipeline refuses new work; its prefill threads sleep until close (no spin)
     pipe.close()
-    eng._set_option("inject_dev_err", 0)
+    eng.set_option("inject_dev_err", 0)
     other.close(); eng.close()
