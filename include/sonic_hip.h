@@ -224,6 +224,26 @@ SONIC_API int sonic_service_step(sonic_engine* d, int n_chunks, int rows, int32_
 SONIC_API int sonic_fetch_row(sonic_engine* d, int row, int n, int32_t* out_ids);
 SONIC_API int sonic_fetch_rows(sonic_engine* d, int n, const int32_t* rows, const int32_t* counts, int32_t* out_ids, int out_ld);
 
+/* Request-level scheduling for live traffic as native threads (csrc/dispatch.cpp): what the reference does with one `await
+ * transcribe()` per partial / final of every WebSocket session (backend/connection_manager.py:127-245, backend/transcription_manager.py:19-65) and
+ * three executor threads in file mode (backend/main.py:429-445, 616-624), all serialised on one model object.  decoders: handles that decode
+ * continuously over their max_batch rows (sonic_service_begin is called on them); prefills: handles that run log-mel + encoder + prompt forward +
+ * first token of whatever is queued - as many requests as the emptiest decoder has free rows - and hand the rows over; all handles share one
+ * weight copy.  A request is W windows (host PCM, or slices of device rings: see sonic_stage_mixed), a prompt and a budget; it joins a running loop
+ * between two chunks and leaves the moment it hits EOS / its budget.  Tokens equal the solo run's bit for bit (decode rows are independent). */
+typedef struct sonic_dispatch sonic_dispatch;
+struct sonic_ring;
+SONIC_API int sonic_dispatch_create(sonic_engine* const* decoders, int n_dec, sonic_engine* const* prefills, int n_pre, int adaptive_tiles, sonic_dispatch** out);
+SONIC_API int sonic_dispatch_submit(sonic_dispatch* d, const int16_t* host_pcm, const int64_t* host_off, struct sonic_ring* const* rings, const int64_t* ring_start,
+                                    const int32_t* ring_n, int W, const int32_t* prompt_ids, int prompt_len, int max_new, int64_t* ticket_out);
+SONIC_API int sonic_dispatch_cancel(sonic_dispatch* d, int64_t ticket);                 /* queued requests only */
+/* next completed request in completion order; blocks up to timeout_ms (< 0: until one completes or the dispatcher is closed and drained); *ticket_out = 0: none */
+SONIC_API int sonic_dispatch_next(sonic_dispatch* d, int timeout_ms, int64_t* ticket_out, int32_t* status_out, int32_t* out_ids, int out_cap, int32_t* n_out,
+                                  char* err, int err_cap);
+SONIC_API int sonic_dispatch_stats(sonic_dispatch* d, int64_t* prefill_batches, int64_t* decode_chunks, int32_t* load_windows, int32_t* free_rows);
+SONIC_API int sonic_dispatch_close(sonic_dispatch* d);     /* queued requests fail, running ones complete (still collectable); handles leave continuous mode */
+SONIC_API int sonic_dispatch_destroy(sonic_dispatch* d);
+
 /* Device-resident ingest.  A ring holds the raw wire PCM of one streaming session in HBM: what the reference keeps as
  * 2048-byte chunks in a host dict (backend/audio_manager.py:21-33, fed from backend/main.py:813-842) and concatenates on the host for
  * every partial / final decode (audio_manager.py:99-123).  A decode names sample ranges of rings instead of handing over host buffers;

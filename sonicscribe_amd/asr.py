@@ -177,7 +177,7 @@ class AudioStream:
 class ASRModel:
     def __init__(self, checkpoint_dir: str, device: str = "cuda", mode: str = "native",
                  cpu_threads: Optional[int] = None, cpu_interop_threads: Optional[int] = None,
-                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, continuous: bool = DEFAULT_CONTINUOUS, decoders: int = 1, bulk: bool = False, _dims: Optional[ModelDims] = None,
+                 *, max_batch: int = 32, max_ctx: int = 1024, slots: int = DEFAULT_SLOTS, continuous: bool = DEFAULT_CONTINUOUS, decoders: int = 1, bulk: bool = False, native_dispatch: Optional[bool] = None, _dims: Optional[ModelDims] = None,
                  _synthetic_seed: Optional[int] = None, _allow_synthetic_prompt: bool = False, _options: Optional[Dict[str, int]] = None):
         if mode not in ["native", "int8"]:
             raise ValueError("mode must be either 'native' or 'int8'")            # asr.py:46-47
@@ -240,7 +240,7 @@ class ASRModel:
         self.slots = max(self.decoders + 1 if self.continuous else 1, int(slots))
         self._slot_engines = [[eng.slot() for _ in range(self.slots - 1)] for eng in self.models]     # same weights, further batches in flight
         self._dispatcher = Dispatcher(self.models, slots=self._slot_engines, continuous=self.continuous, decoders=self.decoders or 1,
-                                      adaptive_tiles="gemm_small_eff" not in (_options or {}), bulk=self.bulk)
+                                      adaptive_tiles="gemm_small_eff" not in (_options or {}), bulk=self.bulk, native=native_dispatch)
         print(f"🚀 初始化 ASR 模型 | 模式: {mode.upper()} | 设备: {self.device} (MI355X HIP engine, "
               f"{self.model.weight_bytes() / 2**20:.0f} MiB weights x {len(self.models)} replica(s), {self.slots} batch slot(s) each)")
 

@@ -396,6 +396,136 @@ class _ContinuousReplica:
                 r.future.set_exception(RuntimeError("ASR engine is closed"))
 
 
+class _NativeContinuousReplica:
+    """Row-level scheduling with the scheduler inside the LIBRARY (include/sonic_hip.h sonic_dispatch_*; csrc/dispatch.cpp): the same schedule as
+    _ContinuousReplica - which stays as its executable description for stub engines (tests/test_dispatch.py) - run by native threads: prefill
+    threads stage / prefill / hand over, decode threads splice / step / fetch.  Python keeps ONE thread per replica that collects completions
+    (sonic_dispatch_next, blocking, GIL released) and resolves futures; put() is a single ctypes call.  No decode chunk passes the interpreter, so
+    128 sessions' own Python work no longer delays the loops that serve them."""
+
+    def __init__(self, engine, index: int, slots: Sequence[Any], decoders: int = 1, adaptive_tiles: bool = True):
+        import ctypes as C
+        decoders = max(1, int(decoders))
+        if len(slots) < decoders:
+            raise ValueError("continuous decoding needs at least one prefill slot per replica beside its decoding handles")
+        self.engine, self.index = engine, index
+        self.decoders = [engine] + list(slots[:decoders - 1])
+        self.prefill_engines = list(slots[decoders - 1:])
+        self.engines = [engine] + list(slots)
+        self.n_rows = engine.max_batch
+        self.lib = engine.lib
+        dec = (C.c_void_p * len(self.decoders))(*[d.h for d in self.decoders])
+        pre = (C.c_void_p * len(self.prefill_engines))(*[p.h for p in self.prefill_engines])
+        h = C.c_void_p()
+        rc = self.lib.sonic_dispatch_create(dec, len(self.decoders), pre, len(self.prefill_engines), int(bool(adaptive_tiles)), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"sonic_dispatch_create failed with status {rc}: " + (self.lib.sonic_last_error(engine.h) or b"").decode())
+        self.h = h
+        self.lock = threading.Lock()
+        self.pending = {}                                # ticket -> Request
+        self.stop = False
+        self.out_cap = int(engine.max_ctx)
+        self.thread = threading.Thread(target=self._complete_loop, name=f"sonic-dispatch-{index}.complete", daemon=True)
+        self.thread.start()
+
+    # diagnostics the Python class offers as attributes
+    def _stats(self):
+        import ctypes as C
+        b, c, l, f = C.c_int64(0), C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        if self.h:
+            self.lib.sonic_dispatch_stats(self.h, C.byref(b), C.byref(c), C.byref(l), C.byref(f))
+        return int(b.value), int(c.value), int(l.value), int(f.value)
+
+    @property
+    def batches(self) -> int:
+        return self._stats()[0]
+
+    @property
+    def steps(self) -> int:
+        return self._stats()[1]
+
+    @property
+    def free_rows(self) -> int:
+        return self._stats()[3]
+
+    def load(self) -> int:
+        return self._stats()[2]
+
+    def put(self, req: Request):
+        import ctypes as C
+        from .engine import RingSlice, _p
+        wins = req.windows
+        W = len(wins)
+        offs = np.zeros(W + 1, np.int64)
+        host, rings, start, n, any_ring = [], [], np.zeros(W, np.int64), np.zeros(W, np.int32), False
+        for i, w in enumerate(wins):
+            if isinstance(w, RingSlice):
+                if w.ring.engine.root is not self.engine.root:
+                    raise ValueError("a ring slice can only be decoded by the engine that owns the ring (or by a slot of it)")
+                rings.append(w.ring.h); start[i] = w.start; n[i] = w.n; any_ring = True
+                offs[i + 1] = offs[i]
+            else:
+                a = np.ascontiguousarray(w, dtype=np.int16)
+                host.append(a); rings.append(None)
+                offs[i + 1] = offs[i] + len(a)
+        pcm = np.concatenate(host) if host and offs[-1] > 0 else np.zeros(1, np.int16)
+        ring_arr = (C.c_void_p * W)(*rings) if any_ring else None
+        prompt = np.ascontiguousarray(req.prompt, dtype=np.int32)
+        t = C.c_int64(0)
+        with self.lock:
+            if self.stop:
+                raise RuntimeError("ASR engine is closed")
+            rc = self.lib.sonic_dispatch_submit(self.h, _p(pcm), _p(offs), ring_arr, _p(start) if any_ring else None, _p(n) if any_ring else None, W,
+                                                _p(prompt), len(prompt), int(req.max_new), C.byref(t))
+            if rc != 0:
+                raise RuntimeError("ASR engine failed" if rc not in (1,) else "ASR engine is closed or the request is malformed")
+            self.pending[int(t.value)] = req
+        ticket = int(t.value)
+        req.future.add_done_callback(lambda f, ticket=ticket: f.cancelled() and self.h and self.lib.sonic_dispatch_cancel(self.h, ticket))
+
+    def _complete_loop(self):
+        import ctypes as C
+        from .engine import SONIC_ERR_MISMATCH, SonicError
+        ids = np.zeros(self.out_cap, np.int32)
+        err = C.create_string_buffer(512)
+        t, st, n = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        while True:
+            rc = self.lib.sonic_dispatch_next(self.h, -1, C.byref(t), C.byref(st), ids.ctypes.data_as(C.c_void_p), self.out_cap, C.byref(n), err, 512)
+            if rc != 0 or t.value == 0:
+                return                                   # closed and drained
+            with self.lock:
+                req = self.pending.pop(int(t.value), None)
+            if req is None or req.future.done():
+                continue
+            try:
+                if st.value == 0:
+                    req.future.set_result(ids[:n.value].copy())
+                else:
+                    msg = err.value.decode(errors="replace")
+                    if "audio spans" in msg or st.value == SONIC_ERR_MISMATCH:
+                        req.future.set_exception(ValueError(msg))
+                    elif "closed" in msg:
+                        req.future.set_exception(RuntimeError(msg))
+                    else:
+                        req.future.set_exception(SonicError(msg))
+            except BaseException:                        # cancelled between the check and the set: the caller is gone
+                pass
+
+    def close(self):
+        with self.lock:
+            if self.stop:
+                return
+            self.stop = True
+        self.lib.sonic_dispatch_close(self.h)            # queued requests fail, running ones complete
+        self.thread.join()                               # ... and are delivered before the handle goes
+        h, self.h = self.h, None
+        self.lib.sonic_dispatch_destroy(h)
+        for r in self.pending.values():
+            if not r.future.done():
+                r.future.set_exception(RuntimeError("ASR engine is closed"))
+        self.pending.clear()
+
+
 class _BulkReplica:
     """File mode (`backend/main.py:429-445`: whole segments submitted in bulk, three decodes kept in flight): requests are grouped, oldest first
     and one step class per batch, into batches of up to `block` windows and handed to the LIBRARY's pipeline (pipeline.NativePipeline ->
@@ -546,7 +676,7 @@ class _BulkReplica:
 
 class Dispatcher:
     def __init__(self, engines: Sequence[Any], slots: Optional[Sequence[Sequence[Any]]] = None, continuous: bool = False, decoders: int = 1,
-                 adaptive_tiles: bool = True, bulk: bool = False, pipeline_factory=None):
+                 adaptive_tiles: bool = True, bulk: bool = False, pipeline_factory=None, native: Optional[bool] = None):
         """engines: one per replica (its own weights).  slots[i]: further engine handles that share replica i's weights (Engine.slot()).
         continuous: row-level scheduling (_ContinuousReplica: the engine - and decoders - 1 of its slots - decode forever, the other slots
         prefill) instead of batch by batch.  bulk: whole batches through the library's native pipeline (_BulkReplica)."""
@@ -556,7 +686,12 @@ class Dispatcher:
         if bulk:
             self.replicas = [_BulkReplica(e, i, slots[i] if slots else (), decoders, pipeline_factory=pipeline_factory) for i, e in enumerate(engines)]
         elif continuous:
-            self.replicas = [_ContinuousReplica(e, i, slots[i] if slots else (), decoders, adaptive_tiles) for i, e in enumerate(engines)]
+            # native: the scheduler inside the library (csrc/dispatch.cpp) - the default for real engine handles; duck-typed stub engines (CPU tests)
+            # and native=False keep the Python class, which is the same schedule statement by statement
+            if native is None:
+                native = all(hasattr(e, "h") and hasattr(getattr(e, "lib", None), "sonic_dispatch_create") for e in engines)
+            cls = _NativeContinuousReplica if native else _ContinuousReplica
+            self.replicas = [cls(e, i, slots[i] if slots else (), decoders, adaptive_tiles) for i, e in enumerate(engines)]
         else:
             self.replicas = [_Replica(e, i, slots[i] if slots else ()) for i, e in enumerate(engines)]
 

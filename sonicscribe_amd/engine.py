@@ -32,6 +32,7 @@ EXPORTS = [
     "sonic_abi_version", "sonic_slot_create", "sonic_slot_count", "sonic_run_staged_async", "sonic_wait",
     "sonic_service_begin", "sonic_service_end", "sonic_splice_rows", "sonic_service_step", "sonic_fetch_row", "sonic_fetch_rows", "sonic_prefill_enqueue",
     "sonic_runtime_info", "sonic_engine_info",
+    "sonic_dispatch_create", "sonic_dispatch_submit", "sonic_dispatch_cancel", "sonic_dispatch_next", "sonic_dispatch_stats", "sonic_dispatch_close", "sonic_dispatch_destroy",
     "sonic_pipeline_create", "sonic_pipeline_submit", "sonic_pipeline_wait", "sonic_pipeline_stats", "sonic_pipeline_last_error", "sonic_pipeline_destroy",
 ]
 ABI_VERSION = 7
@@ -144,6 +145,13 @@ def load_library():
     lib.sonic_test_linear_int8.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.sonic_slot_create.argtypes = [vp, C.POINTER(vp)]
     lib.sonic_slot_count.argtypes = [vp]
+    lib.sonic_dispatch_create.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.sonic_dispatch_submit.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, i64p]
+    lib.sonic_dispatch_cancel.argtypes = [vp, C.c_int64]
+    lib.sonic_dispatch_next.argtypes = [vp, C.c_int, i64p, ip, vp, C.c_int, ip, C.c_char_p, C.c_int]
+    lib.sonic_dispatch_stats.argtypes = [vp, i64p, i64p, ip, ip]
+    lib.sonic_dispatch_close.argtypes = [vp]
+    lib.sonic_dispatch_destroy.argtypes = [vp]
     lib.sonic_engine_info.argtypes = [vp, ip, ip, ip, ip, C.POINTER(vp)]
     lib.sonic_run_staged_async.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
     lib.sonic_wait.argtypes = [vp, C.c_int, ip]

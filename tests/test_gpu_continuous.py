@@ -171,13 +171,16 @@ def test_rows_that_stop_at_eos_are_refilled():
     dec.close()
 
 
-def test_asrmodel_continuous_equals_batch_model():
+@pytest.mark.parametrize("native", [True, False], ids=["native-dispatch", "python-dispatch"])
+def test_asrmodel_continuous_equals_batch_model(native):
     """the façade with continuous=True: mixed partial / final budgets from many sessions, host tensors and device rings; every transcript
-    equals the batch-by-batch model's"""
+    equals the batch-by-batch model's.  native: the scheduler inside the library (csrc/dispatch.cpp, the default) / the Python class it restates"""
     from sonicscribe_amd.asr import ASRModel
+    from sonicscribe_amd.dispatch import _ContinuousReplica, _NativeContinuousReplica
     d = replace(spec.TINY, eos_ids=())
     ref = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=1)
-    con = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=2, continuous=True)
+    con = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=2, continuous=True, native_dispatch=native)
+    assert isinstance(con._dispatcher.replicas[0], _NativeContinuousReplica if native else _ContinuousReplica)
     assert con.get_model_info()["continuous"] is True and con.model.weight_bytes() == ref.model.weight_bytes()
     wavs = [synth.synth_pcm(900 + i, 16000 * (2 + i % 4)).astype(np.float32) / 32768.0 for i in range(30)]
     budgets = [15 if i % 3 else 60 for i in range(30)]
@@ -196,16 +199,25 @@ def test_asrmodel_continuous_equals_batch_model():
     got = st.submit_chunks(0, st.next_chunk_id - 1, 30).result(timeout=60)
     assert got == ref.transcribe((np.frombuffer(wire, np.int16).astype(np.float32) / np.float32(32768.0))[None], 16000, max_new_tokens=30)
     st.close()
+    # a request that cannot be decoded (prompt + budget beyond max_ctx) fails alone; one with a bad placeholder count raises ValueError as everywhere
+    with pytest.raises(Exception):
+        con.submit(wavs[0][None], 16000, 2000).result(timeout=60)
+    assert con.submit(wavs[1][None], 16000, budgets[1]).result(timeout=60) == want[1]
+    rep = con._dispatcher.replicas[0]
+    assert rep.load() == 0 and rep.free_rows == 8 and rep.batches > 0 and rep.steps > 0
     ref.close(); con.close()
+    with pytest.raises(RuntimeError):
+        con.submit(wavs[1][None], 16000, 4)
 
 
-def test_asrmodel_two_decoders_of_64_rows_bulk_shape():
+@pytest.mark.parametrize("native", [True, False], ids=["native-dispatch", "python-dispatch"])
+def test_asrmodel_two_decoders_of_64_rows_bulk_shape(native):
     """the bulk shape of the facade (bench.py's pipeline through dispatch._ContinuousReplica): two decoding handles over 64 rows each + one prefill
     slot on one weight copy; 150 requests of mixed length and budget from the caller's threads, every transcript equal to the one-slot batch model's"""
     from sonicscribe_amd.asr import ASRModel
     d = replace(spec.TINY, eos_ids=())
     ref = ASRModel.from_synthetic(d, device="cuda:0", max_batch=8, max_ctx=512, slots=1, continuous=False)
-    bulk = ASRModel.from_synthetic(d, device="cuda:0", max_batch=64, max_ctx=512, slots=3, continuous=True, decoders=2)
+    bulk = ASRModel.from_synthetic(d, device="cuda:0", max_batch=64, max_ctx=512, slots=3, continuous=True, decoders=2, native_dispatch=native)
     info = bulk.get_model_info()
     assert info["continuous"] is True and info["slots_per_replica"] == 3 and bulk.model.slot_count() == 3
     rep = bulk._dispatcher.replicas[0]
@@ -216,7 +228,7 @@ def test_asrmodel_two_decoders_of_64_rows_bulk_shape():
     futs = [bulk.submit(wavs[i % 50][None], 16000, budgets[i % 50]) for i in range(150)]
     got = [f.result(timeout=300) for f in futs]
     assert got == [want[i % 50] for i in range(150)]
-    assert rep.load() == 0 and all(r is None for rows in rep.rows for r in rows)
+    assert rep.load() == 0 and rep.free_rows == 128 and (native or all(r is None for rows in rep.rows for r in rows))
     ref.close(); bulk.close()
 
 
