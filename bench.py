@@ -310,6 +310,28 @@ def extra_batch_run(dims, device_index: int, mode: str, B: int, max_new: int, st
         e.close()
 
 
+def facade_bulk_measure(dims, device_index: int, B: int, max_new: int, native_dispatch=None, batches: int = 20):
+    """The facade's bulk shape: ASRModel.submit() x (batches x B) host float tensors of 20 s - host-side normalisation, H2D, three decode loops + a prefill
+    slot behind the row-level dispatcher (native threads in the library by default; native_dispatch=False: the Python class), detokenised strings back."""
+    from sonicscribe_amd import synth as _synth
+    from sonicscribe_amd.asr import ASRModel
+    fm = ASRModel.from_synthetic(dims, seed=20260128, device=f"cuda:{device_index}", mode="native", max_batch=64, max_ctx=512, slots=4, continuous=True, decoders=3,
+                                 native_dispatch=native_dispatch)
+    wavs = [(_synth.synth_pcm(i, SEG_SECONDS * 16000).astype(np.float32) / np.float32(32768.0))[None] for i in range(B)]
+    [f.result() for f in [fm.submit(w, 16000, max_new) for w in wavs]]                  # warm-up
+    t1 = time.perf_counter()
+    futs = [fm.submit(wavs[i % B], 16000, max_new) for i in range(batches * B)]
+    [f.result() for f in futs]
+    d1 = time.perf_counter() - t1
+    kind = type(fm._dispatcher.replicas[0]).__name__
+    fm.close()
+    return {"value": batches * B / d1, "unit": "20s-segments/sec", "segments": batches * B, "wall_s": d1, "dispatcher": kind,
+            "note": f"ASRModel(max_batch=64, slots=4, continuous=True, decoders=3).submit() x {batches * B} host float tensors of 20 s, {max_new} tokens each: "
+                    "host-side normalisation, H2D, the three decode loops + prefill slot behind the row-level dispatcher (rows join and leave one by one; "
+                    "csrc/dispatch.cpp native threads unless dispatcher says _ContinuousReplica), detokenised strings back; seven batches are in flight, so the "
+                    "figure still contains the fill and drain of a 4 s run; not the headline"}
+
+
 def run_streaming(a):
     print(json.dumps(streaming_measure(a)), flush=True)
 
@@ -328,7 +350,7 @@ def streaming_measure(a):
     S = a.sessions
     dev = "cuda:*" if a.gpus > 1 else "cuda:" + ",".join(["0"] * max(1, a.replicas_per_gpu))     # several replicas on one GPU fill each other's decode bubbles
     model = ASRModel.from_synthetic(dims, seed=20260128, device=dev, mode=a.mode, max_batch=a.batch, max_ctx=512, slots=getattr(a, "slots", 2),
-                                    continuous=getattr(a, "continuous", False), decoders=getattr(a, "decoders", 1), _options=dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in getattr(a, "opt", []) or []))
+                                    continuous=getattr(a, "continuous", False), decoders=getattr(a, "decoders", 1), native_dispatch=(False if getattr(a, "python_dispatch", False) else None), _options=dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in getattr(a, "opt", []) or []))
     n_rep = len(model.models)
     speech = SEG_SECONDS * 16000
     wire = [synth.synth_pcm(i, speech) for i in range(S)]                          # int16, as the WebSocket delivers it
@@ -438,6 +460,8 @@ def main():
     ap.add_argument("--streaming", action="store_true", help="BASELINE config 5: real-time session simulation (partial / final latency), one process")
     ap.add_argument("--sessions", type=int, default=16, help="concurrent sessions of --streaming (128 sessions / 8 GPUs = 16 per GPU)")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="--streaming on one GPU: engine replicas sharing it (DESIGN.md 4: concurrent decode chains)")
+    ap.add_argument("--python-dispatch", action="store_true", help="row-level scheduling by the Python class (dispatch._ContinuousReplica) instead of the library's native threads (csrc/dispatch.cpp): A/B")
+    ap.add_argument("--facade-only", action="store_true", help="only the facade_bulk leg (ASRModel.submit x 640 segments): A/B of the dispatchers")
     ap.add_argument("--continuous", action="store_true", help="--streaming: row-level scheduling (the engine decodes forever over its rows, slots prefill; dispatch._ContinuousReplica)")
     ap.add_argument("--decoders", type=int, default=1, help="--streaming --continuous: decoding handles per replica (each loops over --batch rows); the other slots prefill")
     ap.add_argument("--single", action="store_true", help="--streaming: also time B=1 transcribe() calls of 5 s / 20 s first (BASELINE config 1's call shape)")
@@ -465,6 +489,13 @@ def main():
         return
     if a.streaming:
         run_streaming(a)
+        return
+    if a.facade_only:
+        import contextlib
+        from sonicscribe_amd import spec as _spec
+        with contextlib.redirect_stdout(sys.stderr):
+            r = facade_bulk_measure(_spec.FULL if a.dims == "full" else _spec.TINY, 0, BATCH, a.max_new, native_dispatch=(False if a.python_dispatch else None))
+        print(json.dumps(r), flush=True)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -823,20 +854,7 @@ def main():
             # the facade's bulk shape: the same pipeline behind ASRModel.submit() - host float tensors in (peak-normalise + PCM_16 on the host, H2D),
             # transcripts out - 10 batches' worth of segments submitted at once
             try:
-                from sonicscribe_amd import synth as _synth
-                from sonicscribe_amd.asr import ASRModel
-                fm = ASRModel.from_synthetic(dims, seed=20260128, device=f"cuda:{device_index}", mode="native", max_batch=64, max_ctx=512, slots=4, continuous=True, decoders=3)
-                wavs = [(_synth.synth_pcm(i, SEG_SECONDS * 16000).astype(np.float32) / np.float32(32768.0))[None] for i in range(B)]
-                [f.result() for f in [fm.submit(w, 16000, a.max_new) for w in wavs]]                  # warm-up
-                t1 = time.perf_counter()
-                futs = [fm.submit(wavs[i % B], 16000, a.max_new) for i in range(20 * B)]
-                [f.result() for f in futs]
-                d1 = time.perf_counter() - t1
-                fm.close()
-                out["facade_bulk"] = {"value": 20 * B / d1, "unit": "20s-segments/sec", "segments": 20 * B, "wall_s": d1,
-                                      "note": "ASRModel(max_batch=64, slots=4, continuous=True, decoders=3).submit() x 640 host float tensors of 20 s, 150 tokens each: "
-                                              "host-side normalisation, H2D, the three decode loops + prefill slot behind dispatch._ContinuousReplica (rows join and leave one by one), "
-                                              "detokenised strings back; seven batches are in flight, so the figure still contains the fill and drain of a 4 s run; not the headline"}
+                out["facade_bulk"] = facade_bulk_measure(dims, device_index, B, a.max_new)
             except Exception as ex:
                 out["facade_bulk"] = {"value": None, "note": f"not measured: {ex!r}"}
             # BASELINE config 5's call pattern at its per-GPU share (128 sessions / 8 GPUs = 16), real-time schedule, device-resident ingest
