@@ -95,6 +95,8 @@ typedef struct {
     float host_prefill_enqueue_ms, host_decode_launch_ms, host_decode_wait_ms;
     int32_t host_decode_launches;
     int32_t decode_lookahead;   /* chunks the decode loop kept queued beyond the early-stop check it was waiting for (adapts: 1 on a host that keeps up) */
+    int32_t decode_launches_per_layer;   /* kernel launches per decoder layer of the token step the last run used (5: <= 2 rows, round 6; 6: fused bf16 / fp16 chain; 7: 33 - 64
+                                          * rows inside continuous loops; 8: int8 and the unfused chain) */
 } sonic_timings;
 
 /* ---- lifetime ---- */

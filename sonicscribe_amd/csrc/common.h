@@ -209,6 +209,9 @@ struct SkinnyArgs {
     const float* x_amax;             // i8 only, optional: X holds the UNQUANTISED fp16 rows and x_amax[row][0..3] partial maxima (written by the
                                      // producer's blocks) of their absmax without the elements >= 6.0: the kernel quantises its X slice while
                                      // staging it - int8 = rn(x * 127 / absmax), 0 for outliers (LLM.int8 row-wise)
+    // PRE form (skinny_xs_kernel<.., PRE>, M <= 2): X is not read - the block computes X = RMSNorm(pre_x + sum of the pre_ks slabs pre_P[ks][pre_mpad][K]) * pre_w
+    // itself (add_rmsnorm_kernel's arithmetic); block (0, 0) writes the updated residual rows to pre_xout (a buffer other than pre_x; may be null)
+    const float* pre_P; int pre_ks, pre_mpad; const bf16_t* pre_x; bf16_t* pre_xout; const float* pre_w; float pre_eps;
     int* err;                        // optional device error word (engine: n_active[1]): a kernel that gives up on an in-kernel wait ORs 1 into it; the greedy
                                      // kernel turns it into a negative running-row count, which every host-side check reads as a failed step
     long long* kt;                   // diagnostics: per-block timestamps [block][8] (100 MHz wall clock), null in production
@@ -227,6 +230,7 @@ struct SkinnyArgs {
 void launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 int skinny_pick_ksplit(int N, int K);
+bool skinny_pre_eligible(int M, int N, int K);
 int skinny_pick_ksplit_i8(int N, int K);
 bool skinny_gu_eligible(int M, int N, int K);
 void launch_skinny_gu(const SkinnyArgs& a, bf16_t* act, hipStream_t s);

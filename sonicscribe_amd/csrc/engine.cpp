@@ -112,7 +112,9 @@ struct sonic_engine {
     bf16_t *Kc = nullptr, *Vc = nullptr, *Vts = nullptr;
     float* dec_cs = nullptr;
     float *slab = nullptr, *lslab = nullptr, *ssq = nullptr;
+    float* slab2 = nullptr;                                         // down_proj's slabs when the next q|k|v (or the lm_head) consumes them itself (PRE form, <= 2 rows)
     bf16_t *sx = nullptr, *shn = nullptr, *sq = nullptr, *satt = nullptr, *sact = nullptr;
+    bf16_t* sx2 = nullptr;                                          // ... and the second residual buffer of that form (the stream ping-pongs layer by layer)
     int *kv_len = nullptr, *tok_pos = nullptr, *n_new = nullptr, *finished = nullptr, *max_new_d = nullptr, *n_active = nullptr;
     int *out_ids = nullptr, *step_ctr = nullptr, *seq_iota = nullptr;
     int *src = nullptr, *tok_seq = nullptr, *tok_pos_pf = nullptr, *q_off = nullptr, *q_len = nullptr, *last_row = nullptr;
@@ -160,6 +162,8 @@ struct sonic_engine {
     LaunchOpts opts;
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0, opt_gemm_trace = 0, opt_no_rope_tiles = 0, opt_prefill_rowmajor = 0;
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
+    int step_launches_per_layer = 0;   // of the token step built last (decode_step): sonic_timings.decode_launches_per_layer
+    int opt_no_pre_norm = 0;       // 1: never the PRE form of the <= 2-row decode step (standalone add+RMSNorm launches as for more rows; A/B - same bits)
     int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
     int* ring_peak = nullptr;                        // [Bm] per-request max |s| of a ring-staged batch (ingest.hip)
@@ -556,6 +560,7 @@ static int alloc_state(sonic_engine* e) {
     e->slabN = mx;
     A(dalloc_act(e, &e->ssq, (size_t)256 * 64));
     A(dalloc_act(e, &e->slab, (size_t)8 * 64 * mx)); A(dalloc_act(e, &e->lslab, (size_t)8 * 64 * d.vocab));
+    A(dalloc_act(e, &e->slab2, (size_t)8 * 16 * d.dec_d)); A(dalloc_act(e, &e->sx2, (size_t)16 * d.dec_d));
     A(dalloc_act(e, &e->sx, (size_t)64 * d.dec_d)); A(dalloc_act(e, &e->shn, (size_t)64 * d.dec_d)); A(dalloc(e, &e->sq, (size_t)64 * e->QD));
     A(dalloc_act(e, &e->satt, (size_t)64 * e->QD)); A(dalloc_act(e, &e->sact, (size_t)64 * d.dec_ff));
     A(dalloc(e, &e->kv_len, 64)); A(dalloc(e, &e->tok_pos, 64)); A(dalloc(e, &e->n_new, 64)); A(dalloc(e, &e->finished, 64));
@@ -662,7 +667,7 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     e->lc = root->lc; e->enc_cs = root->enc_cs; e->dec_cs = root->dec_cs;
     e->opts = root->opts; e->opt_no_graph = root->opt_no_graph; e->opt_no_fused_rope = root->opt_no_fused_rope; e->opt_no_gelu_lut = root->opt_no_gelu_lut;
     e->opt_i8_defer_thr = root->opt_i8_defer_thr; e->opt_i8_no_xq = root->opt_i8_no_xq; e->opt_i8_no_lnq = root->opt_i8_no_lnq; e->opt_i8_no_qkv_fuse = root->opt_i8_no_qkv_fuse;
-    e->opt_decode_chunk = root->opt_decode_chunk;
+    e->opt_decode_chunk = root->opt_decode_chunk; e->opt_no_pre_norm = root->opt_no_pre_norm;
     e->weight_bytes = 0; e->finalized = true; e->owner = root;
     root->slots.push_back(e);
     *out = e;
@@ -1249,9 +1254,30 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
     const int D = d.dec_d, mpad = ((R + 15) / 16) * 16, dt = e->dt;
     int ks;
     if (D > 8192) launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st, dt);   // else: done by the greedy kernel of the previous step
+    // <= 2 rows (the B = 1 call shape of BASELINE configs 1 and 5; round 6): no standalone add+RMSNorm launch behind down_proj - the next q|k|v projection
+    // (and, behind the last layer, the lm_head) sums the slabs, adds the residual and normalises its rows itself (skinny_xs_kernel<.., PRE>, the same
+    // arithmetic statement by statement: same bits).  Five launches per layer instead of six.  down_proj then writes its slabs to slab2 (the consumer
+    // writes slab while other blocks of it still read) and the residual stream alternates between sx and sx2.
+    const bool fuse_all = !d.dec_layers ? false : (e->dec[0].wgu_t8 && skinny_gu_eligible(R, 2 * d.dec_ff, D) && skinny_o_eligible(R, D, e->QD));
+    const bool pre = fuse_all && !e->opt_no_pre_norm && skinny_pre_eligible(R, e->qkvN, D) && skinny_pre_eligible(R, d.vocab, D) && D % 8 == 0;
+    bf16_t* resid = e->sx;                               // where the residual rows live right now
+    int ks_down = 0;
+    e->step_launches_per_layer = !fuse_all ? 8 : pre ? 5 : ((e->opts.gu64_split_norm > 0 || (e->opts.gu64_split_norm == 0 && e->cap_svc)) && R > 32 && D % 128 == 0 && D <= 2048) ? 7 : 6;
+    auto skinny_pre = [&](const bf16_t* W, float* P, int N, const float* nw, bf16_t* xout, int* ks_out, long long* kt) {
+        SkinnyArgs a{}; a.kt = kt;
+        a.X = resid; a.ldx = D; a.W = W; a.P = P; a.M = R; a.N = N; a.K = D; a.ksplit = skinny_pick_ksplit(N, D); a.dt = dt;
+        a.pre_P = e->slab2; a.pre_ks = ks_down; a.pre_mpad = mpad; a.pre_x = resid; a.pre_xout = xout; a.pre_w = nw; a.pre_eps = d.dec_rms_eps;
+        if (ks_out) *ks_out = a.ksplit;
+        launch_skinny(a, e->st);
+    };
     for (int l = 0; l < d.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
+        if (pre && l > 0) {
+            bf16_t* other = resid == e->sx ? e->sx2 : e->sx;
+            skinny_pre(L.wqkv_t, e->slab, e->qkvN, L.ln1, other, &ks, kt_slot(e, l, 0));
+            resid = other;
+        } else
         skinny(e, e->shn, D, L.wqkv_t, e->slab, R, e->qkvN, D, &ks, kt_slot(e, l, 0));
         DecodeAttnArgs da{}; da.kt = kt_slot(e, l, 1);
         da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = dt;     // RoPE + KV append fused into the attention kernel
@@ -1264,8 +1290,8 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             // o_proj + residual add (+ row sum-of-squares partials) -> gate/up with RMSNorm applied while staging X + SwiGLU:
             // two kernels instead of o_proj, add+RMSNorm, gate/up, SwiGLU
             SkinnyArgs oa{}; oa.X = e->satt; oa.ldx = e->QD; oa.W = L.wo_t; oa.M = R; oa.N = D; oa.K = e->QD; oa.ksplit = 1; oa.dt = dt; oa.kt = kt_slot(e, l, 2);
-            launch_skinny_o(oa, e->sx, D, e->ssq, e->st);
-            SkinnyArgs ga{}; ga.X = e->sx; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt; ga.kt = kt_slot(e, l, 3); ga.err = e->n_active + 1;
+            launch_skinny_o(oa, resid, D, e->ssq, e->st);
+            SkinnyArgs ga{}; ga.X = resid; ga.ldx = D; ga.W = L.wgu_t8; ga.M = R; ga.N = 2 * d.dec_ff; ga.K = D; ga.ksplit = 1; ga.dt = dt; ga.kt = kt_slot(e, l, 3); ga.err = e->n_active + 1;
             if ((e->opts.gu64_split_norm > 0 || (e->opts.gu64_split_norm == 0 && e->cap_svc)) && R > 32 && D % 128 == 0 && D <= 2048) {
                 // 33 .. 64 rows: the rows are normalised ONCE by their own small kernel (from the same partials, in the same order: same bits) and
                 // gate/up stages them as they are - 256 blocks each normalising all 64 rows was the longest single piece of the 64-row step
@@ -1284,10 +1310,14 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
             launch_swiglu_slab(e->slab, ks, mpad, 2 * d.dec_ff, e->sact, R, e->st, dt, L.wgu_t ? 0 : 1);
         }
         }
-        skinny(e, e->sact, d.dec_ff, L.wdown_t, e->slab, R, D, d.dec_ff, &ks, kt_slot(e, l, 4));
+        skinny(e, e->sact, d.dec_ff, L.wdown_t, pre ? e->slab2 : e->slab, R, D, d.dec_ff, &ks, kt_slot(e, l, 4));
+        ks_down = ks;
+        if (pre) continue;                               // the next layer's q|k|v (or the lm_head) consumes the slabs
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
         launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, dt);
     }
+    if (pre) skinny_pre(e->embed_t, e->lslab, d.vocab, e->dec_nw, nullptr, nullptr, nullptr);   // tied lm_head behind the last layer's slabs (the updated residual is not needed again)
+    else
     skinny(e, e->shn, D, e->embed_t, e->lslab, R, d.vocab, D, nullptr);   // tied lm_head (modeling_glmasr.py:517)
     launch_greedy(greedy_args(e, R, dump), e->st);
 }
@@ -1298,6 +1328,7 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
 // (half the bytes of the bf16 step) into exact int32 slabs, and the consumer dequantises them (int8_util.h deq4).
 static void decode_step_i8(sonic_engine* e, int R, bool dump) {
     const sonic_dims& d = e->d;
+    e->step_launches_per_layer = 8;
     const int D = d.dec_d, FF = d.dec_ff, mpad = ((R + 15) / 16) * 16;
     const QuantOut q_hn{e->hn_q, D, e->sca_hn, e->oc_hn, e->ol_hn, D, e->ov_hn};
     const QuantOut q_att{e->att_q, e->QD, e->sca_att, e->oc_att, e->ol_att, e->QD, e->ov_att};
@@ -1849,7 +1880,7 @@ static int run_all(sonic_engine* e, const int32_t* req_win, int R, const int32_t
     }
     t.decode_steps = steps_done;
     t.host_prefill_enqueue_ms = (float)host_enqueue_first; t.host_decode_launch_ms = (float)e->host_launch_ms; t.host_decode_wait_ms = (float)e->host_wait_ms;
-    t.host_decode_launches = e->host_launches; t.decode_lookahead = e->lookahead;
+    t.host_decode_launches = e->host_launches; t.decode_lookahead = e->lookahead; t.decode_launches_per_layer = e->step_launches_per_layer;
     if (!e->run_starved && e->lookahead > 1) e->lookahead -= 1;       // a batch whose queue never ran dry: one chunk less ahead next time
     return SONIC_OK;
 }
@@ -2142,6 +2173,7 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     hipLaunchKernelGGL(service_reset_kernel, dim3(1), dim3(64), 0, e->st, e->kv_len, e->tok_pos, e->n_new, e->finished, e->max_new_d, e->n_active);
     if (e->force_d) return fail(e, SONIC_ERR_INVALID, "teacher forcing is set: clear it before continuous decoding");
     hipGraphExec_t gx = nullptr;                            // the chunk graphs exist before the first splice: nothing captures on this stream later
+    if (e->Bm >= 2 && !e->i8) TRY(chunk_graph(e, 2, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx, true));   // a pool with at most two occupied rows (round 6: five launches per layer)
     for (int R = 16; ; R += 16) {                           // one per 16 rows (sonic_service_step runs as many rows as are occupied)
         const int r = R < e->Bm ? R : e->Bm;
         TRY(chunk_graph(e, r, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx, true));
@@ -2213,6 +2245,7 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
     // sonic_service_begin) - a lightly loaded pool does not pay the step time of a full one (1.15 ms for 1-16 rows, 1.35 for 32, 1.83 for 64)
     int R = rows <= 0 || rows > e->Bm ? e->Bm : (rows + 15) / 16 * 16;
     if (R > e->Bm) R = e->Bm;
+    if (rows > 0 && rows <= 2 && e->Bm >= 2 && !e->i8) R = 2;      // one or two sessions' rows: the <= 2-row step (same bits per row as any other row count)
     auto read_check = [&](bool block) -> int {
         const int i = (int)(e->svc_checked % CHK_RING);
         if (!block) { const hipError_t q = hipEventQuery(e->chk_ev[i]); if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; } if (q != hipSuccess) return -1; }
@@ -2818,6 +2851,8 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "i8_defer_thr")) { e->opt_i8_defer_thr = value; return SONIC_OK; }   // int8: outlier lists longer than this go to the dense side product (-1: never)
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
+    if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }   // <= 2 rows: standalone add+RMSNorm launches as for more rows (A/B, same bits)
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "decode_lookahead")) { e->lookahead = value < 1 ? 1 : (value > CHK_MAX_AHEAD ? CHK_MAX_AHEAD : value); return SONIC_OK; }   // start value (it adapts)
     if (!strcmp(key, "decode_chunk")) { e->opt_decode_chunk = value > 0 ? (value > 64 ? 64 : value) : 1; return SONIC_OK; }   // token steps per graph launch / early-stop check

@@ -437,7 +437,13 @@ __global__ __launch_bounds__(512) void skinny_readfloor_kernel(SkinnyArgs a) {
 // XQ (int8 kind): the activation rows arrive unquantised (fp16) with their absmax; the block quantises its slice on the way into LDS.  This
 // removes the separate one-block-per-row quantisation launch between a producer that does not own whole rows (decode attention: one block
 // per (row, kv head); the fused gate/up kernel: 24 columns per block) and the projection that consumes it.
-template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = false>
+// PRE (16-bit kinds, M <= 2; round 6): the block computes its X slice itself from the PREVIOUS projection's slabs - X = RMSNorm(x + sum of slabs), the
+// arithmetic of add_rmsnorm_kernel statement by statement (thread c of a row's 256 owns columns 8c .. 8c + 7; slabs added in ascending order from 0.f;
+// sum of squares per thread in column order, wave butterfly, the row's four wave partials in order) - so the standalone add+RMSNorm launch between
+// down_proj and the next q|k|v projection (or the lm_head) disappears at no change of any bit.  Every block redoes the whole row (it needs the row's
+// sum of squares): 68 KiB of slab and residual reads per row and block out of L2, which pays below three rows.  The updated residual row is written
+// by block (0, 0) to a SECOND buffer (other blocks still read the old one), so the residual stream ping-pongs between two buffers layer by layer.
+template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = false, bool PRE = false>
 __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
     typedef typename KD::elem ET_; typedef typename KD::frag Frag; typedef typename KD::acc Acc;
     // element size; elements per 16-B chunk, per MFMA k-step, per 128-B LDS row, per 1-KiB weight tile
@@ -468,6 +474,8 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xq[p]) : "v"(src) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xam[p]) : "v"(am) : "memory");
         }
+    } else if constexpr (PRE) {
+        // requested below, beside the weights (asm loads + one counted wait: the weights stay in flight while the rows are normalised)
     } else {
         const int lr = lane >> 3, lc = (lane & 7) ^ lr;
 #pragma unroll
@@ -480,6 +488,26 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(smem + ii * 1024), 16, 0, 0);
             }
+        }
+    }
+    // PRE: this thread's share of the previous projection's slabs, the residual row and the norm weight (19 loads of 16 bytes), requested first
+    static_assert(!PRE || (!KD::I8 && !XQ), "PRE: 16-bit kinds");
+    __shared__ float pre_part[8];
+    const int prow = tid >> 8, pc = tid & 255;                       // PRE: row 0 -> threads 0 .. 255, row 1 -> 256 .. 511
+    const bool pvalid = PRE && prow < a.M && pc < (a.K >> 3);
+    f32x4 pnw0, pnw1, psl0[8], psl1[8]; i32x4 pxr;
+    if constexpr (PRE) {
+        const int cc = pvalid ? pc : 0, rr = prow < a.M ? prow : 0;
+        const float* wq = a.pre_w + cc * 8;
+        const ET_* xq = (const ET_*)a.pre_x + (long)rr * a.K + cc * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pnw0) : "v"(wq) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(pnw1) : "v"(wq) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pxr) : "v"(xq) : "memory");
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float* sp = a.pre_P + ((long)(ks < a.pre_ks ? ks : 0) * a.pre_mpad + rr) * a.K + cc * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(psl0[ks]) : "v"(sp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(psl1[ks]) : "v"(sp) : "memory");
         }
     }
     // then the weights (HBM, nontemporal): asm loads with hand-counted waits, so that k-step u is multiplied as soon as ITS fragment
@@ -504,7 +532,46 @@ __global__ __launch_bounds__(512) void skinny_xs_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][mb][e] = 0;
     KT(a, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");       // this wave's X pieces are in LDS (XQ: in registers)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");       // this wave's X pieces are in LDS (XQ / PRE: in registers)
+    if constexpr (PRE) {
+        typedef typename std::conditional<std::is_same<ET_, f16_t>::value, f16x8, bf16x8>::type PV8;
+        asm volatile("" : "+v"(pnw0), "+v"(pnw1), "+v"(pxr));
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(psl0[ks]), "+v"(psl1[ks]));
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < a.pre_ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += psl0[ks][j]; acc[4 + j] += psl1[ks][j]; }
+            }
+        const PV8 tx = __builtin_bit_cast(PV8, pxr);
+        PV8 ox; float v[8]; float ssq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ox[j] = (ET_)((float)tx[j] + rT<ET_>(acc[j])); v[j] = (float)ox[j]; ssq += v[j] * v[j]; }
+        if (!pvalid) ssq = 0.f;
+        if (pvalid && a.pre_xout && blockIdx.x == 0 && blockIdx.y == 0) *(PV8*)((ET_*)a.pre_xout + (long)prow * a.K + pc * 8) = ox;
+        ssq = wave_sum(ssq);
+        if (lane == 0) pre_part[wid] = ssq;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // (raw barrier: __syncthreads would add a vmcnt(0) fence - the weights are still in flight)
+        asm volatile("" ::: "memory");
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tot += pre_part[(prow & 1) * 4 + i];
+        const float rs = 1.0f / sqrtf(tot / a.K + a.pre_eps);
+        const int kcol = pc * 8 - kb;                                // this thread's 8 columns inside the block's K slice?
+        if (pvalid && kcol >= 0 && kcol < BKk) {
+            PV8 oy;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oy[j] = (ET_)((j < 4 ? pnw0[j & 3] : pnw1[j & 3]) * rT<ET_>(v[j] * rs));
+            const int kblock = kcol / ROWE, ch = (kcol % ROWE) / CE;
+            // image rows beyond M hold copies of the last row (as the DMA path's clamped rows): their outputs are never consumed
+            for (int m = prow; m < MB * 16; m += (prow == a.M - 1 ? 1 : MB * 16))
+                *(PV8*)(smem + kblock * KBS + m * 128 + ((ch ^ (m & 7)) << 4)) = oy;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if constexpr (XQ) {
         // quantise (elementwise.hip quant_emit_row's arithmetic) and park in the image: byte (row m, element k) of a 128-element k-block at
         // kblock * KBS + m * 128 + ((chunk ^ (m & 7)) << 4) + k % 16
@@ -1275,12 +1342,20 @@ template <typename KD, int MB> static void launch_skinny_mb(const SkinnyArgs& a,
         default: launch_skinny_v<KD, MB, 1>(a, s); break;
     }
 }
-template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = false> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
+template <typename KD, int MB, int WN, int WK, int KSW, int NT = 1, bool XQ = false, bool PRE = false> static void launch_xs_v(const SkinnyArgs& a, int nkslices, hipStream_t s) {
     constexpr int EB = sizeof(typename KD::elem), KS = 64 / EB, ROWE = 128 / EB;
     constexpr int NI = (WK * KSW * KS / ROWE) * MB * 2;
     const size_t img = (size_t)NI * 1024, red = (size_t)8 * NT * MB * 1024, lds = img > red ? img : red;
-    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW, NT, XQ>, (int)lds);
-    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW, NT, XQ>), dim3(a.N / (WN * NT * 16), nkslices), dim3(512), lds, s, a);
+    if (lds > 65536) ensure_dyn_lds((const void*)skinny_xs_kernel<KD, MB, WN, WK, KSW, NT, XQ, PRE>, (int)lds);
+    hipLaunchKernelGGL((skinny_xs_kernel<KD, MB, WN, WK, KSW, NT, XQ, PRE>), dim3(a.N / (WN * NT * 16), nkslices), dim3(512), lds, s, a);
+}
+// PRE form (SkinnyArgs.pre_P): M <= 2, 16-bit kinds, any of the shared-X tilings
+bool skinny_pre_eligible(int M, int N, int K) { return M >= 1 && M <= 2 && K % 8 == 0 && K <= 2048 && skinny_pick_cfg(N, K) != 0; }
+template <typename KD> static void launch_skinny_xs_pre(const SkinnyArgs& a, int cfg, hipStream_t s) {
+    if (cfg == 1) launch_xs_v<KD, 1, 4, 2, 16, 1, false, true>(a, a.K / 1024, s);
+    else if (cfg == 3) launch_xs_v<KD, 1, 4, 2, 12, 1, false, true>(a, a.K / 768, s);
+    else if (cfg == 4) launch_xs_v<KD, 1, 1, 8, 2, 3, false, true>(a, a.K / 512, s);
+    else launch_xs_v<KD, 1, 2, 4, 4, 1, false, true>(a, a.K / 512, s);
 }
 template <typename KD, int MB> static void launch_skinny_xs(const SkinnyArgs& a, int cfg, hipStream_t s) {
     if (cfg == 1) launch_xs_v<KD, MB, 4, 2, 16>(a, a.K / 1024, s);
@@ -1336,6 +1411,7 @@ template <int MB> static void launch_skinny_i8(const SkinnyArgs& a, hipStream_t 
 template <typename KD> static void launch_skinny_16(const SkinnyArgs& a, hipStream_t s) {
     const int cfg = skinny_pick_cfg(a.N, a.K);
     const int mb = (a.M + 15) / 16;
+    if (a.pre_P) { launch_skinny_xs_pre<KD>(a, cfg, s); return; }      // (the caller checked skinny_pre_eligible)
     if (cfg) {
         if (mb <= 1) launch_skinny_xs<KD, 1>(a, cfg, s);
         else if (mb == 2) launch_skinny_xs<KD, 2>(a, cfg, s);

@@ -57,7 +57,7 @@ class SonicTimings(C.Structure):
         ("gemm_ms", C.c_float), ("gemm_launches", C.c_int32), ("gemm_flops", C.c_double), ("decode_steps", C.c_int32),
         ("enc_gemm_ms", C.c_float), ("enc_gemm_flops", C.c_double),
         ("host_prefill_enqueue_ms", C.c_float), ("host_decode_launch_ms", C.c_float), ("host_decode_wait_ms", C.c_float), ("host_decode_launches", C.c_int32),
-        ("decode_lookahead", C.c_int32),
+        ("decode_lookahead", C.c_int32), ("decode_launches_per_layer", C.c_int32),
     ]
 
 

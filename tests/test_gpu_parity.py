@@ -623,3 +623,62 @@ def test_streaming_sessions_coalesced():
     assert [tuple(x) for x in got] == want
     assert all(len(a.split()) == 15 for a, _ in want)
     m.close()
+
+
+@pytest.mark.parametrize("dims_tag", ["fullwidth", "tiny"])
+def test_two_row_decode_step_without_add_rmsnorm_launches(dims_tag):
+    """Round 6: at <= 2 rows the token step has five launches per layer - the q|k|v projection (and, behind the last layer, the
+    lm_head) sums down_proj's slabs, adds the residual and normalises its rows itself (skinny_xs_kernel<.., PRE>).  It restates add_rmsnorm_kernel
+    statement by statement, so: the logits of every step are the same BITS as with the standalone launches (option no_pre_norm), eagerly and through
+    the captured graphs, a row alone equals the same row inside a batch of 5 (which takes the six-launch chain), and a continuous loop with one or
+    two occupied rows (the R = 2 chunk graph) returns the solo tokens.  HF semantics: modeling_llama.py:60-65, 306-324."""
+    from dataclasses import replace
+    from sonicscribe_amd.engine import Engine
+    d = (replace(spec.FULL, enc_layers=1, dec_layers=3, vocab=1024, audio_token_id=1000, eos_ids=()) if dims_tag == "fullwidth"
+         else replace(spec.TINY, eos_ids=()))
+    e = Engine(d, 0, max_batch=16, max_ctx=384)
+    e.load_synthetic(11)
+    lens = [16000 * (1 + i) + 37 * i for i in range(5)]
+    segs = [synth.synth_pcm(700 + i, n) for i, n in enumerate(lens)]
+    prompts = [[1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(n)) + [7, 301, 302, 303, 9, 11][: 3 + i % 4] for i, n in enumerate(lens)]
+    n_new = 9
+    ids5, log5 = e.transcribe_batch(segs, prompts, [n_new] * 5, want_logits=True)                  # five rows: the six-launch chain
+    per_layer_5 = e.timings()["decode_launches_per_layer"]
+    for R in (1, 2):
+        ids_p, log_p = e.transcribe_batch(segs[:R], prompts[:R], [n_new] * R, want_logits=True)
+        took = e.timings()["decode_launches_per_layer"]
+        ids_g, _ = e.transcribe_batch(segs[:R], prompts[:R], [n_new] * R)                         # graph replay
+        e.set_option("no_pre_norm", 1)
+        try:
+            ids_n, log_n = e.transcribe_batch(segs[:R], prompts[:R], [n_new] * R, want_logits=True)
+            took_n = e.timings()["decode_launches_per_layer"]
+        finally:
+            e.set_option("no_pre_norm", 0)
+        assert np.array_equal(log_p.view(np.uint32), log_n.view(np.uint32)), R
+        assert np.array_equal(log_p.view(np.uint32), log5[:, :R].view(np.uint32)), R             # batch invariance across the two chains
+        for i in range(R):
+            assert np.array_equal(ids_p[i], ids_n[i]) and np.array_equal(ids_p[i], ids_g[i]) and np.array_equal(ids_p[i], ids5[i])
+        if dims_tag == "fullwidth":
+            assert (took, took_n, per_layer_5) == (5, 6, 6), (took, took_n, per_layer_5)          # the five-launch chain really ran
+    # continuous loop: one, then two occupied rows (R = 2 chunk graphs), then a third joins (R = 16 graphs)
+    pre = e.slot()
+    e.service_begin()
+    got = {}
+    pre.stage_pcm(segs[:1]); pre.prefill(prompts[:1], [n_new])
+    seq = {0: e.splice_rows(pre, [0], [0])}
+    for step in range(200):
+        if step == 1:
+            pre.stage_pcm(segs[1:2]); pre.prefill(prompts[1:2], [n_new]); seq[1] = e.splice_rows(pre, [0], [1])
+        if step == 2:
+            pre.stage_pcm(segs[2:3]); pre.prefill(prompts[2:3], [n_new]); seq[2] = e.splice_rows(pre, [0], [2])
+        top = max([r for r in seq if r not in got], default=-1) + 1
+        if top == 0 and step > 2:
+            break
+        fin, nn, s_, _ = e.service_step(1, max(top, 1))
+        for r in list(seq):
+            if r not in got and s_ > seq[r] and fin[r]:
+                got[r] = e.fetch_row(r, int(nn[r]))
+    e.service_end()
+    for r in range(3):
+        assert np.array_equal(got[r], ids5[r]), r
+    e.close()
