@@ -284,3 +284,53 @@ def test_back_to_back_enqueued_prefills_keep_their_own_plans(dims):
         assert len(ids) == budgets[v][i] and np.array_equal(ids, solo[v][i]), (v, i)
     dec.service_end()
     dec.close()
+
+
+def test_native_dispatcher_failure_cancel_and_close_paths():
+    """csrc/dispatch.cpp beyond the happy path: a queued request can be cancelled (its future is cancelled, the library drops it before it reaches a
+    handle); close() fails what is still queued and completes what is running; a device error raised inside a decode loop (the error word a fused
+    kernel sets when it gives up on an in-kernel wait, injected here) fails every request in flight and queued with the engine's message, and
+    later submits are refused - nothing hangs.  Call sites: connection_manager.py:127-245 (a session that goes away), main.py:84-86 (model release)."""
+    from sonicscribe_amd.asr import ASRModel
+    from sonicscribe_amd.dispatch import _NativeContinuousReplica
+    d = replace(spec.TINY, eos_ids=())
+    m = ASRModel.from_synthetic(d, device="cuda:0", max_batch=4, max_ctx=512, slots=2, continuous=True)
+    rep = m._dispatcher.replicas[0]
+    assert isinstance(rep, _NativeContinuousReplica)
+    wav = synth.synth_pcm(5, 16000 * 3).astype(np.float32) / 32768.0
+    want = m.transcribe(wav[None], 16000, max_new_tokens=40)
+    # 12 long requests on a 4-row pool: the last ones are still queued when they are cancelled
+    futs = [m.submit(wav[None], 16000, 200) for _ in range(12)]
+    cancelled = [f for f in futs[6:] if f.cancel()]
+    assert len(cancelled) >= 1
+    for f in futs:
+        if f not in cancelled:
+            assert isinstance(f.result(timeout=120), str)
+    assert m.transcribe(wav[None], 16000, max_new_tokens=40) == want          # the dispatcher goes on
+    # device error inside the loop
+    running = [m.submit(wav[None], 16000, 300) for _ in range(6)]
+    m.model.set_option("inject_dev_err", 1)
+    errs = 0
+    for f in running:
+        try:
+            f.result(timeout=120)
+        except Exception as ex:
+            errs += 1
+            assert "in-kernel wait" in str(ex) or "failed" in str(ex) or "closed" in str(ex), ex
+    assert errs >= 1
+    with pytest.raises(Exception):
+        m.submit(wav[None], 16000, 4).result(timeout=60)
+    m.model.set_option("inject_dev_err", 0)
+    m.close()
+    # close() with work queued: everything resolves
+    m2 = ASRModel.from_synthetic(d, device="cuda:0", max_batch=4, max_ctx=512, slots=2, continuous=True)
+    futs = [m2.submit(wav[None], 16000, 150) for _ in range(16)]
+    m2.close()
+    n_ok = 0
+    for f in futs:
+        assert f.done()
+        if f.exception() is None:
+            n_ok += 1
+        else:
+            assert "closed" in str(f.exception())
+    assert 1 <= n_ok <= 16
