@@ -508,8 +508,10 @@ template <> struct PV16<f16_t> {
 //     VALU-bound at 0.9 us per slice (in-kernel timeline, profiles/round2_decode_timeline.txt).
 //  3. the new key comes from LDS; the 8 waves' (m, l, acc) states are merged through LDS.
 // Probabilities are rounded to bf16 for the P.V product and kept in fp32 for the row sum, as in the prefill kernel.
-template <typename T>
-__global__ __launch_bounds__(512) void decode_attn_kernel(DecodeAttnArgs a) {
+// WPE = waves per SIMD the register allocation leaves room for: 2 (151 VGPRs: this kernel alone on its CU) or 4 (128 VGPRs, 21 dwords spilled: a second 8-wave
+// block - another decode loop's attention, or its q|k|v / down_proj - fits beside it; option decode_attn_occ2, A/B in profiles/round6_attn_occupancy.txt)
+template <typename T, int WPE = 2>
+__global__ __launch_bounds__(512, WPE) void decode_attn_kernel(DecodeAttnArgs a) {
     typedef typename ET<T>::v8 V8;
     constexpr int HD = 128, HALF = 64, GMAX = 4, NW = 8;
     __shared__ __attribute__((aligned(16))) float s_acc[NW][GMAX][HD];
@@ -761,5 +763,6 @@ void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {
 #ifdef SONIC_AB
     if (g_opts.decode_attn_v1) { DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_v1_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a)); return; }
 #endif
-    DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a));
+    if (g_opts.decode_attn_occ2) { DT_SWITCH(a.dt, T, hipLaunchKernelGGL((decode_attn_kernel<T, 4>), dim3(B, a.Hkv), dim3(512), 0, s, a)); return; }
+    DT_SWITCH(a.dt, T, hipLaunchKernelGGL((decode_attn_kernel<T, 2>), dim3(B, a.Hkv), dim3(512), 0, s, a));
 }

@@ -72,6 +72,7 @@ struct LaunchOpts {
     int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)
     int no_skinny_i8_wide = 0; // int8 decode skinny GEMM: always 32 rows x 1024 per block (A/B)
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
+    int decode_attn_occ2 = 0;  // decode attention compiled for 128 VGPRs (two 8-wave blocks per CU can co-reside; a few spilled registers): A/B
     int decode_attn_v1 = 0;    // decode attention with P.V on the VALU (round 2), for A/B runs
     int flash_variant = 2;     // prefill / encoder attention: bit 0 two LDS buffers + one barrier per tile (no gain measured), bit 1 lazy accumulator rescale (-0.6 ms per batch; default)
     int flash_enc = 1;         // encoder attention (head dim 64, no mask): 0 = flash_attn_kernel (rounds 1-4), v > 0 = flash_enc_kernel mode v - 1 (attn_enc.hip; round 5)

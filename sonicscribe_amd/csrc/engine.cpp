@@ -2849,6 +2849,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm256_persist_cus")) { e->opts.gemm256_persist_cus = value > 0 ? value : 256; return SONIC_OK; }
     if (!strcmp(key, "gemm256_gm")) { e->opts.gemm256_gm = value > 0 ? value : 8; return SONIC_OK; }   // raster group height of the 256x256 GEMM (experiments)
     if (!strcmp(key, "i8_defer_thr")) { e->opt_i8_defer_thr = value; return SONIC_OK; }   // int8: outlier lists longer than this go to the dense side product (-1: never)
+    if (!strcmp(key, "decode_attn_occ2")) { e->opts.decode_attn_occ2 = value; drop_graphs(e); return SONIC_OK; }   // decode attention at 128 VGPRs (two blocks per CU can co-reside; A/B)
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }
