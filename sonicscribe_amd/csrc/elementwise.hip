@@ -686,7 +686,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-__global__ void synth_fill_kernel(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32) {
+__global__ void synth_fill_kernel(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, int round_f32) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long z = mix64(key + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ULL);
@@ -694,7 +694,7 @@ __global__ void synth_fill_kernel(unsigned long long key, long n, float scale, f
     const float r = __fsub_rn(__fmul_rn((float)bits, 0x1p-23f), 1.0f);
     const float v = __fadd_rn(offset, __fmul_rn(r, scale));
     if (out_bf) out_bf[i] = f2bf(v);
-    if (out_f32) out_f32[i] = out_bf ? rbf(v) : v;      // fp32 alone: the generator's exact value (synth.synth_fill(..., bf16=False))
+    if (out_f32) out_f32[i] = (out_bf || round_f32) ? rbf(v) : v;      // fp32 alone: the generator's exact value (synth.synth_fill(..., bf16=False)) unless round_f32
 }
 
 // ---------------------------------------------------------------- launchers
@@ -756,6 +756,6 @@ void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s, int
 void launch_bf16_to_f16(const bf16_t* in, bf16_t* out, long n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(bf16_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, (f16_t*)out, n);
 }
-void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(synth_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, key, n, scale, offset, out_bf, out_f32);
+void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s, int round_f32) {
+    if (n > 0) hipLaunchKernelGGL(synth_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, key, n, scale, offset, out_bf, out_f32, round_f32);
 }

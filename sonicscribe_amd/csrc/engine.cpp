@@ -163,6 +163,7 @@ struct sonic_engine {
     int opt_no_graph = 0, opt_gemm_timing = 0, opt_no_fused_rope = 0, opt_no_gelu_lut = 0, opt_gemm_trace = 0, opt_no_rope_tiles = 0, opt_prefill_rowmajor = 0;
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
     int step_launches_per_layer = 0;   // of the token step built last (decode_step): sonic_timings.decode_launches_per_layer
+    int opt_f32_synth_bf16 = 0;    // SONIC_MODE_F32: sonic_load_synthetic writes the bf16-rounded values (the weights a bf16 engine gets from the same seed) as fp32
     int opt_no_pre_norm = 0;       // 1: never the PRE form of the <= 2-row decode step (standalone add+RMSNorm launches as for more rows; A/B - same bits)
     int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
@@ -850,7 +851,7 @@ extern "C" int sonic_load_synthetic(sonic_engine* e, uint64_t seed) {
         else if (it.kind == 1) scale = (float)sqrt(3.0 / (double)it.shape[1]);
         else if (it.kind == 3) offset = 1.0f;
         const uint64_t key = mix64h(seed * 0x9E3779B97F4A7C15ULL + fnv1a64h(it.name.c_str()));
-        if (e->f32) launch_synth_fill(key, (long)numel(it.shape), scale, offset, nullptr, t32, e->st);     // the generator's exact fp32 values (synth.py bf16=False)
+        if (e->f32) launch_synth_fill(key, (long)numel(it.shape), scale, offset, nullptr, t32, e->st, e->opt_f32_synth_bf16);     // the generator's exact fp32 values (synth.py bf16=False); option f32_synth_bf16: the bf16-rounded ones (the weights of a bf16 engine with the same seed)
         else launch_synth_fill(key, (long)t->n, scale, offset, t->p, nullptr, e->st);
     }
     HIPC(e, stream_sync(e));
@@ -2853,6 +2854,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "f32_synth_bf16")) { e->opt_f32_synth_bf16 = value; return SONIC_OK; }
     if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }   // <= 2 rows: standalone add+RMSNorm launches as for more rows (A/B, same bits)
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)
     if (!strcmp(key, "decode_lookahead")) { e->lookahead = value < 1 ? 1 : (value > CHK_MAX_AHEAD ? CHK_MAX_AHEAD : value); return SONIC_OK; }   // start value (it adapts)

@@ -150,7 +150,7 @@ void launch_ring_stage(const RingStageArgs& a, int W, int max_n, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s, int dt = DT_BF16);      // fp32 -> element type
 void launch_bf16_to_f32(const bf16_t* in, float* out, long n, hipStream_t s, int dt = DT_BF16);      // element type -> fp32
 void launch_bf16_to_f16(const bf16_t* in, bf16_t* out, long n, hipStream_t s);                       // bf16 storage -> fp16 storage (RNE), in place allowed
-void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s);
+void launch_synth_fill(unsigned long long key, long n, float scale, float offset, bf16_t* out_bf, float* out_f32, hipStream_t s, int round_f32 = 0);   // round_f32: the fp32 output holds the bf16-rounded value
 
 // ---- int8 mode: activation / weight quantisation (quant.hip) ----
 // Row-wise int8 of a weight matrix [N][K] (fp16 storage): CB, SCB (Int8Params.cuda(): int8_vectorwise_quant(W.half()))

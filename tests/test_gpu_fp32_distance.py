@@ -84,3 +84,43 @@ def test_full_width_vocab_59264(golden_dir):
     e.set_forced_ids(None)
     e.close()
     closer_than_reference_bf16("full-width layers, vocabulary 59264", logits[:, 0, ::16], g32["step_logits_sub"], g16["step_logits_sub"])
+
+
+def test_full_depth_product_paths_against_the_fp32_kind():
+    """Round 6: the fp32 kind of the GPU path (SONIC_MODE_F32, itself within 1e-5 of the reference's fp32 fixtures: tests/test_gpu_fp32_mode.py) makes the fp32
+    truth available AT FULL DEPTH - 32 encoder + 28 decoder layers, vocabulary 59264 - where no fixture exists and the CPU oracle needs minutes per segment.
+    Same weights (the generator's bf16 values, held as fp32 in the fp32 engine), a 20 s and a 5 s segment in one batch, prefill + 7 teacher-forced steps:
+      * the bf16 product path (every production kernel, 60 layers deep) stays within a bf16-sized distance of the fp32 arithmetic: measured max |dlogit| 0.104,
+        mean 0.0145 on logits in [-4.8, 4.3]; bounds 0.125 (8 bf16 ulp of 2^-6, the full-depth bound of the oracle tests) and 0.02;
+      * its argmax equals the fp32 argmax wherever the fp32 top-1 / top-2 margin exceeds twice that bound;
+      * the fp16 kind of the same templates (SONIC_MODE_F16) is 9 x closer, as its rounding is: measured max 0.0115, mean 0.0016; bounds 0.02 / 0.003.
+    HF semantics: asr.py:407-422 (generate), modeling_glmasr.py:171-346, modeling_llama.py:217-324."""
+    from sonicscribe_amd.engine import Engine, MODE_F16, MODE_F32, MODE_NATIVE
+    d = replace(spec.FULL, eos_ids=())
+    segs = [synth.synth_pcm(70, 20 * 16000), synth.synth_pcm(71, 5 * 16000)]
+    prompts = [[1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(len(s))) + [7, 301, 302, 303, 9, 11] for s in segs]
+    rng = np.random.default_rng(17)
+    force = rng.integers(2, 59000, size=(2, 8)).astype(np.int32)
+    out = {}
+    for tag, mode in (("fp32", MODE_F32), ("bf16", MODE_NATIVE), ("fp16", MODE_F16)):
+        e = Engine(d, 0, mode, max_batch=2, max_ctx=512)
+        if mode == MODE_F32:
+            e.set_option("f32_synth_bf16", 1)
+        e.load_synthetic(SEED)
+        e.set_forced_ids(force)
+        ids, lg = e.transcribe_batch(segs, prompts, [8, 8], want_logits=True)
+        e.set_forced_ids(None)
+        assert all(np.array_equal(ids[r], force[r]) for r in range(2))
+        out[tag] = lg
+        e.close()
+    truth = out["fp32"]
+    assert np.isfinite(truth).all() and truth.std() > 0.3
+    srt = np.sort(truth, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    for tag, bound_max, bound_mean in (("bf16", 0.125, 0.02), ("fp16", 0.02, 0.003)):
+        dl = np.abs(out[tag] - truth)
+        agree = out[tag].argmax(-1) == truth.argmax(-1)
+        print(f"full depth (32 + 28 layers, vocabulary 59264), 2 rows x 8 steps, {tag} product path vs the fp32 kind: max |dlogit| {dl.max():.4f}, mean {dl.mean():.5f}, "
+              f"logits in [{truth.min():.2f}, {truth.max():.2f}], argmax equal at {int(agree.sum())} of {agree.size} (row, step) pairs, smallest fp32 margin {margin.min():.4f}")
+        assert dl.max() <= bound_max and dl.mean() <= bound_mean, (tag, float(dl.max()), float(dl.mean()))
+        assert agree[margin > 2 * bound_max].all()
