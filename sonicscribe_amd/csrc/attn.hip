@@ -523,6 +523,13 @@ __global__ __launch_bounds__(512, WPE) void decode_attn_kernel(DecodeAttnArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, g = lane >> 4;                        // S: head column r, keys 4g..4g+3;  K rows: key r, dim chunk g;  V: piece r of keys 4g..4g+3
     const int b = blockIdx.x, kvh = blockIdx.y;
+    if ((int)blockIdx.y >= a.Hkv) {                 // idle-CU prefetch blocks (experiment, option decode_prefetch): weights of later kernels -> L2 / Infinity Cache
+        const int blk = (blockIdx.y - a.Hkv) * gridDim.x + blockIdx.x, nblk = (gridDim.y - a.Hkv) * gridDim.x;
+        prefetch_share(a.pf[0], blk, nblk);
+        prefetch_share(a.pf[1], blk, nblk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     T* Kc = (T*)a.Kc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
     T* Vc = (T*)a.Vc + ((long)b * a.Hkv + kvh) * a.ctx_max * HD;
     const int cm1 = a.ctx_max - 1;
@@ -764,5 +771,5 @@ void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s) {
     if (g_opts.decode_attn_v1) { DT_SWITCH(a.dt, T, hipLaunchKernelGGL(decode_attn_v1_kernel<T>, dim3(B, a.Hkv), dim3(512), 0, s, a)); return; }
 #endif
     if (g_opts.decode_attn_occ2) { DT_SWITCH(a.dt, T, hipLaunchKernelGGL((decode_attn_kernel<T, 4>), dim3(B, a.Hkv), dim3(512), 0, s, a)); return; }
-    DT_SWITCH(a.dt, T, hipLaunchKernelGGL((decode_attn_kernel<T, 2>), dim3(B, a.Hkv), dim3(512), 0, s, a));
+    DT_SWITCH(a.dt, T, hipLaunchKernelGGL((decode_attn_kernel<T, 2>), dim3(B, a.Hkv + (a.pf_y > 0 ? a.pf_y : 0)), dim3(512), 0, s, a));
 }

@@ -72,6 +72,8 @@ struct LaunchOpts {
     int gemm128_shallow = 0;   // 128x128 GEMM: always the two-stage ring (A/B)
     int no_skinny_i8_wide = 0; // int8 decode skinny GEMM: always 32 rows x 1024 per block (A/B)
     int gemm256_stagger = 1;   // 256x256 GEMM: SIMD partner waves run half a phase apart
+    int decode_prefetch = 0;   // bit 0: the decode attention launch's idle CUs (<= 32 rows) stream o_proj's weights, bit 1: ... and the first half of gate/up's, bit 2: the
+                               // add+RMSNorm launch's idle CUs stream the next q|k|v's (experiment, profiles/round6_prefetch_ab.txt)
     int decode_attn_occ2 = 0;  // decode attention compiled for 128 VGPRs (two 8-wave blocks per CU can co-reside; a few spilled registers): A/B
     int decode_attn_v1 = 0;    // decode attention with P.V on the VALU (round 2), for A/B runs
     int flash_variant = 2;     // prefill / encoder attention: bit 0 two LDS buffers + one barrier per tile (no gain measured), bit 1 lazy accumulator rescale (-0.6 ms per batch; default)
@@ -111,6 +113,24 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Idle-CU weight prefetch (round 6 experiment, option decode_prefetch): blocks beyond a kernel's own grid stream a byte range - the weights a LATER kernel of
+// the token step will read - through plain (temporal) loads whose data is discarded, so the range is resident in the Infinity Cache / an XCD's L2 when its
+// consumer asks for it.  Block `blk` of `nblk` takes a contiguous share; 16 bytes per lane and load, every load in flight before the one wait.
+struct PrefetchRange { const void* p; long bytes; };
+__device__ __forceinline__ void prefetch_share(const PrefetchRange& r, int blk, int nblk) {
+    if (!r.p || r.bytes <= 0) return;
+    const long step = (long)blockDim.x * 16;
+    const long per = ((r.bytes + nblk - 1) / nblk + step - 1) / step * step;
+    const long lo = (long)blk * per, hi = lo + per < r.bytes ? lo + per : r.bytes;
+    const char* q = (const char*)r.p;
+    // the destination registers stay allocated ("+v") until the loads have landed: an output the compiler believes dead would be handed to the address
+    // arithmetic of the next iteration while the data of an earlier load is still on its way into it
+    i32x4 t = {0, 0, 0, 0};
+    for (long off = lo + (long)threadIdx.x * 16; off + 16 <= hi; off += step)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(t) : "v"(q + off) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t) :: "memory");
 }
 
 // ---- GEMM launch descriptors (gemm.hip) ----

@@ -198,8 +198,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const float* w
 // int8 mode (dq.sca != null): P holds the int32 slabs of the quantised projection; the normalised row is also emitted quantised (qo.q).
 template <typename T>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* x, const float* P, int ksplit, int mpad, const float* w, T* y,
-                                                          int rows, int d, float eps, DeqInfo dq, QuantOut qo) {
+                                                          int rows, int d, float eps, DeqInfo dq, QuantOut qo, PrefetchRange pf) {
     typedef typename ET<T>::v8 V8;
+    if ((int)blockIdx.x >= rows) {                    // idle-CU prefetch blocks (experiment, option decode_prefetch bit 2): stream the next q|k|v's weights and leave
+        prefetch_share(pf, blockIdx.x - rows, gridDim.x - rows);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     __shared__ float part[16], qpart[16];             // (qpart / qparti: the re-quantisation's own scratch - no barrier before its first write)
     __shared__ int parti[17], qparti[17];
     __shared__ int s_ok[OUTL_CAP];
@@ -709,11 +714,13 @@ void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d,
     else { DT_SWITCH(dt, T, hipLaunchKernelGGL((rmsnorm_kernel<T, false>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, w, (T*)y, rows, d, eps, row_map, q)); }
 }
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
-                        int dt, const DeqInfo* dq, const QuantOut* qo) {
+                        int dt, const DeqInfo* dq, const QuantOut* qo, const PrefetchRange* pf, int pf_blocks) {
     const int threads = ((d >> 3) + 63) / 64 * 64;   // d <= 2048 -> <= 256 threads
     const DeqInfo q = dq ? *dq : DeqInfo{};
     const QuantOut o = qo ? *qo : QuantOut{};
-    DT_SWITCH(dt, T, hipLaunchKernelGGL(add_rmsnorm_kernel<T>, dim3(rows), dim3(threads), 0, s, (T*)x, P, ksplit, mpad, w, (T*)y, rows, d, eps, q, o));
+    const PrefetchRange r = pf ? *pf : PrefetchRange{nullptr, 0};
+    const int extra = pf && pf->p && pf_blocks > 0 ? pf_blocks : 0;
+    DT_SWITCH(dt, T, hipLaunchKernelGGL(add_rmsnorm_kernel<T>, dim3(rows + extra), dim3(threads), 0, s, (T*)x, P, ksplit, mpad, w, (T*)y, rows, d, eps, q, o, r));
 }
 void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt, int gu8) {
     const long n = (long)rows * (n2 >> 3);

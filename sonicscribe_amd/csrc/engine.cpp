@@ -1284,6 +1284,12 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         da.P = e->slab; da.ksplit = ks; da.mpad = mpad; da.cs = e->dec_cs; da.dt = dt;     // RoPE + KV append fused into the attention kernel
         da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
         da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
+        if ((e->opts.decode_prefetch & 3) && R * d.dec_kv_heads <= 128 && L.wo_t) {
+            // experiment: the attention launch covers R x Hkv of the 256 CUs - the others stream the weights of the kernels behind it
+            da.pf_y = (256 - R * d.dec_kv_heads) / R;
+            if (e->opts.decode_prefetch & 1) da.pf[0] = PrefetchRange{L.wo_t, (long)D * e->QD * 2};
+            if ((e->opts.decode_prefetch & 2) && L.wgu_t8) da.pf[1] = PrefetchRange{L.wgu_t8, (long)d.dec_ff * D * 2};       // the first half of gate/up (25 MB)
+        }
         launch_decode_attn(da, R, e->st);
         const bool fuse_gu = L.wgu_t8 && skinny_gu_eligible(R, 2 * d.dec_ff, D);
         const bool fuse_o = fuse_gu && skinny_o_eligible(R, D, e->QD);
@@ -1315,7 +1321,9 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
         ks_down = ks;
         if (pre) continue;                               // the next layer's q|k|v (or the lm_head) consumes the slabs
         const float* nw = (l + 1 < d.dec_layers) ? e->dec[l + 1].ln1 : e->dec_nw;
-        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, dt);
+        PrefetchRange pfq{nullptr, 0};
+        if ((e->opts.decode_prefetch & 4) && l + 1 < d.dec_layers && e->dec[l + 1].wqkv_t) pfq = PrefetchRange{e->dec[l + 1].wqkv_t, (long)e->qkvN * D * 2};
+        launch_add_rmsnorm(e->sx, e->slab, ks, mpad, nw, e->shn, R, D, d.dec_rms_eps, e->st, dt, nullptr, nullptr, &pfq, R < 256 ? 256 - R : 0);
     }
     if (pre) skinny_pre(e->embed_t, e->lslab, d.vocab, e->dec_nw, nullptr, nullptr, nullptr);   // tied lm_head behind the last layer's slabs (the updated residual is not needed again)
     else
@@ -2850,6 +2858,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "gemm256_persist_cus")) { e->opts.gemm256_persist_cus = value > 0 ? value : 256; return SONIC_OK; }
     if (!strcmp(key, "gemm256_gm")) { e->opts.gemm256_gm = value > 0 ? value : 8; return SONIC_OK; }   // raster group height of the 256x256 GEMM (experiments)
     if (!strcmp(key, "i8_defer_thr")) { e->opt_i8_defer_thr = value; return SONIC_OK; }   // int8: outlier lists longer than this go to the dense side product (-1: never)
+    if (!strcmp(key, "decode_prefetch")) { e->opts.decode_prefetch = value; drop_graphs(e); return SONIC_OK; }   // idle-CU weight prefetch (experiment)
     if (!strcmp(key, "decode_attn_occ2")) { e->opts.decode_attn_occ2 = value; drop_graphs(e); return SONIC_OK; }   // decode attention at 128 VGPRs (two blocks per CU can co-reside; A/B)
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }

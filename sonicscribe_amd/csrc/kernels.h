@@ -66,6 +66,8 @@ struct DecodeAttnArgs {
                           // unused partials stay 0
     int* big_out;         // with amax_out: [B][4] how many of the block's outputs are >= 6.0
     long long* kt;        // diagnostics: per-block timestamps (common.h KT)
+    PrefetchRange pf[2];  // experiment (option decode_prefetch): blocks blockIdx.y >= Hkv stream these ranges (weights of later kernels) and exit
+    int pf_y;             // ... that many extra grid rows
 };
 void launch_decode_attn(const DecodeAttnArgs& a, int B, hipStream_t s);
 
@@ -126,7 +128,7 @@ void launch_layernorm(const bf16_t* x, const float* w, const float* b, bf16_t* y
 void launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int rows, int d, float eps, const int* row_map, hipStream_t s, int dt = DT_BF16,
                     const QuantActArgs* qa = nullptr);
 void launch_add_rmsnorm(bf16_t* x, const float* P, int ksplit, int mpad, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s,
-                        int dt = DT_BF16, const DeqInfo* dq = nullptr, const QuantOut* qo = nullptr);
+                        int dt = DT_BF16, const DeqInfo* dq = nullptr, const QuantOut* qo = nullptr, const PrefetchRange* pf = nullptr, int pf_blocks = 0);
 void launch_rmsnorm_ss(const bf16_t* x, const float* SS, const float* w, bf16_t* y, int rows, int d, float eps, hipStream_t s, int dt = DT_BF16);
 void launch_swiglu_slab(const float* P, int ksplit, int mpad, int n2, bf16_t* act, int rows, hipStream_t s, int dt = DT_BF16, int gu8 = 0);
 // int8 decode: int32 gate/up slabs (rows interleaved in 16-row groups as for EPI_SWIGLU) -> act (fp16) + its quantised form
