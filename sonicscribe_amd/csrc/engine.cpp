@@ -164,6 +164,8 @@ struct sonic_engine {
     double host_launch_ms = 0, host_wait_ms = 0; int host_launches = 0;   // host time of the last run's decode loop: inside hipGraphLaunch / waiting for a check
     int step_launches_per_layer = 0;   // of the token step built last (decode_step): sonic_timings.decode_launches_per_layer
     int opt_f32_synth_bf16 = 0;    // SONIC_MODE_F32: sonic_load_synthetic writes the bf16-rounded values (the weights a bf16 engine gets from the same seed) as fp32
+    int opt_decode_gemv = 0;       // 1: token steps of <= 4 rows run the GEMV chain (gemv.hip: five launches per layer, no MFMA tiles); opt-in - another summation order than the
+                                   // MFMA chain, so a request's low bits then depend on whether its step had <= 4 rows.  Measured slower than the MFMA chain (profiles/round6_gemv_ab.txt): an experiment, off
     int opt_no_pre_norm = 0;       // 1: never the PRE form of the <= 2-row decode step (standalone add+RMSNorm launches as for more rows; A/B - same bits)
     int opt_decode_chunk = 2;      // token steps per captured graph = granularity of the early-stop check (sonic_set_option "decode_chunk")
     long long* kt = nullptr; int kt_layer = -1;     // diagnostics ("ktrace" option): in-kernel timestamps of one decoder layer's kernels
@@ -668,7 +670,7 @@ extern "C" int sonic_slot_create(sonic_engine* parent, sonic_engine** out) {
     e->lc = root->lc; e->enc_cs = root->enc_cs; e->dec_cs = root->dec_cs;
     e->opts = root->opts; e->opt_no_graph = root->opt_no_graph; e->opt_no_fused_rope = root->opt_no_fused_rope; e->opt_no_gelu_lut = root->opt_no_gelu_lut;
     e->opt_i8_defer_thr = root->opt_i8_defer_thr; e->opt_i8_no_xq = root->opt_i8_no_xq; e->opt_i8_no_lnq = root->opt_i8_no_lnq; e->opt_i8_no_qkv_fuse = root->opt_i8_no_qkv_fuse;
-    e->opt_decode_chunk = root->opt_decode_chunk; e->opt_no_pre_norm = root->opt_no_pre_norm;
+    e->opt_decode_chunk = root->opt_decode_chunk; e->opt_no_pre_norm = root->opt_no_pre_norm; e->opt_decode_gemv = root->opt_decode_gemv;
     e->weight_bytes = 0; e->finalized = true; e->owner = root;
     root->slots.push_back(e);
     *out = e;
@@ -1253,6 +1255,33 @@ static void decode_step(sonic_engine* e, int R, bool dump) {
     if (e->i8) { decode_step_i8(e, R, dump); return; }
     const sonic_dims& d = e->d;
     const int D = d.dec_d, mpad = ((R + 15) / 16) * 16, dt = e->dt;
+    if (e->opt_decode_gemv && R <= GEMV_MAX_ROWS && d.dec_layers > 0 && e->dec[0].wgu_t8 && gemv_eligible(R, e->qkvN, D, GEMV_SLAB_NORM) && gemv_eligible(R, D, e->QD, GEMV_RESID) &&
+        gemv_eligible(R, 2 * d.dec_ff, D, GEMV_SWIGLU_NORM) && gemv_eligible(R, D, d.dec_ff, GEMV_RESID) && gemv_eligible(R, d.vocab, D, GEMV_SLAB_NORM)) {
+        // 1 - 4 rows, opt-in (gemv.hip): q|k|v (norm inside) -> attention -> o_proj (+ residual) -> gate/up (norm inside, SwiGLU) -> down_proj (+ residual); lm_head (norm inside)
+        e->step_launches_per_layer = 5;
+        auto gv = [&](int mode, const bf16_t* X, long ldx, const bf16_t* W, int N, int K, const float* nw, float* P, bf16_t* resid, bf16_t* act) {
+            GemvArgs g{}; g.X = X; g.ldx = ldx; g.W = W; g.M = R; g.N = N; g.K = K; g.dt = dt; g.norm_w = nw; g.eps = d.dec_rms_eps; g.P = P; g.resid = resid; g.ldr = D; g.act = act;
+            launch_gemv(g, mode, e->st);
+        };
+        for (int l = 0; l < d.dec_layers; ++l) {
+            const DecLayerW& L = e->dec[l];
+            const size_t kvoff = (size_t)l * e->Bm * d.dec_kv_heads * e->max_ctx * d.dec_head_dim;
+            gv(GEMV_SLAB_NORM, e->sx, D, L.wqkv_t, e->qkvN, D, L.ln1, e->slab, nullptr, nullptr);
+            DecodeAttnArgs da{};
+            da.P = e->slab; da.ksplit = 1; da.mpad = mpad; da.cs = e->dec_cs; da.dt = dt;
+            da.Kc = e->Kc + kvoff; da.Vc = e->Vc + kvoff; da.O = e->satt; da.kv_len = e->kv_len; da.Hq = d.dec_heads; da.Hkv = d.dec_kv_heads;
+            da.ctx_max = e->max_ctx; da.scale = 1.0f / sqrtf((float)d.dec_head_dim);
+            launch_decode_attn(da, R, e->st);
+            gv(GEMV_RESID, e->satt, e->QD, L.wo_t, D, e->QD, nullptr, nullptr, e->sx, nullptr);
+            gv(GEMV_SWIGLU_NORM, e->sx, D, L.wgu_t8, 2 * d.dec_ff, D, L.ln2, nullptr, nullptr, e->sact);
+            gv(GEMV_RESID, e->sact, d.dec_ff, L.wdown_t, D, d.dec_ff, nullptr, nullptr, e->sx, nullptr);
+        }
+        gv(GEMV_SLAB_NORM, e->sx, D, e->embed_t, d.vocab, D, e->dec_nw, e->lslab, nullptr, nullptr);
+        GreedyArgs g = greedy_args(e, R, dump);
+        g.ksplit = 1;
+        launch_greedy(g, e->st);
+        return;
+    }
     int ks;
     if (D > 8192) launch_rmsnorm(e->sx, e->dec[0].ln1, e->shn, R, D, d.dec_rms_eps, nullptr, e->st, dt);   // else: done by the greedy kernel of the previous step
     // <= 2 rows (the B = 1 call shape of BASELINE configs 1 and 5; round 6): no standalone add+RMSNorm launch behind down_proj - the next q|k|v projection
@@ -2183,6 +2212,7 @@ extern "C" int sonic_service_begin(sonic_engine* e) {
     if (e->force_d) return fail(e, SONIC_ERR_INVALID, "teacher forcing is set: clear it before continuous decoding");
     hipGraphExec_t gx = nullptr;                            // the chunk graphs exist before the first splice: nothing captures on this stream later
     if (e->Bm >= 2 && !e->i8) TRY(chunk_graph(e, 2, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx, true));   // a pool with at most two occupied rows (round 6: five launches per layer)
+    if (e->Bm >= 4 && !e->i8 && e->opt_decode_gemv) TRY(chunk_graph(e, 4, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx, true));   // ... four, on the GEMV chain (opt-in)
     for (int R = 16; ; R += 16) {                           // one per 16 rows (sonic_service_step runs as many rows as are occupied)
         const int r = R < e->Bm ? R : e->Bm;
         TRY(chunk_graph(e, r, e->opt_decode_chunk > 0 ? e->opt_decode_chunk : 1, &gx, true));
@@ -2255,6 +2285,7 @@ extern "C" int sonic_service_step(sonic_engine* e, int n_chunks, int rows, int32
     int R = rows <= 0 || rows > e->Bm ? e->Bm : (rows + 15) / 16 * 16;
     if (R > e->Bm) R = e->Bm;
     if (rows > 0 && rows <= 2 && e->Bm >= 2 && !e->i8) R = 2;      // one or two sessions' rows: the <= 2-row step (same bits per row as any other row count)
+    else if (rows > 0 && rows <= 4 && e->Bm >= 4 && !e->i8 && e->opt_decode_gemv) R = 4;
     auto read_check = [&](bool block) -> int {
         const int i = (int)(e->svc_checked % CHK_RING);
         if (!block) { const hipError_t q = hipEventQuery(e->chk_ev[i]); if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; } if (q != hipSuccess) return -1; }
@@ -2863,6 +2894,7 @@ extern "C" int sonic_set_option(sonic_engine* e, const char* key, int value) {
     if (!strcmp(key, "decode_attn_v1")) { e->opts.decode_attn_v1 = value; drop_graphs(e); return SONIC_OK; }   // round 2's VALU P.V decode attention (A/B)
     if (!strcmp(key, "prefill_taps")) { e->taps_on = value; return SONIC_OK; }
     if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }
+    if (!strcmp(key, "decode_gemv")) { e->opt_decode_gemv = value; drop_graphs(e); return SONIC_OK; }
     if (!strcmp(key, "f32_synth_bf16")) { e->opt_f32_synth_bf16 = value; return SONIC_OK; }
     if (!strcmp(key, "no_pre_norm")) { e->opt_no_pre_norm = value; drop_graphs(e); return SONIC_OK; }   // <= 2 rows: standalone add+RMSNorm launches as for more rows (A/B, same bits)
     if (!strcmp(key, "no_graph")) { e->opt_no_graph = value; return SONIC_OK; }            // eager decode loop (debugging)

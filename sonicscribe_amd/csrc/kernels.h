@@ -212,3 +212,18 @@ void launch_f32_zero_pad_rows(float* h, int W, int n_frames, int C, hipStream_t 
 void launch_f32_assemble(const int* src, const float* table, const float* audio, float* x, int n_tok, int d, hipStream_t s);
 void launch_f32_kv_append(const float* kn, const float* vn, float* Kc, float* Vc, const int* seq, const int* pos, int n_tok, int kd, long seq_stride, hipStream_t s);
 void launch_f32_swiglu(const float* g, const float* u, float* act, long n, hipStream_t s);
+
+// ---- the 1 - 4 row token step as weight-streaming GEMV kernels (gemv.hip; option decode_gemv) ----
+#define GEMV_MAX_ROWS 4
+enum { GEMV_SLAB_NORM = 0 /* P[r][n] = (RMSNorm(X) . norm_w) W^T, fp32 */, GEMV_RESID = 1 /* resid += X W^T */, GEMV_SWIGLU_NORM = 2 /* act = silu(g) * u of (RMSNorm(X) . norm_w) Wgu^T */ };
+struct GemvArgs {
+    const bf16_t* X; long ldx;       // [M <= 4][K] activation rows (the raw residual stream for the *_NORM modes)
+    const bf16_t* W;                 // [N][K] fragment-tiled (launch_tile_weights; gate/up: launch_tile_weights_gu8)
+    int M, N, K, dt;
+    const float* norm_w; float eps;  // *_NORM modes: RMSNorm weight [K]
+    float* P;                        // GEMV_SLAB_NORM: fp32 [M][N] (one "slab" for decode_attn_kernel / greedy_kernel)
+    bf16_t* resid; long ldr;         // GEMV_RESID: residual rows, updated in place
+    bf16_t* act;                     // GEMV_SWIGLU_NORM: [M][N / 2]
+};
+void launch_gemv(const GemvArgs& a, int mode, hipStream_t s);
+bool gemv_eligible(int M, int N, int K, int mode);
