@@ -310,7 +310,10 @@ SONIC_API int sonic_debug_ktrace(sonic_engine* e, int64_t* out, int64_t n);
 /* per-engine experiment knobs: "skinny_variant", "gemm_force128", "gemm256_stagger", "prefill_taps", "no_fused_gu",
  * "no_graph" (eager decode loop), "decode_chunk" (token steps per hipGraph launch = granularity of the early-stop check and of row splices, default 2),
  * "decode_lookahead" (start value of the adaptive queue depth of the decode loop, in chunks), "gemm_timing" (HIP events around every encoder-layer GEMM launch -> sonic_timings.enc_gemm_*),
- * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table) */
+ * "no_fused_rope" (encoder RoPE as its own pass), "no_gelu_lut" (fc1 GELU by arithmetic instead of the LDS table); the full list with what each one measured is in
+ * DESIGN.md 1.  Round 6: "no_pre_norm" (<= 2 rows: standalone add + RMSNorm launches instead of the five-launch chain; same bits), "decode_gemv" / "decode_prefetch" /
+ * "decode_attn_occ2" (experiments that lost: profiles/round6_*), "f32_synth_bf16" (SONIC_MODE_F32: sonic_load_synthetic writes the bf16-rounded values),
+ * "inject_dev_err" (tests: sets / clears the device error word) */
 SONIC_API int sonic_set_option(sonic_engine* e, const char* key, int value);
 
 #ifdef __cplusplus
