@@ -93,16 +93,17 @@ def test_full_depth_product_paths_against_the_fp32_kind():
       * the bf16 product path (every production kernel, 60 layers deep) stays within a bf16-sized distance of the fp32 arithmetic: measured max |dlogit| 0.104,
         mean 0.0145 on logits in [-4.8, 4.3]; bounds 0.125 (8 bf16 ulp of 2^-6, the full-depth bound of the oracle tests) and 0.02;
       * its argmax equals the fp32 argmax wherever the fp32 top-1 / top-2 margin exceeds twice that bound;
-      * the fp16 kind of the same templates (SONIC_MODE_F16) is 9 x closer, as its rounding is: measured max 0.0115, mean 0.0016; bounds 0.02 / 0.003.
+      * the fp16 kind of the same templates (SONIC_MODE_F16) is 9 x closer, as its rounding is: measured max 0.0115, mean 0.0016; bounds 0.02 / 0.003;
+      * the int8 mode (LLM.int8 linears, asr.py:169-210) on the same weights: measured max 0.229, mean 0.036 - the quantisation's distance; bounds 0.5 / 0.06.
     HF semantics: asr.py:407-422 (generate), modeling_glmasr.py:171-346, modeling_llama.py:217-324."""
-    from sonicscribe_amd.engine import Engine, MODE_F16, MODE_F32, MODE_NATIVE
+    from sonicscribe_amd.engine import Engine, MODE_F16, MODE_F32, MODE_INT8, MODE_NATIVE
     d = replace(spec.FULL, eos_ids=())
     segs = [synth.synth_pcm(70, 20 * 16000), synth.synth_pcm(71, 5 * 16000)]
     prompts = [[1, 17, 23, 5] + [d.audio_token_id] * spec.audio_token_count(spec.valid_frames(len(s))) + [7, 301, 302, 303, 9, 11] for s in segs]
     rng = np.random.default_rng(17)
     force = rng.integers(2, 59000, size=(2, 8)).astype(np.int32)
     out = {}
-    for tag, mode in (("fp32", MODE_F32), ("bf16", MODE_NATIVE), ("fp16", MODE_F16)):
+    for tag, mode in (("fp32", MODE_F32), ("bf16", MODE_NATIVE), ("fp16", MODE_F16), ("int8", MODE_INT8)):
         e = Engine(d, 0, mode, max_batch=2, max_ctx=512)
         if mode == MODE_F32:
             e.set_option("f32_synth_bf16", 1)
@@ -117,7 +118,9 @@ def test_full_depth_product_paths_against_the_fp32_kind():
     assert np.isfinite(truth).all() and truth.std() > 0.3
     srt = np.sort(truth, axis=-1)
     margin = srt[..., -1] - srt[..., -2]
-    for tag, bound_max, bound_mean in (("bf16", 0.125, 0.02), ("fp16", 0.02, 0.003)):
+    # int8 = LLM.int8 linears (asr.py:169-210) on the same weights: its distance is the quantisation's, reported and bounded loosely (parity of that mode is unpinned:
+    # bitsandbytes is absent; what is pinned is the restated algorithm, tests/test_gpu_int8.py)
+    for tag, bound_max, bound_mean in (("bf16", 0.125, 0.02), ("fp16", 0.02, 0.003), ("int8", 0.5, 0.06)):
         dl = np.abs(out[tag] - truth)
         agree = out[tag].argmax(-1) == truth.argmax(-1)
         print(f"full depth (32 + 28 layers, vocabulary 59264), 2 rows x 8 steps, {tag} product path vs the fp32 kind: max |dlogit| {dl.max():.4f}, mean {dl.mean():.5f}, "
