@@ -154,8 +154,13 @@ struct GemmI8 {
     // in defer_out (same row pitch as C; no outlier sum, no residual) and launch_i8_outlier_side finishes them with a dense fp16 MFMA
     // product over the gathered columns.  NULL: every list is walked in the epilogue (O(columns) scalar loads per output element).
     bf16_t* defer_out; int defer_thr;
-    const int8_t* wk;                 // k-major copy of W ([K][N]) for the outlier columns when GemmArgs.W is the fragment-tiled copy (GemmArgs.w_tiled); NULL: W is row-major
+    // (rounds 3 - 5 had `wk` here: a k-major copy of W for the outlier columns of a tiled operand.  Round 6 gathers them from the tiled copy itself - i8_tiled_row_off /
+    //  i8_tiled_k_off with GemmArgs.w_tiled - and the copy is gone: 1.29 GB at full size)
 };
+
+// byte offset of W[n][k] inside the fragment-tiled int8 copy (launch_tile_weights_i8: (16-row, 64-k) tiles of 1 KiB): the row part and the k part add
+__host__ __device__ __forceinline__ long i8_tiled_row_off(int n, int K) { return (long)(n >> 4) * (K >> 6) * 1024 + (long)(n & 15) * 16; }   // consecutive n of a 16-row group: 16 bytes apart
+__host__ __device__ __forceinline__ long i8_tiled_k_off(int k) { return ((long)(k >> 6) << 10) + (((k >> 4) & 3) << 8) + (k & 15); }
 
 struct GemmArgs {
     const bf16_t* A; long lda;       // [M][K] row stride lda (elements); lda < K allowed (overlapping im2col rows).  int8 GEMM: int8_t data

@@ -882,7 +882,8 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
         TRY(dalloc_big(e, &q->cbt, (size_t)N * K, false));
         launch_tile_weights_i8(q->cb, q->cbt, N, K, e->st);
         e->weight_bytes += (int64_t)N * K;
-        if (!getenv("SONIC_NO_CBK")) {           // k-major copy for the decode consumers' outlier gathers (8 consecutive bytes instead of 8 sectors)
+        if (getenv("SONIC_KEEP_CBK")) {          // k-major copy for the outlier gathers (8 consecutive bytes instead of 8 strided ones): rounds 3 - 5's default, now the A/B -
+                                                 // round 6 gathers outlier columns from the tiled copy itself (1.29 GB less at full size: 3 683 -> 2 394 MiB)
             TRY(dalloc_big(e, &q->cbk, (size_t)N * K, false));
             launch_transpose_i8(q->cb, q->cbk, N, K, e->st);
             e->weight_bytes += (int64_t)N * K;
@@ -891,7 +892,7 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
     HIPC(e, stream_sync(e));
     for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)*w16) { e->allocs.erase(it); break; }
     (void)hipFree(*w16); *w16 = nullptr; e->alloc_bytes -= (int64_t)N * K * 2;
-    if (q->cbt && q->cbk && !getenv("SONIC_KEEP_ROWMAJOR")) {
+    if (q->cbt && !getenv("SONIC_KEEP_ROWMAJOR")) {
         // the row-major int8 matrix was the prefill GEMM's operand and its outlier-column source: the tiled and the k-major copy serve both now
         for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it) if (*it == (void*)q->cb) { e->allocs.erase(it); break; }
         (void)hipFree(q->cb); q->cb = nullptr; q->cb_rowmajor_kept = false;
@@ -1079,7 +1080,7 @@ static bool qlinear(sonic_engine* e, int epi, const bf16_t* X, long ldx, const b
     GemmArgs a{};
     a.A = (const bf16_t*)e->qa; a.lda = K; a.W = (const bf16_t*)q.cb; a.C = C; a.ldc = ldc; a.bias = bias; a.R = R; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dt = DT_F16;
     // decoder projections: ONE int8 operand copy since round 5 - the fragment-tiled one of the decode step (+ the k-major copy for outlier columns)
-    if (q.cbt && q.cbk && (!e->opt_prefill_rowmajor || !q.cb_rowmajor_kept)) { a.W = (const bf16_t*)q.cbt; a.w_tiled = 1; a.q.wk = q.cbk; }
+    if (q.cbt && (!e->opt_prefill_rowmajor || !q.cb_rowmajor_kept)) { a.W = (const bf16_t*)q.cbt; a.w_tiled = 1; }     // (outlier columns are gathered from the tiled copy)
     a.q.sca = e->q_sca; a.q.scb = q.scb; a.q.x16 = X; a.q.ldx16 = ldx; a.q.oc_cnt = e->q_oc_cnt; a.q.oc_list = e->q_oc_list; a.q.oc_ld = e->q_kmax;
     a.q.row_group = grp.gmap; a.q.group_div = grp.gdiv;
     // int8 q|k|v: RoPE + V^T inside the GEMM's epilogue (round 3; the register form of the 16-bit kinds spilled beside the dequantisation, the int8

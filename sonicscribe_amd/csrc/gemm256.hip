@@ -488,13 +488,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 const int cnt = rws[0].cnt;
                 const int* lst = a.q.oc_list + (long)rws[0].g * a.q.oc_ld;
                 const f16_t* xb = (const f16_t*)a.q.x16;
-                // W[nc + j][k]: from the row-major matrix (rows K apart, k contiguous) or, GemmI8.wk (W is the fragment-tiled copy), from the k-major one
-                // (rows contiguous, k N apart) - one loop, two strides
-                const int8_t* wb = a.q.wk ? a.q.wk + nc : (const int8_t*)a.W + (long)nc * a.K;
-                const int wsj = a.q.wk ? 1 : a.K, wsk = a.q.wk ? a.N : 1;
+                // W[nc + j][k]: from the row-major matrix (rows K apart, k contiguous)
+                // ... or (round 6: w_tiled without a k-major copy) from the fragment-tiled copy itself: the four columns nc .. nc + 3 lie in one 16-row group,
+                // 16 bytes apart; the k part of the address is i8_tiled_k_off(k)
+                const bool tg = a.w_tiled != 0;
+                const int8_t* wb = tg ? (const int8_t*)a.W + i8_tiled_row_off(nc, a.K) : (const int8_t*)a.W + (long)nc * a.K;
+                const int wsj = tg ? 16 : a.K;
                 for (int i = 0; i < cnt; ++i) {
                     const int k = lst[i];
-                    const int8_t* wp = wb + (long)k * wsk;
+                    const int8_t* wp = wb + (tg ? i8_tiled_k_off(k) : (long)k);
                     float wd[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) wd[j] = rT<f16_t>(__fmul_rn(__fmul_rn((float)wp[j * wsj], sb[j]), INT8_DEQ_W));

@@ -353,15 +353,15 @@ __device__ __forceinline__ float i8_add_outliers(const GemmI8& q, const int8_t* 
     return rT<f16_t>(__fadd_rn(v, a2));
 }
 
-// the same sum with W[n][k] taken from the k-major copy (wc = wk + n, element k at wc[k * N]): the prefill GEMMs of the decoder read the fragment-tiled
-// weights since round 5 and their row-major int8 copy is gone.  Compiled only into the epilogues that can meet such an operand (gemm_lin<KD, WK>):
-// in the GELU epilogue the second list walk made the encoder's int8 fc1 kernel keep its accumulators in scratch.
-__device__ __forceinline__ float i8_add_outliers_k(const GemmI8& q, const int8_t* wc, int N, float sb, int g, int cnt, long m, float v) {
+// W[n][k] from the fragment-tiled copy: the prefill GEMMs of the decoder read the decode step's tiled weights since round 5 (their row-major int8 copy is gone) and,
+// since round 6, gather the outlier columns from it too (rounds 3 - 5 kept a k-major copy for that: 1.29 GB at full size).  wt = W + i8_tiled_row_off(n, K), element k at
+// i8_tiled_k_off(k).  Compiled only into the epilogues that can meet such an operand (gemm_lin<KD, WK>).
+__device__ __forceinline__ float i8_add_outliers_t(const GemmI8& q, const int8_t* wt, float sb, int g, int cnt, long m, float v) {
     const f16_t* xr = (const f16_t*)q.x16 + m * q.ldx16;
     float a2 = 0.f;
     for (int i = 0; i < cnt; ++i) {
         const int k = q.oc_list[(long)g * q.oc_ld + i];
-        a2 = __fmaf_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn((float)wc[(long)k * N], sb), INT8_DEQ_W)), a2);
+        a2 = __fmaf_rn((float)xr[k], rT<f16_t>(__fmul_rn(__fmul_rn((float)wt[i8_tiled_k_off(k)], sb), INT8_DEQ_W)), a2);
     }
     return rT<f16_t>(__fadd_rn(v, a2));
 }
@@ -382,7 +382,7 @@ __device__ __forceinline__ I8Row i8_row(const GemmArgs& a, int m) {
 // Linear output of one accumulator element as a float that is exactly representable in the output type: 16-bit kinds round
 // acc + bias once; the int8 kind applies the LLM.int8 dequantisation (sonic_oracle.c linear_int8) and adds the outlier columns.
 // rw: the row's metadata (i8_row), sb: SCB[n] (int8 kind only).
-// WK: the epilogue may meet GemmI8.wk (decoder projections; never the GELU epilogue - compiled into it, the second addressing form made the
+// WK: the epilogue may meet a fragment-tiled W (GemmArgs.w_tiled: decoder projections; never the GELU epilogue - compiled into it, the second addressing form made the
 // encoder's int8 fc1 kernel keep its accumulators in scratch).
 template <typename KD, bool WK = true, typename AccE>
 __device__ __forceinline__ float gemm_lin(const GemmArgs& a, AccE accv, int m, int n, float bias, const I8Row& rw, float sb) {
@@ -390,7 +390,8 @@ __device__ __forceinline__ float gemm_lin(const GemmArgs& a, AccE accv, int m, i
     if constexpr (KD::I8) {
         float v = rT<f16_t>(fmaf((float)accv, __fmul_rn(__fmul_rn(rw.sa, sb), MM_DEQUANT_CONST), bias));
         if (rw.cnt > 0) {
-            if (WK && a.q.wk) v = i8_add_outliers_k(a.q, a.q.wk + n, a.N, sb, rw.g, rw.cnt, m, v);
+            // (two addressing forms only: a third one - the k-major copy of rounds 3 - 5 beside these - put 528 bytes of the 256x256 int8 kernels' registers into scratch)
+            if (WK && a.w_tiled) v = i8_add_outliers_t(a.q, (const int8_t*)a.W + i8_tiled_row_off(n, a.K), sb, rw.g, rw.cnt, m, v);
             else v = i8_add_outliers(a.q, (const int8_t*)a.W + (long)n * a.K, sb, rw.g, rw.cnt, m, v);
         }
         return v;

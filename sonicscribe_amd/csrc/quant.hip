@@ -193,7 +193,7 @@ void launch_quant_act(const QuantActArgs& a, hipStream_t s) {
 struct OutlierSideArgs {
     const f16_t* x16; long ldx;              // unquantised activations [M][K]
     const int8_t* cb; const float* scb;      // weights [N][K] row-wise int8 + row absmax
-    const int8_t* cbk;                       // ... or (cb == NULL) their k-major copy [K][N]
+    const int8_t* cbt;                       // ... or (cb == NULL) the fragment-tiled copy (i8_tiled_row_off / i8_tiled_k_off)
     const f16_t* tmp; const f16_t* R; long ldr; f16_t* C; long ldc;   // v in, residual in, out (tmp has C's pitch)
     const int* oc_cnt; const int* oc_list; int oc_ld, thr;
     const int* row_group; int group_div; int row_off;     // group of row m = row_group[(m + row_off) / group_div], as the GEMM's epilogue (int8_util.h i8_row)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void i8_outlier_side_kernel(OutlierSideArgs a)
             for (int i = tid; i < RN * 32; i += 256) {
                 const int r = i >> 5, c = i & 31, n = n0 + r;
                 f16_t v = (f16_t)0.f;
-                if (k0 + c < cnt && n < a.N) v = (f16_t)rT<f16_t>(__fmul_rn(__fmul_rn((float)(a.cb ? a.cb[(long)n * a.K + lst[k0 + c]] : a.cbk[(long)lst[k0 + c] * a.N + n]), a.scb[n]), INT8_DEQ_W));
+                if (k0 + c < cnt && n < a.N) v = (f16_t)rT<f16_t>(__fmul_rn(__fmul_rn((float)(a.cb ? a.cb[(long)n * a.K + lst[k0 + c]] : a.cbt[i8_tiled_row_off(n, a.K) + i8_tiled_k_off(lst[k0 + c])]), a.scb[n]), INT8_DEQ_W));
                 *(f16_t*)(sw + r * XP + c * 2) = v;
             }
             __syncthreads();
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void i8_outlier_side_kernel(OutlierSideArgs a)
 void launch_i8_outlier_side(const GemmArgs& g, hipStream_t s) {
     if (!g.q.defer_out || g.M <= 0) return;
     OutlierSideArgs a{};
-    a.x16 = (const f16_t*)g.q.x16; a.ldx = g.q.ldx16; a.cb = g.q.wk ? nullptr : (const int8_t*)g.W; a.cbk = g.q.wk; a.scb = g.q.scb;
+    a.x16 = (const f16_t*)g.q.x16; a.ldx = g.q.ldx16; a.cb = g.w_tiled ? nullptr : (const int8_t*)g.W; a.cbt = g.w_tiled ? (const int8_t*)g.W : nullptr; a.scb = g.q.scb;
     a.tmp = (const f16_t*)g.q.defer_out; a.R = (const f16_t*)g.R; a.ldr = g.ldr; a.C = (f16_t*)g.C; a.ldc = g.ldc;
     a.oc_cnt = g.q.oc_cnt; a.oc_list = g.q.oc_list; a.oc_ld = g.q.oc_ld; a.thr = g.q.defer_thr;
     a.row_group = g.q.row_group; a.group_div = g.q.group_div; a.row_off = g.q.row_off; a.M = g.M; a.N = g.N; a.K = g.K;
