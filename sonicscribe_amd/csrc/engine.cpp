@@ -874,7 +874,7 @@ static int to_f32(sonic_engine* e, const std::string& name, float** out) {
     return SONIC_OK;
 }
 // int8 mode: row-wise int8 of a packed [N][K] fp16 matrix (Int8Params.cuda()); the 16-bit matrix is released afterwards
-static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool tiled) {
+static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool tiled, bool kmajor = false) {
     TRY(dalloc(e, &q->cb, (size_t)N * K, false)); TRY(dalloc(e, &q->scb, (size_t)N, false));
     launch_quant_weights(*w16, q->cb, q->scb, N, K, e->st);
     e->weight_bytes += (int64_t)N * K + (int64_t)N * 4 - (int64_t)N * K * 2;
@@ -882,8 +882,12 @@ static int quantize(sonic_engine* e, bf16_t** w16, int N, int K, QW* q, bool til
         TRY(dalloc_big(e, &q->cbt, (size_t)N * K, false));
         launch_tile_weights_i8(q->cb, q->cbt, N, K, e->st);
         e->weight_bytes += (int64_t)N * K;
-        if (getenv("SONIC_KEEP_CBK")) {          // k-major copy for the outlier gathers (8 consecutive bytes instead of 8 strided ones): rounds 3 - 5's default, now the A/B -
-                                                 // round 6 gathers outlier columns from the tiled copy itself (1.29 GB less at full size: 3 683 -> 2 394 MiB)
+        // k-major copy for the decode consumers' outlier gathers (8 consecutive bytes per outlier column and 8 outputs; from the tiled copy the same 8 bytes lie in 8
+        // different 16-byte pieces: 16 x the cache lines).  Rounds 3 - 5 kept it for all four decoder projections (1.29 GB at full size); round 6 keeps it only where it
+        // pays - o_proj and down_proj, whose consumer (add + RMSNorm: one block per row walking the row's whole outlier list over 2048 outputs) got 25 % slower without it -
+        // and lets the prefill epilogues, the side product, the attention prologue and SwiGLU gather from the tiled copy: 3 683 -> 2 865 MiB at the same step time.
+        // SONIC_KEEP_CBK=1: all four (A/B); SONIC_NO_CBK=1: none (2 395 MiB, the 64-row step +4.9 %).
+        if ((kmajor && !getenv("SONIC_NO_CBK")) || getenv("SONIC_KEEP_CBK")) {
             TRY(dalloc_big(e, &q->cbk, (size_t)N * K, false));
             launch_transpose_i8(q->cb, q->cbk, N, K, e->st);
             e->weight_bytes += (int64_t)N * K;
@@ -985,8 +989,8 @@ extern "C" int sonic_finalize_weights(sonic_engine* e) {
         };
         L.wgu_t8 = nullptr; L.wqkv_t = L.wo_t = L.wgu_t = L.wdown_t = nullptr;
         if (e->i8) {
-            TRY(quantize(e, &L.wqkv, e->qkvN, d.dec_d, &L.qqkv, true)); TRY(quantize(e, &L.wo, d.dec_d, e->QD, &L.qo, true));
-            TRY(quantize(e, &L.wgu, 2 * d.dec_ff, d.dec_d, &L.qgu, true)); TRY(quantize(e, &L.wdown, d.dec_d, d.dec_ff, &L.qdown, true));
+            TRY(quantize(e, &L.wqkv, e->qkvN, d.dec_d, &L.qqkv, true)); TRY(quantize(e, &L.wo, d.dec_d, e->QD, &L.qo, true, true));
+            TRY(quantize(e, &L.wgu, 2 * d.dec_ff, d.dec_d, &L.qgu, true)); TRY(quantize(e, &L.wdown, d.dec_d, d.dec_ff, &L.qdown, true, true));
             continue;
         }
         TRY(tiled(L.wqkv, &L.wqkv_t, e->qkvN, d.dec_d)); TRY(tiled(L.wo, &L.wo_t, d.dec_d, e->QD));
